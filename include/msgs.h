@@ -1,0 +1,196 @@
+/*
+ * msgs.h — C ABI of libmsgs_hip.so, the MI355X (gfx950) multi-scale 3D-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the reference's un-vendored native module
+ * `diff_gaussian_rasterization._C` (imported at /root/reference/gaussian_renderer/__init__.py:14,
+ * constructed :37-55, called :94-108).  The reference binds that module with pybind11/torch; this
+ * library is bound with ctypes from ms-gs_amd/diff_gaussian_rasterization/__init__.py (see
+ * INTEGRATION.md for the stub a maintainer adds).  Plain pointers and sizes only: no torch types,
+ * no C++ types, nothing thrown across the boundary.
+ *
+ *   reference entry point (upstream name)                 replaced by
+ *   ---------------------------------------------------   ---------------------------------------
+ *   _C.rasterize_gaussians(...)            (forward)      msgs_forward_stage1 + msgs_forward_stage2
+ *   _C.rasterize_gaussians_backward(...)   (backward)     msgs_backward
+ *   _C.mark_visible(...)                   (unused by the reference)
+ *                                                          msgs_mark_visible
+ *   resize-callback byte tensors (geom/binning/img state)  msgs_*_bytes size queries; the CALLER
+ *                                                          allocates (torch caching allocator) and
+ *                                                          keeps the buffers alive for backward
+ *
+ * Ownership: every pointer is owned by the caller; the library never allocates device memory,
+ * never frees or retains a pointer past the call.  All `const float*` / `float*` arguments are
+ * DEVICE pointers unless the name says `host`.  Calls are asynchronous on `stream` except that
+ * msgs_forward_stage1 synchronises the stream once to return the instance count (the same D2H
+ * `num_rendered` read the reference's forward performs).
+ *
+ * Threading: re-entrant and stateless (forward is called from the Python main thread, backward
+ * from PyTorch's autograd thread).
+ *
+ * Return value: 0 = MSGS_OK; < 0 = invalid argument / capacity (MSGS_ERR_*); > 0 = hipError_t.
+ */
+#ifndef MSGS_H_
+#define MSGS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSGS_ABI_VERSION 1
+
+#define MSGS_OK 0
+#define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
+#define MSGS_ERR_CAPACITY (-2)     /* a caller-supplied buffer is smaller than the size query says   */
+#define MSGS_ERR_TOO_MANY (-3)     /* more than 2^32-1 tile instances                                */
+#define MSGS_ERR_SH_DEGREE (-4)    /* sh_degree outside 0..3 or (sh_degree+1)^2 > sh_coeffs          */
+
+#define MSGS_TILE 16               /* 16x16 pixel tiles                     */
+
+/* View / raster settings: the 15 fields of GaussianRasterizationSettings
+ * (/root/reference/gaussian_renderer/__init__.py:37-53). */
+typedef struct msgs_view {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    float fade_size;
+    int32_t sh_degree;        /* active degree 0..3                                                 */
+    int32_t sh_coeffs;        /* K: coefficients stored per Gaussian in `shs` ((max_degree+1)^2)    */
+    int32_t filter_small;     /* bool */
+    int32_t filter_large;     /* bool */
+    int32_t prefiltered;      /* bool (accepted; the reference always passes False)                  */
+    int32_t debug;            /* bool: synchronise + return the first HIP error after every stage   */
+    const float* bg;          /* [3]   device                                                        */
+    const float* viewmatrix;  /* [16]  device; world_view_transform = W2C^T row-major (cameras.py:54) */
+    const float* projmatrix;  /* [16]  device; full_proj_transform (cameras.py:55-56)                */
+    const float* campos;      /* [3]   device; camera_center (cameras.py:57)                         */
+} msgs_view_t;
+
+/* Per-Gaussian inputs: the 13 kwargs of GaussianRasterizer.forward
+ * (/root/reference/gaussian_renderer/__init__.py:95-107).  means2D carries no data forward (it is
+ * the gradient sink, :27-31) and therefore only appears in msgs_backward. */
+typedef struct msgs_gaussians {
+    int32_t P;
+    int32_t reserved;
+    const float* means3D;          /* [P,3]                                                          */
+    const float* shs;              /* [P,K,3]  xor colors_precomp                                    */
+    const float* colors_precomp;   /* [P,3]                                                          */
+    const float* opacities;        /* [P] (the reference passes [P,1])                               */
+    const float* scales;           /* [P,3]    with rotations, xor cov3D_precomp                     */
+    const float* rotations;        /* [P,4]    (w,x,y,z), pre-normalised (gaussian_model.py:132-133) */
+    const float* cov3D_precomp;    /* [P,6]    xx,xy,xz,yy,yz,zz (general_utils.py:64-73)            */
+    const float* max_pixel_sizes;  /* [P]      -1 = unset (gaussian_model.py:224)                    */
+    const float* min_pixel_sizes;  /* [P]      -1 = unset (gaussian_model.py:225)                    */
+    const float* occ_multiplier;   /* [P,4]    accepted; identity semantics (DESIGN.md SPEC M5)      */
+    const float* dc_delta;         /* [P,12]   accepted; identity semantics (DESIGN.md SPEC M5)      */
+    const uint8_t* base_mask;      /* [P]      bool                                                  */
+} msgs_gaussians_t;
+
+/* Gradient outputs of msgs_backward.  Every non-NULL buffer is fully written (zeros for
+ * Gaussians that were not rendered), so the caller may pass uninitialised memory. */
+typedef struct msgs_grads {
+    float* dL_dmeans3D;        /* [P,3]                                                              */
+    float* dL_dmeans2D;        /* [P,3]   (x,y in the NDC-ish units of SURVEY App. A.3; z = 0)       */
+    float* dL_dshs;            /* [P,K,3] when shs was given                                         */
+    float* dL_dcolors;         /* [P,3]   when colors_precomp was given                              */
+    float* dL_dopacities;      /* [P]                                                                */
+    float* dL_dscales;         /* [P,3]   when scales/rotations were given                           */
+    float* dL_drotations;      /* [P,4]                                                              */
+    float* dL_dcov3D;          /* [P,6]   when cov3D_precomp was given                               */
+} msgs_grads_t;
+
+/* Optional per-kernel timing (bench.py's roofline leg).  The caller owns the events; the library
+ * records ev[2*k] before and ev[2*k+1] after kernel class k on `stream`.  NULL = no timing. */
+enum {
+    MSGS_K_PREPROCESS = 0, MSGS_K_DEPTH_SORT = 1, MSGS_K_SCAN = 2, MSGS_K_EMIT = 3,
+    MSGS_K_TILE_SORT = 4, MSGS_K_RANGES = 5, MSGS_K_BLEND_FWD = 6, MSGS_K_BLEND_BWD = 7,
+    MSGS_K_PREPROCESS_BWD = 8, MSGS_K_COUNT = 9
+};
+typedef struct msgs_timing {
+    void* ev[2 * MSGS_K_COUNT];   /* hipEvent_t handles created by the caller (msgs_timing_create) */
+} msgs_timing_t;
+
+int msgs_abi_version(void);
+const char* msgs_error_string(int code);
+
+/* ---- size queries (bytes) -------------------------------------------------------------------- */
+/* per-Gaussian state written by stage 1, read by stage 2 and by backward */
+size_t msgs_geom_bytes(int32_t P);
+/* scratch of stage 1 (depth sort double buffers, scan partials); dead after stage 1 returns */
+size_t msgs_stage1_scratch_bytes(int32_t P);
+/* per-instance state written by stage 2 (sorted Gaussian ids + tile ranges), read by backward */
+size_t msgs_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
+/* scratch of stage 2 (tile sort double buffers, histograms); dead after stage 2 returns */
+size_t msgs_stage2_scratch_bytes(int64_t num_instances, int32_t width, int32_t height);
+/* per-pixel state written by stage 2 (final transmittance, last contributor), read by backward */
+size_t msgs_image_bytes(int32_t width, int32_t height);
+/* scratch of backward (per-Gaussian 2-D gradient records) */
+size_t msgs_backward_scratch_bytes(int32_t P);
+
+/* ---- forward --------------------------------------------------------------------------------- */
+/* Stage 1: preprocess (projection, EWA splat, SH->RGB, pixel size, multi-scale filters, exact
+ * tile-overlap count), depth sort of the Gaussians, exclusive scan of the overlap counts.
+ * Writes radii[P] (int32, 0 = not rendered) and pixel_sizes[P]; returns the number of tile
+ * instances through *num_instances_host after ONE stream synchronisation. */
+int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g,
+                        int32_t* radii, float* pixel_sizes,
+                        void* geom, size_t geom_bytes,
+                        void* scratch, size_t scratch_bytes,
+                        int64_t* num_instances_host,
+                        const msgs_timing_t* timing, void* stream);
+
+/* Stage 2: emit (tile, Gaussian) instances in depth order, stable radix sort by tile, tile ranges,
+ * per-tile front-to-back alpha blend.  Writes out_color[3,H,W], out_acc_pixel_size[H,W],
+ * out_depth[H,W]. */
+int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g,
+                        const void* geom, size_t geom_bytes,
+                        int64_t num_instances,
+                        void* binning, size_t binning_bytes,
+                        void* scratch, size_t scratch_bytes,
+                        void* image_state, size_t image_bytes,
+                        float* out_color, float* out_acc_pixel_size, float* out_depth,
+                        const msgs_timing_t* timing, void* stream);
+
+/* ---- backward -------------------------------------------------------------------------------- */
+/* dL_dcolor is [3,H,W].  acc_pixel_size / depth / pixel_sizes carry no gradient (they never
+ * enter the reference's loss, /root/reference/train.py:205-216). */
+int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g,
+                  const int32_t* radii,
+                  const void* geom, size_t geom_bytes,
+                  int64_t num_instances,
+                  const void* binning, size_t binning_bytes,
+                  const void* image_state, size_t image_bytes,
+                  const float* dL_dcolor,
+                  void* scratch, size_t scratch_bytes,
+                  const msgs_grads_t* grads,
+                  const msgs_timing_t* timing, void* stream);
+
+/* ---- optional -------------------------------------------------------------------------------- */
+/* visibility mask only (upstream markVisible; present[P] uint8) */
+int msgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present, void* stream);
+
+/* Statistics of the last-built binning (for the algorithmic-bytes formula of DESIGN.md):
+ * out_host[0] = sum over tiles of max-over-pixels last contributor (D_trav),
+ * out_host[1] = number of Gaussians with radii > 0 (V).  Synchronises `stream`. */
+int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
+                       const void* binning, size_t binning_bytes,
+                       const void* image_state, size_t image_bytes,
+                       void* scratch, size_t scratch_bytes,
+                       int64_t* out_host, void* stream);
+
+/* timing helpers: create/destroy the 2*MSGS_K_COUNT events and read elapsed ms per kernel class
+ * (ms_host[MSGS_K_COUNT]; a class that was not recorded reads as -1).  The caller synchronises
+ * the stream before msgs_timing_read. */
+int msgs_timing_create(msgs_timing_t* t);
+int msgs_timing_destroy(msgs_timing_t* t);
+int msgs_timing_read(const msgs_timing_t* t, float* ms_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGS_H_ */

@@ -1,0 +1,655 @@
+/*
+ * msgs_oracle.cpp — float32 CPU restatement of the multi-scale 3D-Gaussian rasterizer
+ * (preprocess -> duplicate with (tile, depth) keys -> stable sort -> tile ranges -> per-tile
+ * front-to-back blend; back-to-front blend backward -> 2-D covariance backward -> preprocess
+ * backward).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may build, load or call this file; the product (ms-gs_amd/) never does.
+ *
+ * PARITY UNPINNED.  The reference's implementation of this path is the un-vendored submodule
+ * submodules/diff-gaussian-rasterization -> https://github.com/JokerYan/MS-GS-rasterizer.git
+ * (/root/reference/.gitmodules:4-6): the directory is empty and the pinned SHA is unrecoverable,
+ * so the reference's arithmetic can be neither compiled nor imported here, and the reference holds
+ * no tests / golden vectors for it.  This file therefore restates
+ *   - the published tile-based EWA splatting algorithm of graphdeco-inria/diff-gaussian-rasterization
+ *     (Kerbl et al., "3D Gaussian Splatting", 2023), which the MS-GS rasterizer forks
+ *     (SURVEY.md App. A.1-A.3), in the same structure: per-Gaussian preprocess, 64-bit
+ *     (tile << 32 | depth bits) keys, stable sort, per-tile ranges, per-pixel blend;
+ *   - the MS-GS additions as they are visible at the reference's call sites:
+ *       settings filter_small / filter_large / fade_size   gaussian_renderer/__init__.py:50-52
+ *       inputs max/min_pixel_sizes, occ_multiplier, dc_delta, base_mask           :99-107
+ *       5-tuple return (color, acc_pixel_size, depth, radii, pixel_sizes)         :94
+ *       consumers: scene/gaussian_model.py:663-686 (update_pixel_sizes), :713-727 (acc_pixel_size,
+ *       depth are [H,W]), train.py:244-250, 288-299
+ *     with the semantics frozen in DESIGN.md §SPEC (M1-M6);
+ *   - conventions pinned by importable reference helpers: SH polynomial utils/sh_utils.py:57-112,
+ *     quaternion->R and covariance packing utils/general_utils.py:64-110, matrices
+ *     utils/graphics_utils.py:38-71 + scene/cameras.py:54-57 (fixtures under tests/golden/).
+ * It deliberately shares no code with ms-gs_amd/csrc: it keeps the reference's structure
+ * (rect-based duplication, one 64-bit key sort) while the HIP path uses exact ellipse culling and a
+ * two-level sort; agreement between the two is what the parity tests establish.
+ *
+ * Build: g++ -O2 -fopenmp -ffp-contract=off -shared -fPIC (oracle/Makefile).  -ffp-contract=off
+ * keeps every float32 operation individually rounded so the per-Gaussian stage is bit-comparable
+ * with the HIP preprocess kernel (which is compiled with contraction off for the same reason).
+ */
+#include "msgs_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <parallel/algorithm>
+#include <omp.h>
+
+namespace {
+
+constexpr int TILE = MSGS_TILE;
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                            -1.0925484305920792f, 0.5462742152960396f};
+constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                            -0.5900435899266435f};
+
+struct Geom {
+    float depth, px, py;
+    float con[3], opacity;   // conic (A,B,C), effective opacity (after the fade weight)
+    float rgb[3];
+    float cov3D[6];
+    float pixel_size, weight;
+    int32_t radius;
+    int32_t rect[4];         // minx, miny, maxx, maxy (tiles)
+    uint8_t clamped[3];
+    uint8_t visible;
+};
+
+}  // namespace
+
+struct msgs_oracle_state {
+    int P = 0, W = 0, H = 0, gx = 0, gy = 0;
+    std::vector<Geom> geom;
+    std::vector<uint32_t> list;           // sorted Gaussian ids
+    std::vector<uint32_t> range_lo, range_hi;
+    std::vector<float> final_T;
+    std::vector<uint32_t> n_contrib;
+    // flat copies for introspection
+    std::vector<float> depths, conic_opacity, rgb, means2D, cov3D;
+    std::vector<int32_t> rects;
+    int64_t traversed = 0;
+};
+
+namespace {
+
+inline uint32_t float_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+/* SH -> RGB (utils/sh_utils.py:74-100; +0.5 and clamp as gaussian_renderer/__init__.py:86-87) */
+inline void sh_to_rgb(int deg, int K, const float* sh, const float* p, const float* campos,
+                      float* rgb, uint8_t* clamped) {
+    float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
+    float len = std::sqrt(dx * dx + dy * dy + dz * dz);
+    float x = dx / len, y = dy / len, z = dz / len;
+    (void)K;
+    for (int c = 0; c < 3; ++c) {
+        auto S = [&](int k) { return sh[k * 3 + c]; };
+        float r = SH_C0 * S(0);
+        if (deg > 0) {
+            r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * S(4) + SH_C2[1] * yz * S(5) +
+                    SH_C2[2] * (2.0f * zz - xx - yy) * S(6) + SH_C2[3] * xz * S(7) +
+                    SH_C2[4] * (xx - yy) * S(8);
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * S(9) + SH_C3[1] * xy * z * S(10) +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11) +
+                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12) +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) +
+                        SH_C3[5] * z * (xx - yy) * S(14) + SH_C3[6] * x * (xx - 3.0f * yy) * S(15);
+                }
+            }
+        }
+        r += 0.5f;
+        clamped[c] = r < 0.0f;
+        rgb[c] = r < 0.0f ? 0.0f : r;
+    }
+}
+
+/* Sigma = R diag(mod s)^2 R^T, R(q) as utils/general_utils.py:85-98 (no normalisation) */
+inline void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* cov) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                     {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                     {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    float S[3] = {mod * s[0], mod * s[1], mod * s[2]};
+    float M[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i][j] = R[i][j] * S[j];
+    auto dot = [&](int i, int j) { return M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2]; };
+    cov[0] = dot(0, 0); cov[1] = dot(0, 1); cov[2] = dot(0, 2);
+    cov[3] = dot(1, 1); cov[4] = dot(1, 2); cov[5] = dot(2, 2);
+}
+
+struct Cov2DCtx {
+    float T[2][3];       // J * Wr
+    float a, b, c;       // with the +0.3
+    float tx_c, ty_c, tz;
+    float x_mul, y_mul;
+    float fx, fy;
+};
+
+inline void compute_cov2d(const float* t, float fx, float fy, float tanx, float tany,
+                          const float* cov3D, const float* V, Cov2DCtx& o) {
+    float limx = 1.3f * tanx, limy = 1.3f * tany;
+    float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    o.x_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    o.y_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    o.tx_c = std::min(limx, std::max(-limx, txtz)) * t[2];
+    o.ty_c = std::min(limy, std::max(-limy, tytz)) * t[2];
+    o.tz = t[2];
+    o.fx = fx; o.fy = fy;
+    float J[2][3] = {{fx / t[2], 0.f, -(fx * o.tx_c) / (t[2] * t[2])},
+                     {0.f, fy / t[2], -(fy * o.ty_c) / (t[2] * t[2])}};
+    // Wr[k][c] = W2C rotation (row k, col c) = V[4*c + k]
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c)
+            o.T[r][c] = J[r][0] * V[4 * c + 0] + J[r][1] * V[4 * c + 1] + J[r][2] * V[4 * c + 2];
+    float S[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]},
+                     {cov3D[2], cov3D[4], cov3D[5]}};
+    float ST[2][3];   // ST[r][i] = sum_j S[i][j] T[r][j]
+    for (int r = 0; r < 2; ++r)
+        for (int i = 0; i < 3; ++i) ST[r][i] = S[i][0] * o.T[r][0] + S[i][1] * o.T[r][1] + S[i][2] * o.T[r][2];
+    o.a = (o.T[0][0] * ST[0][0] + o.T[0][1] * ST[0][1] + o.T[0][2] * ST[0][2]) + 0.3f;
+    o.b = o.T[0][0] * ST[1][0] + o.T[0][1] * ST[1][1] + o.T[0][2] * ST[1][2];
+    o.c = (o.T[1][0] * ST[1][0] + o.T[1][1] * ST[1][1] + o.T[1][2] * ST[1][2]) + 0.3f;
+}
+
+inline void view_point(const float* V, const float* p, float* t) {
+    t[0] = ((V[0] * p[0] + V[4] * p[1]) + V[8] * p[2]) + V[12];
+    t[1] = ((V[1] * p[0] + V[5] * p[1]) + V[9] * p[2]) + V[13];
+    t[2] = ((V[2] * p[0] + V[6] * p[1]) + V[10] * p[2]) + V[14];
+}
+
+inline void proj_point(const float* M, const float* p, float* h) {
+    for (int k = 0; k < 4; ++k) h[k] = ((M[k] * p[0] + M[4 + k] * p[1]) + M[8 + k] * p[2]) + M[12 + k];
+}
+
+/* MS-GS pixel size (DESIGN.md SPEC M1): extent, through the centre and along the image axes, of
+ * the alpha >= 1/255 level set of the low-passed 2-D Gaussian; the smaller of the two. */
+inline float pixel_size_of(float opacity, float conA, float conC) {
+    float v = 255.0f * opacity;
+    if (!(v > 1.0f) || !(conA > 0.f) || !(conC > 0.f)) return 0.f;
+    float ell = 2.0f * std::log(v);
+    float sx = 2.0f * std::sqrt(ell / conA);
+    float sy = 2.0f * std::sqrt(ell / conC);
+    return std::min(sx, sy);
+}
+
+/* MS-GS filter weight (DESIGN.md SPEC M2-M4) */
+inline float filter_weight(const msgs_view_t* v, float size, float minps, float maxps, bool base) {
+    float w = 1.0f;
+    if (v->filter_small && !base && minps > 0.f && size < minps) {
+        if (v->fade_size > 0.f) {
+            float rel = minps / std::max(size, 1e-30f);
+            w *= std::min(1.f, std::max(0.f, 1.f - (rel - 1.f) / v->fade_size));
+        } else w = 0.f;
+    }
+    if (v->filter_large && maxps > 0.f && size > maxps) {
+        if (v->fade_size > 0.f) {
+            float rel = size / maxps;
+            w *= std::min(1.f, std::max(0.f, 1.f - (rel - 1.f) / v->fade_size));
+        } else w = 0.f;
+    }
+    return w;
+}
+
+}  // namespace
+
+extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians_t* g,
+                                   float* out_color, float* out_acc_ps, float* out_depth,
+                                   int32_t* radii, float* pixel_sizes, uint8_t* borderline,
+                                   msgs_oracle_state_t** state_out, int num_threads) {
+    if (!view || !g) return MSGS_ERR_INVALID_ARG;
+    if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return MSGS_ERR_INVALID_ARG;
+    bool has_sr = g->scales != nullptr && g->rotations != nullptr;
+    if (has_sr == (g->cov3D_precomp != nullptr)) return MSGS_ERR_INVALID_ARG;
+    if (g->shs && (view->sh_degree < 0 || view->sh_degree > 3 ||
+                   (view->sh_degree + 1) * (view->sh_degree + 1) > view->sh_coeffs))
+        return MSGS_ERR_SH_DEGREE;
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+    const int P = g->P, W = view->image_width, H = view->image_height;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    auto* st = new msgs_oracle_state();
+    st->P = P; st->W = W; st->H = H; st->gx = gx; st->gy = gy;
+    st->geom.assign(P, Geom{});
+    const float fx = W / (2.0f * view->tanfovx), fy = H / (2.0f * view->tanfovy);
+    const float* V = view->viewmatrix;
+    const float* PM = view->projmatrix;
+
+    // ---- K1 preprocess (App. A.1) ----
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {
+        Geom& ge = st->geom[i];
+        ge.visible = 0; ge.radius = 0; ge.pixel_size = 0.f;
+        radii[i] = 0; pixel_sizes[i] = 0.f;
+        const float* p = g->means3D + 3 * i;
+        float t[3];
+        view_point(V, p, t);
+        ge.depth = t[2];
+        if (t[2] <= 0.2f) continue;                                   // Q1
+        float h[4];
+        proj_point(PM, p, h);
+        float pw = 1.0f / (h[3] + 0.0000001f);                         // Q9
+        float ndc_x = h[0] * pw, ndc_y = h[1] * pw;
+        if (g->cov3D_precomp) std::memcpy(ge.cov3D, g->cov3D_precomp + 6 * i, 24);
+        else cov3d_from_scale_rot(g->scales + 3 * i, view->scale_modifier, g->rotations + 4 * i, ge.cov3D);
+        Cov2DCtx c2;
+        compute_cov2d(t, fx, fy, view->tanfovx, view->tanfovy, ge.cov3D, V, c2);
+        float det = c2.a * c2.c - c2.b * c2.b;
+        if (det == 0.0f) continue;                                     // Q3
+        float det_inv = 1.f / det;
+        ge.con[0] = c2.c * det_inv; ge.con[1] = -c2.b * det_inv; ge.con[2] = c2.a * det_inv;
+        float mid = 0.5f * (c2.a + c2.c);
+        float root = std::sqrt(std::max(0.1f, mid * mid - det));       // Q4
+        float lam1 = mid + root, lam2 = mid - root;
+        float my_radius = std::ceil(3.f * std::sqrt(std::max(lam1, lam2)));
+        ge.px = ((ndc_x + 1.0f) * W - 1.0f) * 0.5f;
+        ge.py = ((ndc_y + 1.0f) * H - 1.0f) * 0.5f;
+        // MS-GS pixel size, written before any filtering (SPEC M1)
+        float o = g->opacities[i];
+        ge.pixel_size = pixel_size_of(o, ge.con[0], ge.con[2]);
+        pixel_sizes[i] = ge.pixel_size;
+        ge.rect[0] = std::min(gx, std::max(0, (int)((ge.px - my_radius) / TILE)));
+        ge.rect[1] = std::min(gy, std::max(0, (int)((ge.py - my_radius) / TILE)));
+        ge.rect[2] = std::min(gx, std::max(0, (int)((ge.px + my_radius + TILE - 1) / TILE)));
+        ge.rect[3] = std::min(gy, std::max(0, (int)((ge.py + my_radius + TILE - 1) / TILE)));
+        if ((ge.rect[2] - ge.rect[0]) * (ge.rect[3] - ge.rect[1]) == 0) continue;
+        float w = filter_weight(view, ge.pixel_size, g->min_pixel_sizes ? g->min_pixel_sizes[i] : -1.f,
+                                g->max_pixel_sizes ? g->max_pixel_sizes[i] : -1.f,
+                                g->base_mask ? g->base_mask[i] != 0 : false);
+        ge.weight = w;
+        if (!(w > 0.f)) continue;                                      // SPEC M2/M3: dropped
+        ge.opacity = o * w;
+        if (g->colors_precomp) {
+            for (int c = 0; c < 3; ++c) { ge.rgb[c] = g->colors_precomp[3 * i + c]; ge.clamped[c] = 0; }
+        } else {
+            sh_to_rgb(view->sh_degree, view->sh_coeffs, g->shs + (size_t)3 * view->sh_coeffs * i, p,
+                      view->campos, ge.rgb, ge.clamped);
+        }
+        ge.radius = (int32_t)my_radius;
+        ge.visible = 1;
+        radii[i] = ge.radius;
+    }
+
+    // ---- K2/K3 duplicate with keys (App. A.2), K4 stable sort ----
+    std::vector<uint64_t> offs(P + 1, 0);
+    for (int i = 0; i < P; ++i) {
+        const Geom& ge = st->geom[i];
+        uint64_t n = ge.visible ? (uint64_t)(ge.rect[2] - ge.rect[0]) * (ge.rect[3] - ge.rect[1]) : 0;
+        offs[i + 1] = offs[i] + n;
+    }
+    const uint64_t D = offs[P];
+    struct KV { uint64_t key; uint32_t val; };
+    std::vector<KV> kv(D);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int i = 0; i < P; ++i) {
+        const Geom& ge = st->geom[i];
+        if (!ge.visible) continue;
+        uint64_t o = offs[i];
+        for (int y = ge.rect[1]; y < ge.rect[3]; ++y)
+            for (int x = ge.rect[0]; x < ge.rect[2]; ++x) {
+                uint64_t key = (uint64_t)(y * gx + x);
+                key = (key << 32) | float_bits(ge.depth);               // Q10
+                kv[o++] = KV{key, (uint32_t)i};
+            }
+    }
+    __gnu_parallel::stable_sort(kv.begin(), kv.end(), [](const KV& a, const KV& b) { return a.key < b.key; });
+    st->list.resize(D);
+    st->range_lo.assign((size_t)gx * gy, 0);
+    st->range_hi.assign((size_t)gx * gy, 0);
+    for (uint64_t i = 0; i < D; ++i) {                                  // K5
+        st->list[i] = kv[i].val;
+        uint32_t tile = (uint32_t)(kv[i].key >> 32);
+        if (i == 0 || (uint32_t)(kv[i - 1].key >> 32) != tile) st->range_lo[tile] = (uint32_t)i;
+        if (i + 1 == D || (uint32_t)(kv[i + 1].key >> 32) != tile) st->range_hi[tile] = (uint32_t)(i + 1);
+    }
+    std::vector<KV>().swap(kv);
+
+    // ---- K6 blend forward (App. A.2) ----
+    st->final_T.assign((size_t)W * H, 1.0f);
+    st->n_contrib.assign((size_t)W * H, 0);
+    const float bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
+    int64_t traversed = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : traversed)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t lo = st->range_lo[tile], hi = st->range_hi[tile];
+        uint32_t tile_max = 0;
+        for (int ly = 0; ly < TILE; ++ly)
+            for (int lx = 0; lx < TILE; ++lx) {
+                const int x = tx * TILE + lx, y = ty * TILE + ly;
+                if (x >= W || y >= H) continue;
+                const float pxf = (float)x, pyf = (float)y;
+                float T = 1.0f, C[3] = {0, 0, 0}, aps = 0.f, adp = 0.f;
+                uint32_t contributor = 0, last = 0;
+                bool flag = false;
+                for (uint32_t k = lo; k < hi; ++k) {
+                    ++contributor;
+                    const Geom& ge = st->geom[st->list[k]];
+                    float dx = ge.px - pxf, dy = ge.py - pyf;
+                    float power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float alpha = std::min(0.99f, ge.opacity * std::exp(power));        // Q6
+                    if (std::fabs(alpha * 255.0f - 1.0f) < 2e-5f) flag = true;
+                    if (alpha < 1.0f / 255.0f) continue;                                 // Q7
+                    float test_T = T * (1 - alpha);
+                    if (std::fabs(test_T - 0.0001f) < 2e-8f) flag = true;
+                    if (test_T < 0.0001f) break;                                         // Q7: not blended
+                    float wgt = alpha * T;
+                    for (int c = 0; c < 3; ++c) C[c] += ge.rgb[c] * wgt;
+                    aps += ge.pixel_size * wgt;                                          // SPEC M6
+                    adp += ge.depth * wgt;
+                    T = test_T;
+                    last = contributor;
+                }
+                const size_t pix = (size_t)y * W + x;
+                st->final_T[pix] = T;
+                st->n_contrib[pix] = last;
+                tile_max = std::max(tile_max, last);
+                for (int c = 0; c < 3; ++c) out_color[(size_t)c * H * W + pix] = C[c] + T * bg[c];
+                out_acc_ps[pix] = aps;
+                out_depth[pix] = adp;
+                if (borderline) borderline[pix] = flag ? 1 : 0;
+            }
+        traversed += tile_max;
+    }
+    st->traversed = traversed;
+
+    // flat copies for the tests
+    st->depths.resize(P); st->conic_opacity.resize((size_t)4 * P); st->rgb.resize((size_t)3 * P);
+    st->means2D.resize((size_t)2 * P); st->cov3D.resize((size_t)6 * P); st->rects.resize((size_t)4 * P);
+    for (int i = 0; i < P; ++i) {
+        const Geom& ge = st->geom[i];
+        st->depths[i] = ge.depth;
+        for (int c = 0; c < 3; ++c) { st->conic_opacity[4 * i + c] = ge.con[c]; st->rgb[3 * i + c] = ge.rgb[c]; }
+        st->conic_opacity[4 * i + 3] = ge.opacity;
+        st->means2D[2 * i] = ge.px; st->means2D[2 * i + 1] = ge.py;
+        for (int c = 0; c < 6; ++c) st->cov3D[6 * i + c] = ge.cov3D[c];
+        for (int c = 0; c < 4; ++c) st->rects[4 * i + c] = ge.rect[c];
+    }
+    if (state_out) *state_out = st; else delete st;
+    return MSGS_OK;
+}
+
+extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_view_t* view,
+                                    const msgs_gaussians_t* g, const float* dL_dcolor,
+                                    const msgs_grads_t* grads, int num_threads) {
+    if (!st || !view || !g || !grads || !dL_dcolor) return MSGS_ERR_INVALID_ARG;
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+    const int P = st->P, W = st->W, H = st->H, gx = st->gx, gy = st->gy;
+    // per-Gaussian 2-D gradient accumulators.  Accumulated in double with atomics so that the
+    // result does not depend on the thread schedule beyond 1e-16 relative.
+    struct Acc { double mean2D[2], conic[3], opacity, color[3]; };
+    std::vector<Acc> acc(P, Acc{});
+    const float bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    // ---- K7 blend backward (App. A.3) ----
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t lo = st->range_lo[tile];
+        for (int ly = 0; ly < TILE; ++ly)
+            for (int lx = 0; lx < TILE; ++lx) {
+                const int x = tx * TILE + lx, y = ty * TILE + ly;
+                if (x >= W || y >= H) continue;
+                const size_t pix = (size_t)y * W + x;
+                const float pxf = (float)x, pyf = (float)y;
+                const float T_final = st->final_T[pix];
+                float T = T_final;
+                const uint32_t last = st->n_contrib[pix];
+                float dL_dpixel[3];
+                for (int c = 0; c < 3; ++c) dL_dpixel[c] = dL_dcolor[(size_t)c * H * W + pix];
+                float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
+                for (uint32_t j = last; j-- > 0;) {
+                    const uint32_t id = st->list[lo + j];
+                    const Geom& ge = st->geom[id];
+                    float dx = ge.px - pxf, dy = ge.py - pyf;
+                    float power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float G = std::exp(power);
+                    const float alpha = std::min(0.99f, ge.opacity * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    float dcol[3];
+                    for (int c = 0; c < 3; ++c) {
+                        accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
+                        last_color[c] = ge.rgb[c];
+                        dL_dalpha += (ge.rgb[c] - accum_rec[c]) * dL_dpixel[c];
+                        dcol[c] = dchannel_dcolor * dL_dpixel[c];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    float bg_dot = 0.f;
+                    for (int c = 0; c < 3; ++c) bg_dot += bg[c] * dL_dpixel[c];
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = ge.opacity * dL_dalpha;                // Q6: through the clamp
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * ge.con[0] - gdy * ge.con[1];
+                    const float dG_ddely = -gdy * ge.con[2] - gdx * ge.con[1];
+                    Acc& a = acc[id];
+                    const double v[9] = {(double)(dL_dG * dG_ddelx * ddelx_dx), (double)(dL_dG * dG_ddely * ddely_dy),
+                                         (double)(-0.5f * gdx * dx * dL_dG), (double)(-0.5f * gdx * dy * dL_dG),
+                                         (double)(-0.5f * gdy * dy * dL_dG), (double)(G * dL_dalpha),
+                                         (double)dcol[0], (double)dcol[1], (double)dcol[2]};
+                    double* dst[9] = {&a.mean2D[0], &a.mean2D[1], &a.conic[0], &a.conic[1], &a.conic[2],
+                                      &a.opacity, &a.color[0], &a.color[1], &a.color[2]};
+                    for (int k = 0; k < 9; ++k) {
+#pragma omp atomic
+                        *dst[k] += v[k];
+                    }
+                }
+            }
+    }
+
+    // ---- K8 (2-D covariance backward) + K9 (preprocess backward), App. A.3 ----
+    const float fx = W / (2.0f * view->tanfovx), fy = H / (2.0f * view->tanfovy);
+    const float* V = view->viewmatrix;
+    const float* PM = view->projmatrix;
+    const int K = view->sh_coeffs;
+    const int deg = view->sh_degree;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; ++i) {
+        const Geom& ge = st->geom[i];
+        float dmean[3] = {0, 0, 0};
+        if (grads->dL_dmeans2D) { grads->dL_dmeans2D[3 * i] = 0; grads->dL_dmeans2D[3 * i + 1] = 0; grads->dL_dmeans2D[3 * i + 2] = 0; }
+        if (grads->dL_dopacities) grads->dL_dopacities[i] = 0.f;
+        if (grads->dL_dshs) std::memset(grads->dL_dshs + (size_t)3 * K * i, 0, sizeof(float) * 3 * K);
+        if (grads->dL_dcolors) std::memset(grads->dL_dcolors + 3 * i, 0, 12);
+        if (grads->dL_dscales) std::memset(grads->dL_dscales + 3 * i, 0, 12);
+        if (grads->dL_drotations) std::memset(grads->dL_drotations + 4 * i, 0, 16);
+        if (grads->dL_dcov3D) std::memset(grads->dL_dcov3D + 6 * i, 0, 24);
+        if (grads->dL_dmeans3D) std::memset(grads->dL_dmeans3D + 3 * i, 0, 12);
+        if (!ge.visible) continue;
+        const Acc& a = acc[i];
+        const float g2x = (float)a.mean2D[0], g2y = (float)a.mean2D[1];
+        const float gA = (float)a.conic[0], gBh = (float)a.conic[1], gC = (float)a.conic[2];
+        const float* p = g->means3D + 3 * i;
+
+        // -- 2-D covariance backward --
+        float t[3];
+        view_point(V, p, t);
+        Cov2DCtx c2;
+        compute_cov2d(t, fx, fy, view->tanfovx, view->tanfovy, ge.cov3D, V, c2);
+        const float ca = c2.a, cb = c2.b, cc = c2.c;
+        const float denom = ca * cc - cb * cb;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);            // Q9
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float dcov[6] = {0, 0, 0, 0, 0, 0};
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * gA + 2 * cb * cc * gBh + (denom - ca * cc) * gC);
+            dL_dc = denom2inv * (-ca * ca * gC + 2 * ca * cb * gBh + (denom - ca * cc) * gA);
+            dL_db = denom2inv * 2 * (cb * cc * gA - (denom + 2 * cb * cb) * gBh + ca * cb * gC);
+            const float(*T)[3] = c2.T;
+            dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+            dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+            dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+            dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
+            dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
+            dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
+        }
+        {
+            const float S[3][3] = {{ge.cov3D[0], ge.cov3D[1], ge.cov3D[2]}, {ge.cov3D[1], ge.cov3D[3], ge.cov3D[4]},
+                                   {ge.cov3D[2], ge.cov3D[4], ge.cov3D[5]}};
+            float ST0[3], ST1[3];
+            for (int k = 0; k < 3; ++k) {
+                ST0[k] = S[k][0] * c2.T[0][0] + S[k][1] * c2.T[0][1] + S[k][2] * c2.T[0][2];
+                ST1[k] = S[k][0] * c2.T[1][0] + S[k][1] * c2.T[1][1] + S[k][2] * c2.T[1][2];
+            }
+            float dT0[3], dT1[3];
+            for (int k = 0; k < 3; ++k) {
+                dT0[k] = 2 * ST0[k] * dL_da + ST1[k] * dL_db;
+                dT1[k] = 2 * ST1[k] * dL_dc + ST0[k] * dL_db;
+            }
+            // Wr[k][c] = V[4*c + k]
+            auto Wr = [&](int k, int c) { return V[4 * c + k]; };
+            const float dJ00 = Wr(0, 0) * dT0[0] + Wr(0, 1) * dT0[1] + Wr(0, 2) * dT0[2];
+            const float dJ02 = Wr(2, 0) * dT0[0] + Wr(2, 1) * dT0[1] + Wr(2, 2) * dT0[2];
+            const float dJ11 = Wr(1, 0) * dT1[0] + Wr(1, 1) * dT1[1] + Wr(1, 2) * dT1[2];
+            const float dJ12 = Wr(2, 0) * dT1[0] + Wr(2, 1) * dT1[1] + Wr(2, 2) * dT1[2];
+            const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+            const float dtx = c2.x_mul * -fx * tz2 * dJ02;                                  // Q2
+            const float dty = c2.y_mul * -fy * tz2 * dJ12;
+            const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * c2.tx_c) * tz3 * dJ02 +
+                              (2 * fy * c2.ty_c) * tz3 * dJ12;
+            // dL/dp_j = sum_i W2C[i][j] dL/dt_i = sum_i V[4*j + i] dt_i
+            for (int j = 0; j < 3; ++j) dmean[j] += V[4 * j + 0] * dtx + V[4 * j + 1] * dty + V[4 * j + 2] * dtz;
+        }
+
+        // -- projection backward --
+        {
+            float h[4];
+            proj_point(PM, p, h);
+            const float m_w = 1.0f / (h[3] + 0.0000001f);
+            const float mul1 = h[0] * m_w * m_w, mul2 = h[1] * m_w * m_w;
+            for (int j = 0; j < 3; ++j)
+                dmean[j] += (PM[4 * j + 0] * m_w - PM[4 * j + 3] * mul1) * g2x +
+                            (PM[4 * j + 1] * m_w - PM[4 * j + 3] * mul2) * g2y;
+        }
+        if (grads->dL_dmeans2D) { grads->dL_dmeans2D[3 * i] = g2x; grads->dL_dmeans2D[3 * i + 1] = g2y; }
+        if (grads->dL_dopacities) grads->dL_dopacities[i] = ge.weight * (float)a.opacity;      // SPEC M4
+
+        // -- colour backward --
+        float dcolr[3] = {(float)a.color[0], (float)a.color[1], (float)a.color[2]};
+        if (g->colors_precomp) {
+            if (grads->dL_dcolors) for (int c = 0; c < 3; ++c) grads->dL_dcolors[3 * i + c] = dcolr[c];
+        } else {
+            for (int c = 0; c < 3; ++c) if (ge.clamped[c]) dcolr[c] = 0.f;                      // Q8
+            const float* sh = g->shs + (size_t)3 * K * i;
+            float* dsh = grads->dL_dshs ? grads->dL_dshs + (size_t)3 * K * i : nullptr;
+            const float* cam = view->campos;
+            float dox = p[0] - cam[0], doy = p[1] - cam[1], doz = p[2] - cam[2];
+            float len = std::sqrt(dox * dox + doy * doy + doz * doz);
+            float x = dox / len, y = doy / len, z = doz / len;
+            float basis[16], bdx[16], bdy[16], bdz[16];
+            for (int k = 0; k < 16; ++k) basis[k] = bdx[k] = bdy[k] = bdz[k] = 0.f;
+            basis[0] = SH_C0;
+            if (deg > 0) {
+                basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
+                bdy[1] = -SH_C1; bdz[2] = SH_C1; bdx[3] = -SH_C1;
+                if (deg > 1) {
+                    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                    basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
+                    bdx[4] = SH_C2[0] * y; bdy[4] = SH_C2[0] * x;
+                    bdy[5] = SH_C2[1] * z; bdz[5] = SH_C2[1] * y;
+                    bdx[6] = SH_C2[2] * -2.f * x; bdy[6] = SH_C2[2] * -2.f * y; bdz[6] = SH_C2[2] * 4.f * z;
+                    bdx[7] = SH_C2[3] * z; bdz[7] = SH_C2[3] * x;
+                    bdx[8] = SH_C2[4] * 2.f * x; bdy[8] = SH_C2[4] * -2.f * y;
+                    if (deg > 2) {
+                        basis[9] = SH_C3[0] * y * (3.f * xx - yy); basis[10] = SH_C3[1] * xy * z;
+                        basis[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                        basis[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                        basis[13] = SH_C3[4] * x * (4.f * zz - xx - yy); basis[14] = SH_C3[5] * z * (xx - yy);
+                        basis[15] = SH_C3[6] * x * (xx - 3.f * yy);
+                        bdx[9] = SH_C3[0] * 6.f * xy; bdy[9] = SH_C3[0] * (3.f * xx - 3.f * yy);
+                        bdx[10] = SH_C3[1] * yz; bdy[10] = SH_C3[1] * xz; bdz[10] = SH_C3[1] * xy;
+                        bdx[11] = SH_C3[2] * -2.f * xy; bdy[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy); bdz[11] = SH_C3[2] * 8.f * yz;
+                        bdx[12] = SH_C3[3] * -6.f * xz; bdy[12] = SH_C3[3] * -6.f * yz; bdz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                        bdx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); bdy[13] = SH_C3[4] * -2.f * xy; bdz[13] = SH_C3[4] * 8.f * xz;
+                        bdx[14] = SH_C3[5] * 2.f * xz; bdy[14] = SH_C3[5] * -2.f * yz; bdz[14] = SH_C3[5] * (xx - yy);
+                        bdx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); bdy[15] = SH_C3[6] * -6.f * xy;
+                    }
+                }
+            }
+            const int ncoef = (deg + 1) * (deg + 1);
+            float ddir[3] = {0, 0, 0};
+            for (int k = 0; k < ncoef; ++k)
+                for (int c = 0; c < 3; ++c) {
+                    if (dsh) dsh[k * 3 + c] = basis[k] * dcolr[c];
+                    const float s = sh[k * 3 + c] * dcolr[c];
+                    ddir[0] += bdx[k] * s; ddir[1] += bdy[k] * s; ddir[2] += bdz[k] * s;
+                }
+            // d normalize: (I - d d^T) / len
+            const float dotv = x * ddir[0] + y * ddir[1] + z * ddir[2];
+            dmean[0] += (ddir[0] - x * dotv) / len;
+            dmean[1] += (ddir[1] - y * dotv) / len;
+            dmean[2] += (ddir[2] - z * dotv) / len;
+        }
+        if (grads->dL_dmeans3D) for (int j = 0; j < 3; ++j) grads->dL_dmeans3D[3 * i + j] = dmean[j];
+
+        // -- 3-D covariance backward --
+        if (g->cov3D_precomp) {
+            if (grads->dL_dcov3D) for (int c = 0; c < 6; ++c) grads->dL_dcov3D[6 * i + c] = dcov[c];
+        } else {
+            const float* q = g->rotations + 4 * i;
+            const float* s = g->scales + 3 * i;
+            const float mod = view->scale_modifier;
+            float r = q[0], x = q[1], y = q[2], z = q[3];
+            float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                             {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                             {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+            float S[3] = {mod * s[0], mod * s[1], mod * s[2]};
+            float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                              {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                              {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dM[3][3], dR[3][3];
+            for (int a2 = 0; a2 < 3; ++a2)
+                for (int b2 = 0; b2 < 3; ++b2) {
+                    float acc2 = 0.f;
+                    for (int k = 0; k < 3; ++k) acc2 += Gm[a2][k] * (R[k][b2] * S[b2]);
+                    dM[a2][b2] = 2.f * acc2;
+                }
+            for (int j = 0; j < 3; ++j) {
+                float ds = dM[0][j] * R[0][j] + dM[1][j] * R[1][j] + dM[2][j] * R[2][j];
+                if (grads->dL_dscales) grads->dL_dscales[3 * i + j] = mod * ds;
+                for (int a2 = 0; a2 < 3; ++a2) dR[a2][j] = dM[a2][j] * S[j];
+            }
+            if (grads->dL_drotations) {
+                float* dq = grads->dL_drotations + 4 * i;
+                dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+                dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+                dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+                dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+            }
+        }
+    }
+    return MSGS_OK;
+}
+
+extern "C" int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* s) { return (int64_t)s->list.size(); }
+extern "C" int64_t msgs_oracle_traversed(const msgs_oracle_state_t* s) { return s->traversed; }
+extern "C" const float* msgs_oracle_final_T(const msgs_oracle_state_t* s) { return s->final_T.data(); }
+extern "C" const uint32_t* msgs_oracle_n_contrib(const msgs_oracle_state_t* s) { return s->n_contrib.data(); }
+extern "C" const float* msgs_oracle_depths(const msgs_oracle_state_t* s) { return s->depths.data(); }
+extern "C" const float* msgs_oracle_conic_opacity(const msgs_oracle_state_t* s) { return s->conic_opacity.data(); }
+extern "C" const float* msgs_oracle_rgb(const msgs_oracle_state_t* s) { return s->rgb.data(); }
+extern "C" const float* msgs_oracle_means2D(const msgs_oracle_state_t* s) { return s->means2D.data(); }
+extern "C" const float* msgs_oracle_cov3D(const msgs_oracle_state_t* s) { return s->cov3D.data(); }
+extern "C" const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* s) { return s->rects.data(); }
+extern "C" void msgs_oracle_free(msgs_oracle_state_t* s) { delete s; }

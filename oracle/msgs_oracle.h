@@ -1,0 +1,50 @@
+/*
+ * msgs_oracle.h — C ABI of the CPU restatement (oracle/liboracle.so).
+ *
+ * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg as the checker; never linked, loaded or called from ms-gs_amd/.
+ * PARITY UNPINNED (see msgs_oracle.cpp header).
+ *
+ * Shares only the POD argument structs with the product (include/msgs.h); all pointers here are
+ * HOST pointers.
+ */
+#ifndef MSGS_ORACLE_H_
+#define MSGS_ORACLE_H_
+#include "../include/msgs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msgs_oracle_state msgs_oracle_state_t;
+
+/* Forward.  borderline (nullable, [H*W] uint8) is set to 1 for pixels where a discrete decision
+ * (alpha < 1/255 skip, T < 1e-4 termination) was within float32 rounding distance of flipping.
+ * *state_out (nullable) receives a heap object to pass to backward / free. */
+int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians_t* g,
+                        float* out_color, float* out_acc_pixel_size, float* out_depth,
+                        int32_t* radii, float* pixel_sizes, uint8_t* borderline,
+                        msgs_oracle_state_t** state_out, int num_threads);
+
+int msgs_oracle_backward(const msgs_oracle_state_t* state, const msgs_view_t* view,
+                         const msgs_gaussians_t* g, const float* dL_dcolor,
+                         const msgs_grads_t* grads, int num_threads);
+
+/* introspection for tests: number of (tile, Gaussian) instances, per-pixel final_T / n_contrib,
+ * per-Gaussian rect and float32 depth */
+int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* state);
+int64_t msgs_oracle_traversed(const msgs_oracle_state_t* state);   /* sum_tiles max_pixels n_contrib */
+const float* msgs_oracle_final_T(const msgs_oracle_state_t* state);
+const uint32_t* msgs_oracle_n_contrib(const msgs_oracle_state_t* state);
+const float* msgs_oracle_depths(const msgs_oracle_state_t* state);
+const float* msgs_oracle_conic_opacity(const msgs_oracle_state_t* state);  /* [P,4] */
+const float* msgs_oracle_rgb(const msgs_oracle_state_t* state);            /* [P,3] */
+const float* msgs_oracle_means2D(const msgs_oracle_state_t* state);        /* [P,2] */
+const float* msgs_oracle_cov3D(const msgs_oracle_state_t* state);          /* [P,6] */
+const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* state);        /* [P,4] minx,miny,maxx,maxy */
+void msgs_oracle_free(msgs_oracle_state_t* state);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

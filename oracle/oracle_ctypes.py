@@ -1,0 +1,195 @@
+"""ctypes binding of oracle/liboracle.so (the float32 CPU restatement).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  ms-gs_amd/ never imports this.  PARITY UNPINNED (see msgs_oracle.cpp).
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class View(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("fade_size", C.c_float),
+                ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+                ("filter_small", C.c_int32), ("filter_large", C.c_int32),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class Gaussians(C.Structure):
+    _fields_ = [("P", C.c_int32), ("reserved", C.c_int32),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+                ("cov3D_precomp", C.c_void_p), ("max_pixel_sizes", C.c_void_p),
+                ("min_pixel_sizes", C.c_void_p), ("occ_multiplier", C.c_void_p),
+                ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+                ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "msgs_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.msgs_oracle_forward.restype = C.c_int
+        L.msgs_oracle_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.c_int]
+        L.msgs_oracle_backward.restype = C.c_int
+        L.msgs_oracle_backward.argtypes = [C.c_void_p, C.POINTER(View), C.POINTER(Gaussians), C.c_void_p,
+                                           C.POINTER(Grads), C.c_int]
+        L.msgs_oracle_num_instances.restype = C.c_int64
+        L.msgs_oracle_num_instances.argtypes = [C.c_void_p]
+        L.msgs_oracle_traversed.restype = C.c_int64
+        L.msgs_oracle_traversed.argtypes = [C.c_void_p]
+        for name in ("final_T", "n_contrib", "depths", "conic_opacity", "rgb", "means2D", "cov3D", "rects"):
+            f = getattr(L, "msgs_oracle_" + name)
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_void_p]
+        L.msgs_oracle_free.restype = None
+        L.msgs_oracle_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _f32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous().cpu()
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class OracleResult:
+    """Holds the oracle's forward outputs + the native state needed for backward."""
+
+    def __init__(self):
+        self.state = C.c_void_p(None)
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self.state:
+                lib().msgs_oracle_free(self.state)
+                self.state = C.c_void_p(None)
+        except Exception:
+            pass
+
+    def _arr(self, name, shape, dtype):
+        p = getattr(lib(), "msgs_oracle_" + name)(self.state)
+        n = int(np.prod(shape))
+        if n == 0:
+            return torch.zeros(shape, dtype=dtype)
+        ct = {torch.float32: C.c_float, torch.int32: C.c_int32}[dtype]
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy()
+        return torch.from_numpy(a).view(*shape)
+
+    @property
+    def num_instances(self):
+        return int(lib().msgs_oracle_num_instances(self.state))
+
+    @property
+    def traversed(self):
+        return int(lib().msgs_oracle_traversed(self.state))
+
+
+def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_precomp=False,
+              cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0):
+    """Forward on a scenes.Scene.  Returns OracleResult with .color/.acc_pixel_size/.depth/.radii/
+    .pixel_sizes/.borderline tensors (CPU)."""
+    L = lib()
+    W, H = cam.image_width, cam.image_height
+    P = scene.P
+    r = OracleResult()
+    t = dict(means3D=_f32(scene.means3D), opac=_f32(scene.opacities.reshape(-1)),
+             maxps=_f32(scene.max_pixel_sizes), minps=_f32(scene.min_pixel_sizes),
+             occ=_f32(scene.occ_multiplier), dcd=_f32(scene.dc_delta),
+             base=scene.base_mask.to(torch.uint8).contiguous().cpu(),
+             bg=_f32(bg), vm=_f32(cam.world_view_transform), pm=_f32(cam.full_proj_transform),
+             cp=_f32(cam.camera_center))
+    if use_cov_precomp:
+        t["cov"] = _f32(cov3D_precomp)
+        t["scales"] = t["rot"] = None
+    else:
+        t["cov"] = None
+        t["scales"], t["rot"] = _f32(scene.scales), _f32(scene.rotations)
+    if use_colors_precomp:
+        t["col"] = _f32(colors_precomp)
+        t["shs"] = None
+    else:
+        t["col"] = None
+        t["shs"] = _f32(scene.shs)
+    K = scene.shs.shape[1]
+    v = View(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(scale_modifier),
+             float(settings.get("fade_size", 1.0)), int(scene.sh_degree), int(K),
+             int(bool(settings.get("filter_small", False))), int(bool(settings.get("filter_large", False))),
+             0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
+    g = Gaussians(P, 0, _ptr(t["means3D"]), _ptr(t["shs"]), _ptr(t["col"]), _ptr(t["opac"]),
+                  _ptr(t["scales"]), _ptr(t["rot"]), _ptr(t["cov"]), _ptr(t["maxps"]), _ptr(t["minps"]),
+                  _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]))
+    r.color = torch.zeros(3, H, W)
+    r.acc_pixel_size = torch.zeros(H, W)
+    r.depth = torch.zeros(H, W)
+    r.radii = torch.zeros(P, dtype=torch.int32)
+    r.pixel_sizes = torch.zeros(P)
+    r.borderline = torch.zeros(H, W, dtype=torch.uint8)
+    rc = L.msgs_oracle_forward(C.byref(v), C.byref(g), _ptr(r.color), _ptr(r.acc_pixel_size), _ptr(r.depth),
+                               _ptr(r.radii), _ptr(r.pixel_sizes), _ptr(r.borderline), C.byref(r.state),
+                               int(num_threads))
+    if rc != 0:
+        raise RuntimeError(f"msgs_oracle_forward failed: {rc}")
+    r._keep = [t, v, g]
+    r.view, r.g = v, g
+    r.W, r.H, r.P, r.K = W, H, P, K
+    r.has_shs = not use_colors_precomp
+    r.has_sr = not use_cov_precomp
+    return r
+
+
+def backward(r, dL_dcolor, num_threads=0):
+    """Backward on an OracleResult; returns dict of CPU float32 gradient tensors."""
+    L = lib()
+    P, K = r.P, r.K
+    dl = _f32(dL_dcolor)
+    out = dict(means3D=torch.zeros(P, 3), means2D=torch.zeros(P, 3), opacities=torch.zeros(P, 1))
+    if r.has_shs:
+        out["shs"] = torch.zeros(P, K, 3)
+    else:
+        out["colors_precomp"] = torch.zeros(P, 3)
+    if r.has_sr:
+        out["scales"] = torch.zeros(P, 3)
+        out["rotations"] = torch.zeros(P, 4)
+    else:
+        out["cov3D_precomp"] = torch.zeros(P, 6)
+    gr = Grads(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out.get("shs")), _ptr(out.get("colors_precomp")),
+               _ptr(out["opacities"]), _ptr(out.get("scales")), _ptr(out.get("rotations")),
+               _ptr(out.get("cov3D_precomp")))
+    rc = L.msgs_oracle_backward(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), int(num_threads))
+    if rc != 0:
+        raise RuntimeError(f"msgs_oracle_backward failed: {rc}")
+    return out
