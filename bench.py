@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of rasterizer forward+backward (BASELINE.json metric) on N MI355X GPUs.
+
+A "step" is one pass of the hot path over one synthetic view per GPU:
+    render() [preprocess -> depth sort -> scan -> emit -> tile sort -> ranges -> blend fwd]
+    -> backward [blend bwd -> preprocess bwd -> torch activations]  (+ grad all-reduce when N > 1)
+driven through the reference's call surface (gaussian_renderer.render -> GaussianRasterizer -> C ABI).
+
+Workload (config.workload):
+  N = 1 : BASELINE.json configs[2] "C3": 1M Gaussians, 1920x1080, SH degree 3, multi-scale fields with
+          filter_small + filter_large, fade_size 0 (train.py:124-125), the seeded synthetic scene of
+          scenes.config("C3"), all inputs resident in HBM before the timed region.
+  N > 1 : the same 1M-Gaussian scene replicated on every GPU, ONE view per GPU per step (camera yawed
+          per rank so the views differ), followed by ONE flat fp32 all-reduce (RCCL) of the 59 floats /
+          Gaussian gradient bucket -> weak scaling (per-GPU work fixed), BASELINE.json configs[3] pattern.
+
+Output: ONE JSON line on rank 0 (see the driver contract in the task statement) carrying `roofline`
+(dominant blend kernel: algorithmic bytes / HIP-event time / 8 TB/s) and `cpu_baseline` (the CPU oracle
+timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def yawed_front_camera(scenes, width, height, rank, world):
+    """front camera rotated about +y by (rank - (world-1)/2) * 2 degrees"""
+    if world == 1:
+        return scenes.front_camera(width, height)
+    a = math.radians(2.0 * (rank - 0.5 * (world - 1)))
+    R = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+    f = 1000.0 * width / 1920.0
+    fovx = 2.0 * math.atan(width / (2.0 * f))
+    fovy = 2.0 * math.atan(height / (2.0 * f))
+    return scenes.make_camera(R, np.zeros(3), fovx, fovy, width, height)
+
+
+def cpu_baseline(scenes, scene, settings, W, H, runs=2):
+    """The CPU oracle (kind "port": there is no reference CPU path) on the SAME workload: the
+    full scene rendered forward+backward at full resolution on all host cores (about 5-10 s per run on
+    8 cores), best of `runs`."""
+    from oracle import oracle_ctypes as oc
+    cam = scenes.front_camera(W, H)
+    bg = torch.zeros(3)
+    dL = scenes.grad_seed(W, H, 2)
+    cores = os.cpu_count() or 1
+    best = None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        r = oc.rasterize(scene, cam, settings, bg, num_threads=cores)
+        t1 = time.perf_counter()
+        oc.backward(r, dL, num_threads=cores)
+        t2 = time.perf_counter()
+        if best is None or (t2 - t0) < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+        del r
+    dt = best[0]
+    return {"value": round(W * H / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "seconds": round(dt, 2), "fwd_s": round(best[1], 2), "bwd_s": round(best[2], 2),
+            "sample": f"the whole workload (same scene, settings, {W}x{H}), forward+backward, float32 "
+                      f"C++/OpenMP oracle on all {cores} host cores, best of {runs} runs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    import scenes
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    from view_parallel import FlatGradBucket
+    from parity_utils import PIPE
+
+    W, H, P = args.width, args.height, args.gaussians
+    settings = dict(filter_small=True, filter_large=True, fade_size=0.0)
+    scene = scenes.frustum_scene(P, W, H, seed=2, sh_degree=3, multiscale=True)
+    cam = yawed_front_camera(scenes, W, H, rank, world).to(dev)
+    pc = SyntheticGaussians(scene, dev, requires_grad=True)
+    bucket = FlatGradBucket(pc.parameters())
+    bg = torch.zeros(3, device=dev)
+    dL = scenes.grad_seed(W, H, 2).to(dev)
+    torch.cuda.synchronize()
+
+    timers = [] if args.no_kernel_timing else [dgr._C.KernelTimer() for _ in range(args.steps)]
+
+    def step(timer=None):
+        dgr._C.set_timer(timer)
+        bucket.zero()
+        out = render(cam, pc, PIPE, bg, **settings)
+        (out["render"] * dL).sum().backward()
+        if world > 1:
+            bucket.all_reduce(average_over=world)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(timers[k] if timers else None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dgr._C.set_timer(None)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * (W * H / 1e6) / (elapsed / args.steps)
+
+    result = {
+        "metric": "Mpixels/s fwd+bwd @1080p, 1M Gaussians; fraction of HBM roofline",
+        "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("C3: 1M Gaussians, 1920x1080, SH3, multi-scale filter_small+filter_large, fade 0"
+                                if (P, W, H) == (1_000_000, 1920, 1080) else f"custom: {P} Gaussians {W}x{H}"),
+                   "gaussians": P, "width": W, "height": H, "views_per_gpu_per_step": 1,
+                   "parallelism": f"view-parallel x{world}" + (", flat fp32 grad all-reduce (RCCL)" if world > 1 else "")},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (per launch, averaged over the timed steps) ----
+        stats = None
+        try:
+            import ctypes as C
+            # rebuild the forward state once to read D_trav / V (outside the timed region)
+            call_out = render(cam, pc, PIPE, bg, **settings)
+            fn = call_out["render"].grad_fn
+            ctx = fn
+            geom, binning, image, D = ctx.state
+            scratch = torch.empty(256, dtype=torch.uint8, device=dev)
+            o = (C.c_int64 * 2)()
+            lib = dgr._C.lib
+            dgr._C.check(lib.msgs_binning_stats(C.byref(ctx.call.view), P, C.c_void_p(ctx.radii.data_ptr()),
+                                                C.c_void_p(binning.data_ptr()), binning.numel(),
+                                                C.c_void_p(image.data_ptr()), image.numel(),
+                                                C.c_void_p(scratch.data_ptr()), scratch.numel(), o,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stats")
+            stats = {"D": int(D), "D_trav": int(o[0]), "V": int(o[1])}
+        except Exception as e:  # statistics are informative; never fail the bench line on them
+            stats = {"error": repr(e)}
+        kernels = None
+        if timers:
+            acc = {}
+            for t in timers:
+                for k, v in t.read_ms().items():
+                    if v >= 0:
+                        acc.setdefault(k, []).append(v)
+            kernels = {k: round(float(np.mean(v)), 4) for k, v in acc.items()}
+        roof = None
+        if kernels and stats and "D_trav" in stats:
+            N = W * H
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            alg = {"blend_fwd": 48 * stats["D_trav"] + 28 * N + 8 * tiles,
+                   "blend_bwd": 48 * stats["D_trav"] + 20 * N + 36 * stats["V"]}
+            dom = max(alg, key=lambda k: kernels.get(k, 0.0))
+            achieved = alg[dom] / (kernels[dom] * 1e-3) / 1e9
+            both = (alg["blend_fwd"] + alg["blend_bwd"]) / ((kernels["blend_fwd"] + kernels["blend_bwd"]) * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom],
+                    "blend_fwd_plus_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
+                                           "algorithmic_bytes": alg["blend_fwd"] + alg["blend_bwd"],
+                                           "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
+        result["roofline"] = roof
+        result["kernel_ms"] = kernels
+        result["binning"] = stats
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(scenes, scene, settings, W, H)
+            except Exception as e:
+                result["cpu_baseline"] = {"error": repr(e)}
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

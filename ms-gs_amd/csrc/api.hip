@@ -1,0 +1,286 @@
+// api.hip — the extern "C" entry points of libmsgs_hip.so declared in include/msgs.h.
+// Host-side orchestration only: argument checks, workspace carving, kernel launches on the caller's
+// stream.  No allocation, no global mutable state, one stream synchronisation (stage 1's instance
+// count) outside debug mode.
+#include "msgs_internal.h"
+
+#include <cstring>
+
+using namespace msgs;
+
+namespace {
+
+struct Timer {
+    const msgs_timing_t* t;
+    hipStream_t s;
+    void begin(int k) const { if (t && t->ev[2 * k]) (void)hipEventRecord((hipEvent_t)t->ev[2 * k], s); }
+    void end(int k) const { if (t && t->ev[2 * k + 1]) (void)hipEventRecord((hipEvent_t)t->ev[2 * k + 1], s); }
+};
+
+inline int check_inputs(const msgs_view_t* v, const msgs_gaussians_t* g) {
+    if (!v || !g) return MSGS_ERR_INVALID_ARG;
+    if (g->P < 0 || v->image_width <= 0 || v->image_height <= 0) return MSGS_ERR_INVALID_ARG;
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) return MSGS_ERR_INVALID_ARG;
+    if (g->P > 0 && (!g->means3D || !g->opacities)) return MSGS_ERR_INVALID_ARG;
+    // exactly one of shs / colors_precomp, exactly one of (scales, rotations) / cov3D_precomp
+    // (upstream raises on both-or-neither)
+    if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return MSGS_ERR_INVALID_ARG;
+    const bool sr = g->scales != nullptr && g->rotations != nullptr;
+    if ((g->scales != nullptr) != (g->rotations != nullptr)) return MSGS_ERR_INVALID_ARG;
+    if (sr == (g->cov3D_precomp != nullptr)) return MSGS_ERR_INVALID_ARG;
+    if (g->shs) {
+        if (v->sh_degree < 0 || v->sh_degree > 3) return MSGS_ERR_SH_DEGREE;
+        if ((v->sh_degree + 1) * (v->sh_degree + 1) > v->sh_coeffs) return MSGS_ERR_SH_DEGREE;
+    }
+    if ((v->image_width + TILE - 1) / TILE > 65535 || (v->image_height + TILE - 1) / TILE > 65535)
+        return MSGS_ERR_INVALID_ARG;
+    return MSGS_OK;
+}
+
+inline int debug_sync(const msgs_view_t* v, hipStream_t s) {
+    if (!v->debug) return MSGS_OK;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    e = hipGetLastError();
+    return e == hipSuccess ? MSGS_OK : (int)e;
+}
+
+inline int tile_bits(int num_tiles) {   // bits needed for tile ids 0..num_tiles (sentinel included)
+    int b = 1;
+    while ((1ll << b) <= (long long)num_tiles) ++b;
+    return b;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return (int)_e;           \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int msgs_abi_version(void) { return MSGS_ABI_VERSION; }
+
+const char* msgs_error_string(int code) {
+    switch (code) {
+        case MSGS_OK: return "ok";
+        case MSGS_ERR_INVALID_ARG: return "invalid argument (NULL or inconsistent pointers: provide exactly one of shs/colors_precomp and exactly one of scales+rotations/cov3D_precomp)";
+        case MSGS_ERR_CAPACITY: return "a caller-supplied buffer is smaller than its size query";
+        case MSGS_ERR_TOO_MANY: return "more than 2^32-1 tile instances";
+        case MSGS_ERR_SH_DEGREE: return "sh_degree must be 0..3 and (sh_degree+1)^2 <= sh_coeffs";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+size_t msgs_geom_bytes(int32_t P) { return GeomLayout(P > 0 ? P : 1).total; }
+size_t msgs_stage1_scratch_bytes(int32_t P) { return Stage1Scratch(P > 0 ? P : 1).total; }
+size_t msgs_binning_bytes(int64_t D, int32_t W, int32_t H) {
+    return BinningLayout(D, (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE)).total;
+}
+size_t msgs_stage2_scratch_bytes(int64_t D, int32_t W, int32_t H) {
+    (void)W; (void)H;
+    const Stage2Scratch L(D);
+    return L.total + align256(4 * (size_t)(D > 0 ? D : 1));   // + sorted key buffer
+}
+size_t msgs_image_bytes(int32_t W, int32_t H) { return ImageLayout(W, H).total; }
+size_t msgs_backward_scratch_bytes(int32_t P) {
+    return align256(sizeof(float) * GRAD_REC_FLOATS * (size_t)(P > 0 ? P : 1));
+}
+
+int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+                        void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
+                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream) {
+    int rc = check_inputs(view, g);
+    if (rc) return rc;
+    if (!num_instances_host) return MSGS_ERR_INVALID_ARG;
+    *num_instances_host = 0;
+    const int P = g->P;
+    if (P == 0) return MSGS_OK;
+    if (!radii || !pixel_sizes || !geom_v || !scratch_v) return MSGS_ERR_INVALID_ARG;
+    if (geom_bytes < msgs_geom_bytes(P) || scratch_bytes < msgs_stage1_scratch_bytes(P)) return MSGS_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    char* geom = (char*)geom_v;
+    char* scratch = (char*)scratch_v;
+    const GeomLayout GL(P);
+    const Stage1Scratch SL(P);
+    const ViewParams vp = make_view_params(view);
+    const Timer tm{timing, s};
+
+    tm.begin(MSGS_K_PREPROCESS);
+    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s));
+    tm.end(MSGS_K_PREPROCESS);
+    if ((rc = debug_sync(view, s))) return rc;
+
+    // depth order of the Gaussians (not rendered -> key 0xFFFFFFFF -> sorted last, zero tiles)
+    tm.begin(MSGS_K_DEPTH_SORT);
+    HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(scratch + SL.keys_a),
+                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s));
+    tm.end(MSGS_K_DEPTH_SORT);
+    if ((rc = debug_sync(view, s))) return rc;
+
+    tm.begin(MSGS_K_SCAN);
+    uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
+    HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
+                               (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s));
+    tm.end(MSGS_K_SCAN);
+
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (total > 0xFFFFFFFFull) return MSGS_ERR_TOO_MANY;
+    *num_instances_host = (int64_t)total;
+    return MSGS_OK;
+}
+
+int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes,
+                        int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
+                        void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
+                        const msgs_timing_t* timing, void* stream) {
+    int rc = check_inputs(view, g);
+    if (rc) return rc;
+    if (D < 0 || D > 0xFFFFFFFFll) return MSGS_ERR_TOO_MANY;
+    const int P = g->P, W = view->image_width, H = view->image_height;
+    if (!binning_v || !image_v || !out_color || !out_acc_ps || !out_depth) return MSGS_ERR_INVALID_ARG;
+    if (P > 0 && (!geom_v || geom_bytes < msgs_geom_bytes(P))) return MSGS_ERR_CAPACITY;
+    if (binning_bytes < msgs_binning_bytes(D, W, H) || image_bytes < msgs_image_bytes(W, H)) return MSGS_ERR_CAPACITY;
+    if (D > 0 && (!scratch_v || scratch_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    const char* geom = (const char*)geom_v;
+    char* binning = (char*)binning_v;
+    char* scratch = (char*)scratch_v;
+    char* image = (char*)image_v;
+    const ViewParams vp = make_view_params(view);
+    const int num_tiles = vp.gx * vp.gy;
+    const BinningLayout BL(D, num_tiles);
+    const Stage2Scratch SL(D);
+    const ImageLayout IL(W, H);
+    const Timer tm{timing, s};
+    uint32_t* ids = (uint32_t*)(binning + BL.ids);
+    uint2* ranges = (uint2*)(binning + BL.ranges);
+    uint32_t* keys_sorted = D > 0 ? (uint32_t*)(scratch + SL.total) : nullptr;
+
+    if (D > 0) {
+        uint32_t* keys_a = (uint32_t*)(scratch + SL.keys_a);
+        uint32_t* ids_a = (uint32_t*)(scratch + SL.ids_a);
+        tm.begin(MSGS_K_EMIT);
+        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s));
+        tm.end(MSGS_K_EMIT);
+        if ((rc = debug_sync(view, s))) return rc;
+        tm.begin(MSGS_K_TILE_SORT);
+        HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, D, 0, tile_bits(num_tiles), scratch + SL.sort, s));
+        tm.end(MSGS_K_TILE_SORT);
+        if ((rc = debug_sync(view, s))) return rc;
+    }
+    tm.begin(MSGS_K_RANGES);
+    HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s));
+    tm.end(MSGS_K_RANGES);
+    if ((rc = debug_sync(view, s))) return rc;
+
+    tm.begin(MSGS_K_BLEND_FWD);
+    HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth,
+                                 (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib), s));
+    tm.end(MSGS_K_BLEND_FWD);
+    return debug_sync(view, s);
+}
+
+int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int32_t* radii, const void* geom_v,
+                  size_t geom_bytes, int64_t D, const void* binning_v, size_t binning_bytes, const void* image_v,
+                  size_t image_bytes, const float* dL_dcolor, void* scratch_v, size_t scratch_bytes,
+                  const msgs_grads_t* grads, const msgs_timing_t* timing, void* stream) {
+    int rc = check_inputs(view, g);
+    if (rc) return rc;
+    if (!grads || !dL_dcolor) return MSGS_ERR_INVALID_ARG;
+    const int P = g->P, W = view->image_width, H = view->image_height;
+    if (P == 0) return MSGS_OK;
+    if (!radii || !geom_v || !binning_v || !image_v || !scratch_v) return MSGS_ERR_INVALID_ARG;
+    if (geom_bytes < msgs_geom_bytes(P) || binning_bytes < msgs_binning_bytes(D, W, H) ||
+        image_bytes < msgs_image_bytes(W, H) || scratch_bytes < msgs_backward_scratch_bytes(P))
+        return MSGS_ERR_CAPACITY;
+    if (g->shs && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const char* geom = (const char*)geom_v;
+    const char* binning = (const char*)binning_v;
+    const char* image = (const char*)image_v;
+    const ViewParams vp = make_view_params(view);
+    const BinningLayout BL(D, vp.gx * vp.gy);
+    const ImageLayout IL(W, H);
+    const Timer tm{timing, s};
+    float* grad_rec = (float*)scratch_v;
+
+    HIP_TRY(hipMemsetAsync(grad_rec, 0, sizeof(float) * GRAD_REC_FLOATS * (size_t)P, s));
+    tm.begin(MSGS_K_BLEND_BWD);
+    HIP_TRY(launch_blend_backward(vp, geom, (const uint32_t*)(binning + BL.ids), (const uint2*)(binning + BL.ranges),
+                                  (const float*)(image + IL.final_T), (const uint32_t*)(image + IL.n_contrib),
+                                  dL_dcolor, grad_rec, s));
+    tm.end(MSGS_K_BLEND_BWD);
+    if ((rc = debug_sync(view, s))) return rc;
+
+    tm.begin(MSGS_K_PREPROCESS_BWD);
+    HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s));
+    tm.end(MSGS_K_PREPROCESS_BWD);
+    return debug_sync(view, s);
+}
+
+int msgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, void* stream) {
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return MSGS_ERR_INVALID_ARG;
+    HIP_TRY(launch_mark_visible(P, means3D, viewmatrix, projmatrix, present, (hipStream_t)stream));
+    return MSGS_OK;
+}
+
+int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii, const void* binning,
+                       size_t binning_bytes, const void* image_v, size_t image_bytes, void* scratch,
+                       size_t scratch_bytes, int64_t* out_host, void* stream) {
+    (void)binning; (void)binning_bytes;
+    if (!view || !image_v || !scratch || !out_host || scratch_bytes < 16) return MSGS_ERR_INVALID_ARG;
+    const int W = view->image_width, H = view->image_height;
+    if (image_bytes < msgs_image_bytes(W, H)) return MSGS_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    const ViewParams vp = make_view_params(view);
+    const ImageLayout IL(W, H);
+    unsigned long long* dev = (unsigned long long*)scratch;
+    HIP_TRY(launch_binning_stats(vp, P, radii, (const uint32_t*)((const char*)image_v + IL.n_contrib), dev, s));
+    unsigned long long host[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host, dev, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    out_host[0] = (int64_t)host[0];
+    out_host[1] = (int64_t)host[1];
+    return MSGS_OK;
+}
+
+int msgs_timing_create(msgs_timing_t* t) {
+    if (!t) return MSGS_ERR_INVALID_ARG;
+    std::memset(t, 0, sizeof(*t));
+    for (int i = 0; i < 2 * MSGS_K_COUNT; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        t->ev[i] = (void*)e;
+    }
+    return MSGS_OK;
+}
+
+int msgs_timing_destroy(msgs_timing_t* t) {
+    if (!t) return MSGS_ERR_INVALID_ARG;
+    for (int i = 0; i < 2 * MSGS_K_COUNT; ++i)
+        if (t->ev[i]) { (void)hipEventDestroy((hipEvent_t)t->ev[i]); t->ev[i] = nullptr; }
+    return MSGS_OK;
+}
+
+int msgs_timing_read(const msgs_timing_t* t, float* ms_host) {
+    if (!t || !ms_host) return MSGS_ERR_INVALID_ARG;
+    for (int k = 0; k < MSGS_K_COUNT; ++k) {
+        float ms = -1.0f;
+        if (t->ev[2 * k] && t->ev[2 * k + 1]) {
+            if (hipEventElapsedTime(&ms, (hipEvent_t)t->ev[2 * k], (hipEvent_t)t->ev[2 * k + 1]) != hipSuccess) {
+                ms = -1.0f;
+                (void)hipGetLastError();
+            }
+        }
+        ms_host[k] = ms;
+    }
+    return MSGS_OK;
+}
+
+}  // extern "C"

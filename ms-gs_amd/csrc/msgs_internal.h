@@ -1,0 +1,239 @@
+// msgs_internal.h — layouts and device helpers shared by the HIP translation units of
+// libmsgs_hip.so (gfx950 only; wave64 is hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/msgs.h"
+
+namespace msgs {
+
+constexpr int TILE = MSGS_TILE;
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------
+// HBM layouts.  All sub-arrays start on 256-byte boundaries.
+// ---------------------------------------------------------------------------------------------
+// Per-Gaussian record read by the blend kernels: 3 x float4 = 48 B, one aligned AoS record so a
+// gather costs three 16-B loads from one or two 64-B lines.
+//   r0 = { px, py, conic.A, conic.B }
+//   r1 = { conic.C, opacity_eff, r, g }
+//   r2 = { b, depth, pixel_size, tau }      tau = ln(255*opacity_eff) + margin (exact-cull bound)
+struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2; };
+
+// Per-Gaussian 2-D gradient record accumulated by the blend backward: 12 floats = 48 B.
+//   [0..1] dL/dmean2D (NDC-ish units)  [2..4] dL/dconic (A, B-half, C)  [5] dL/dopacity_eff
+//   [6..8] dL/drgb   [9..11] pad
+constexpr int GRAD_REC_FLOATS = 12;
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct GeomLayout {
+    size_t rec, rect, tiles, key, flags, weight, order, offs, total;
+    __host__ __device__ explicit GeomLayout(int64_t P) {
+        size_t o = 0;
+        rec = o;    o = align256(o + sizeof(GaussRec) * P);
+        rect = o;   o = align256(o + 8 * P);        // uint2: (minx | miny<<16, maxx | maxy<<16)
+        tiles = o;  o = align256(o + 4 * P);        // exact tile-overlap count
+        key = o;    o = align256(o + 4 * P);        // depth sort key (float bits / 0xFFFFFFFF)
+        flags = o;  o = align256(o + 4 * P);        // bit0..2 colour clamped, bit3 rendered
+        weight = o; o = align256(o + 4 * P);        // multi-scale fade weight
+        order = o;  o = align256(o + 4 * P);        // Gaussian ids in depth order
+        offs = o;   o = align256(o + 4 * P);        // exclusive scan of tiles[order[r]]
+        total = o + 256;
+    }
+};
+
+// radix sort geometry: 256 threads x SORT_ITEMS keys per block
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
+
+__host__ __device__ inline int64_t sort_blocks(int64_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
+__host__ __device__ inline int64_t scan_blocks(int64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+
+// scratch needed by one radix_sort_pairs call over n pairs (alt key/val buffers + histograms)
+struct SortScratch {
+    size_t keys_alt, vals_alt, hist, partials, total;
+    __host__ __device__ explicit SortScratch(int64_t n) {
+        size_t o = 0;
+        int64_t nb = sort_blocks(n > 0 ? n : 1);
+        keys_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
+        vals_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
+        hist = o;     o = align256(o + 4 * (size_t)256 * nb);
+        partials = o; o = align256(o + 8 * (size_t)(scan_blocks(256 * nb) + 2));
+        total = o;
+    }
+};
+
+struct Stage1Scratch {
+    size_t keys_a, sort, scan_partials, total_out, total;
+    __host__ __device__ explicit Stage1Scratch(int64_t P) {
+        size_t o = 0;
+        keys_a = o;        o = align256(o + 4 * (size_t)(P > 0 ? P : 1));
+        sort = o;          o = align256(o + SortScratch(P).total);
+        scan_partials = o; o = align256(o + 8 * (size_t)(scan_blocks(P > 0 ? P : 1) + 2));
+        total_out = o;     o = align256(o + 16);
+        total = o;
+    }
+};
+
+struct BinningLayout {
+    size_t ids, ranges, total;
+    __host__ __device__ BinningLayout(int64_t D, int64_t tiles) {
+        size_t o = 0;
+        ids = o;    o = align256(o + 4 * (size_t)(D > 0 ? D : 1));
+        ranges = o; o = align256(o + 8 * (size_t)tiles);
+        total = o;
+    }
+};
+
+struct Stage2Scratch {
+    size_t keys_a, ids_a, sort, total;
+    __host__ __device__ explicit Stage2Scratch(int64_t D) {
+        size_t o = 0;
+        int64_t n = D > 0 ? D : 1;
+        keys_a = o; o = align256(o + 4 * (size_t)n);
+        ids_a = o;  o = align256(o + 4 * (size_t)n);
+        sort = o;   o = align256(o + SortScratch(n).total);
+        total = o;
+    }
+};
+
+struct ImageLayout {
+    size_t final_T, n_contrib, total;
+    __host__ __device__ ImageLayout(int64_t W, int64_t H) {
+        size_t o = 0;
+        final_T = o;   o = align256(o + 4 * (size_t)(W * H));
+        n_contrib = o; o = align256(o + 4 * (size_t)(W * H));
+        total = o;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+// Exact-culling test: does the alpha >= 1/255 level set  q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy <= tau
+// of a Gaussian centred at (gx, gy) intersect the rectangle of pixel centres [x0,x1] x [y0,y1]?
+// Conservative by construction (tau carries a safety margin), written with explicit roundings so
+// that every caller (count, emit) gets bit-identical answers whatever the surrounding code is.
+__device__ __forceinline__ bool ellipse_hits_rect(float gx, float gy, float A, float B, float C,
+                                                  float tau, float x0, float x1, float y0, float y1) {
+    const float dxlo = __fsub_rn(gx, x1), dxhi = __fsub_rn(gx, x0);
+    const float dylo = __fsub_rn(gy, y1), dyhi = __fsub_rn(gy, y0);
+    const float cx = fminf(fmaxf(0.0f, dxlo), dxhi);
+    const float cy = fminf(fmaxf(0.0f, dylo), dyhi);
+    if (cx == 0.0f && cy == 0.0f) return true;          // centre inside the rectangle
+    float qmin = 3.0e38f;
+    if (cx != 0.0f) {                                    // facing vertical edge dx = cx
+        float dy = __fdiv_rn(-__fmul_rn(B, cx), C);
+        dy = fminf(fmaxf(dy, dylo), dyhi);
+        const float q = __fmaf_rn(__fmul_rn(B, cx), dy,
+                                  __fmul_rn(0.5f, __fmaf_rn(__fmul_rn(A, cx), cx, __fmul_rn(__fmul_rn(C, dy), dy))));
+        qmin = fminf(qmin, q);
+    }
+    if (cy != 0.0f) {                                    // facing horizontal edge dy = cy
+        float dx = __fdiv_rn(-__fmul_rn(B, cy), A);
+        dx = fminf(fmaxf(dx, dxlo), dxhi);
+        const float q = __fmaf_rn(__fmul_rn(B, dx), cy,
+                                  __fmul_rn(0.5f, __fmaf_rn(__fmul_rn(A, dx), dx, __fmul_rn(__fmul_rn(C, cy), cy))));
+        qmin = fminf(qmin, q);
+    }
+    return qmin <= tau;
+}
+
+// DPP move helper (gfx9 DPP controls: quad_perm 0x00-0xFF, row_shl 0x101-0x10F, row_shr 0x111-0x11F,
+// row_ror 0x121-0x12F, row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143)
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = false>
+__device__ __forceinline__ float dpp_mov(float v, float old = 0.0f) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK,
+                                                      BANK_MASK, BOUND));
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = false>
+__device__ __forceinline__ unsigned dpp_mov_u(unsigned v, unsigned old = 0u) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+
+// After this, lanes 48..63 hold the wave total (lane 63 always does).
+__device__ __forceinline__ float wave_sum_to_row3(float v) {
+    v += dpp_mov<0xB1>(v);            // xor 1
+    v += dpp_mov<0x4E>(v);            // xor 2
+    v += dpp_mov<0x124>(v);           // + quad (q-1)
+    v += dpp_mov<0x128>(v);           // + quads (q-2, q-3): every lane = row sum
+    v += dpp_mov<0x142, 0xA>(v);      // rows 1,3 += row 0,2
+    v += dpp_mov<0x143, 0xC>(v);      // rows 2,3 += row 1 (= rows 0+1)
+    return v;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+    return v;
+}
+
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch entry points implemented in the .hip files
+// ---------------------------------------------------------------------------------------------
+struct ViewParams {            // by-value kernel argument
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, fx, fy;
+    float scale_modifier, fade_size;
+    int sh_degree, sh_coeffs;
+    int filter_small, filter_large;
+    const float* bg;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+};
+
+inline ViewParams make_view_params(const msgs_view_t* v) {
+    ViewParams p;
+    p.W = v->image_width; p.H = v->image_height;
+    p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE;
+    p.tanfovx = v->tanfovx; p.tanfovy = v->tanfovy;
+    p.fx = p.W / (2.0f * v->tanfovx); p.fy = p.H / (2.0f * v->tanfovy);
+    p.scale_modifier = v->scale_modifier; p.fade_size = v->fade_size;
+    p.sh_degree = v->sh_degree; p.sh_coeffs = v->sh_coeffs;
+    p.filter_small = v->filter_small; p.filter_large = v->filter_large;
+    p.bg = v->bg; p.viewmatrix = v->viewmatrix; p.projmatrix = v->projmatrix; p.campos = v->campos;
+    return p;
+}
+
+// preprocess.hip
+hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
+                             char* geom, hipStream_t s);
+hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
+                                      const char* geom, const float* grad_rec, const msgs_grads_t& grads,
+                                      hipStream_t s);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                               uint8_t* present, hipStream_t s);
+// sort.hip
+// Stable LSD radix sort of n (u32 key, u32 val) pairs on bits [begin_bit, end_bit).  vals_in may be
+// NULL (identity).  The result lands in keys_out/vals_out (which may alias neither input); the
+// inputs are clobbered when more than one pass is needed.
+hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                            int64_t n, int begin_bit, int end_bit, char* scratch /* SortScratch(n) */,
+                            hipStream_t s);
+// out[r] = exclusive sum of in[gather ? gather[r] : r]; *total (device, u64) = grand total
+hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
+                              uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s);
+// binning.hip
+hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
+                       int64_t D, hipStream_t s);
+hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s);
+// blend.hip
+hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
+                                float* out_color, float* out_ps, float* out_depth, float* final_T,
+                                uint32_t* n_contrib, hipStream_t s);
+hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
+                                 const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
+                                 float* grad_rec, hipStream_t s);
+hipError_t launch_binning_stats(const ViewParams& vp, int P, const int32_t* radii, const uint32_t* n_contrib,
+                                unsigned long long* out2 /* device, zeroed inside */, hipStream_t s);
+
+}  // namespace msgs

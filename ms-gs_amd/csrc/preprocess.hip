@@ -1,0 +1,536 @@
+// preprocess.hip — per-Gaussian stages of the rasterizer for gfx950.
+//
+//   preprocess_kernel           K1: projection, EWA splat, SH->RGB, MS-GS pixel size and filters,
+//                                   exact tile-overlap count            
+//   preprocess_backward_kernel  K8+K9: 2-D covariance, projection, SH and 3-D covariance backward
+//                                                                      
+//   mark_visible_kernel         K10
+//
+// Replaces the per-Gaussian kernels of the reference's un-vendored CUDA module
+// (/root/reference/.gitmodules:4-6; call site gaussian_renderer/__init__.py:94-108).
+//
+// Both kernels are HBM-streaming (309 B in / ~80 B out per Gaussian forward at SH degree 3).
+// One thread per Gaussian; floating-point contraction is OFF in this file so that every float32
+// operation is individually rounded and the discrete outputs (radii, tile rects, depth sort keys)
+// are bit-reproducible against the CPU oracle.
+#include "msgs_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace msgs {
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Cam {
+    float V[16];
+    float M[16];
+    float cam[3];
+};
+
+__device__ __forceinline__ void load_cam(const ViewParams& vp, Cam& c) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c.V[i] = vp.viewmatrix[i]; c.M[i] = vp.projmatrix[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.cam[i] = vp.campos[i];
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* cov) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    const float S[3] = {mod * s[0], mod * s[1], mod * s[2]};
+    float M[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i][j] = R[i][j] * S[j];
+    cov[0] = M[0][0] * M[0][0] + M[0][1] * M[0][1] + M[0][2] * M[0][2];
+    cov[1] = M[0][0] * M[1][0] + M[0][1] * M[1][1] + M[0][2] * M[1][2];
+    cov[2] = M[0][0] * M[2][0] + M[0][1] * M[2][1] + M[0][2] * M[2][2];
+    cov[3] = M[1][0] * M[1][0] + M[1][1] * M[1][1] + M[1][2] * M[1][2];
+    cov[4] = M[1][0] * M[2][0] + M[1][1] * M[2][1] + M[1][2] * M[2][2];
+    cov[5] = M[2][0] * M[2][0] + M[2][1] * M[2][1] + M[2][2] * M[2][2];
+}
+
+struct Cov2D {
+    float T[2][3];
+    float a, b, c;
+    float tx_c, ty_c, tz, x_mul, y_mul;
+};
+
+__device__ __forceinline__ void compute_cov2d(const float* t, const ViewParams& vp, const float* cov3D,
+                                              const float* V, Cov2D& o) {
+    const float limx = 1.3f * vp.tanfovx, limy = 1.3f * vp.tanfovy;
+    const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    o.x_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    o.y_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    o.tx_c = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    o.ty_c = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    o.tz = t[2];
+    const float J[2][3] = {{vp.fx / t[2], 0.f, -(vp.fx * o.tx_c) / (t[2] * t[2])},
+                           {0.f, vp.fy / t[2], -(vp.fy * o.ty_c) / (t[2] * t[2])}};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            o.T[r][c] = J[r][0] * V[4 * c + 0] + J[r][1] * V[4 * c + 1] + J[r][2] * V[4 * c + 2];
+    const float S[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]},
+                           {cov3D[2], cov3D[4], cov3D[5]}};
+    float ST[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ST[r][i] = S[i][0] * o.T[r][0] + S[i][1] * o.T[r][1] + S[i][2] * o.T[r][2];
+    o.a = (o.T[0][0] * ST[0][0] + o.T[0][1] * ST[0][1] + o.T[0][2] * ST[0][2]) + 0.3f;
+    o.b = o.T[0][0] * ST[1][0] + o.T[0][1] * ST[1][1] + o.T[0][2] * ST[1][2];
+    o.c = (o.T[1][0] * ST[1][0] + o.T[1][1] * ST[1][1] + o.T[1][2] * ST[1][2]) + 0.3f;
+}
+
+__device__ __forceinline__ void view_point(const float* V, const float* p, float* t) {
+    t[0] = ((V[0] * p[0] + V[4] * p[1]) + V[8] * p[2]) + V[12];
+    t[1] = ((V[1] * p[0] + V[5] * p[1]) + V[9] * p[2]) + V[13];
+    t[2] = ((V[2] * p[0] + V[6] * p[1]) + V[10] * p[2]) + V[14];
+}
+
+__device__ __forceinline__ void proj_point(const float* M, const float* p, float* h) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = ((M[k] * p[0] + M[4 + k] * p[1]) + M[8 + k] * p[2]) + M[12 + k];
+}
+
+// MS-GS pixel size, DESIGN.md SPEC M1
+__device__ __forceinline__ float pixel_size_of(float opacity, float conA, float conC) {
+    const float v = 255.0f * opacity;
+    if (!(v > 1.0f) || !(conA > 0.f) || !(conC > 0.f)) return 0.f;
+    const float ell = 2.0f * logf(v);
+    const float sx = 2.0f * sqrtf(ell / conA);
+    const float sy = 2.0f * sqrtf(ell / conC);
+    return fminf(sx, sy);
+}
+
+// MS-GS filter weight, DESIGN.md SPEC M2-M4
+__device__ __forceinline__ float filter_weight(const ViewParams& vp, float size, float minps, float maxps,
+                                               bool base) {
+    float w = 1.0f;
+    if (vp.filter_small && !base && minps > 0.f && size < minps) {
+        if (vp.fade_size > 0.f) {
+            const float rel = minps / fmaxf(size, 1e-30f);
+            w *= fminf(1.f, fmaxf(0.f, 1.f - (rel - 1.f) / vp.fade_size));
+        } else w = 0.f;
+    }
+    if (vp.filter_large && maxps > 0.f && size > maxps) {
+        if (vp.fade_size > 0.f) {
+            const float rel = size / maxps;
+            w *= fminf(1.f, fmaxf(0.f, 1.f - (rel - 1.f) / vp.fade_size));
+        } else w = 0.f;
+    }
+    return w;
+}
+
+__device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, float x, float y, float z) {
+    auto S = [&](int k) { return sh[k * 3 + c]; };
+    float r = SH_C0 * S(0);
+    if (deg > 0) {
+        r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            r = r + SH_C2[0] * xy * S(4) + SH_C2[1] * yz * S(5) + SH_C2[2] * (2.0f * zz - xx - yy) * S(6) +
+                SH_C2[3] * xz * S(7) + SH_C2[4] * (xx - yy) * S(8);
+            if (deg > 2) {
+                r = r + SH_C3[0] * y * (3.0f * xx - yy) * S(9) + SH_C3[1] * xy * z * S(10) +
+                    SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11) +
+                    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12) +
+                    SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) + SH_C3[5] * z * (xx - yy) * S(14) +
+                    SH_C3[6] * x * (xx - 3.0f * yy) * S(15);
+            }
+        }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gaussians_t g,
+                                                         int32_t* __restrict__ radii,
+                                                         float* __restrict__ pixel_sizes,
+                                                         char* __restrict__ geom) {
+    const int P = g.P;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const GeomLayout L(P);
+    GaussRec* rec = reinterpret_cast<GaussRec*>(geom + L.rec);
+    uint2* rect = reinterpret_cast<uint2*>(geom + L.rect);
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(geom + L.tiles);
+    uint32_t* key = reinterpret_cast<uint32_t*>(geom + L.key);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(geom + L.flags);
+    float* weight = reinterpret_cast<float*>(geom + L.weight);
+
+    Cam cm;
+    load_cam(vp, cm);
+
+    int32_t out_radius = 0;
+    float out_psize = 0.f;
+    uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, out_flags = 0;
+    uint2 out_rect = make_uint2(0, 0);
+    float out_weight = 0.f;
+
+    const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
+    float t[3];
+    view_point(cm.V, p, t);
+    do {
+        if (t[2] <= 0.2f) break;                                    // Q1 near-plane cull
+        float h[4];
+        proj_point(cm.M, p, h);
+        const float pw = 1.0f / (h[3] + 0.0000001f);
+        const float ndc_x = h[0] * pw, ndc_y = h[1] * pw;
+        float cov3D[6];
+        if (g.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cov3D[k] = g.cov3D_precomp[6 * i + k];
+        } else {
+            const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            cov3d_from_scale_rot(s, vp.scale_modifier, q, cov3D);
+        }
+        Cov2D c2;
+        compute_cov2d(t, vp, cov3D, cm.V, c2);
+        const float det = c2.a * c2.c - c2.b * c2.b;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float conA = c2.c * det_inv, conB = -c2.b * det_inv, conC = c2.a * det_inv;
+        const float mid = 0.5f * (c2.a + c2.c);
+        const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lam1 = mid + root, lam2 = mid - root;
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+        const float px = ((ndc_x + 1.0f) * vp.W - 1.0f) * 0.5f;
+        const float py = ((ndc_y + 1.0f) * vp.H - 1.0f) * 0.5f;
+        const float o = g.opacities[i];
+        out_psize = pixel_size_of(o, conA, conC);                    // SPEC M1 (before any filter)
+        const int minx = min(vp.gx, max(0, (int)((px - my_radius) / TILE)));
+        const int miny = min(vp.gy, max(0, (int)((py - my_radius) / TILE)));
+        const int maxx = min(vp.gx, max(0, (int)((px + my_radius + TILE - 1) / TILE)));
+        const int maxy = min(vp.gy, max(0, (int)((py + my_radius + TILE - 1) / TILE)));
+        if ((maxx - minx) * (maxy - miny) == 0) break;
+        const float w = filter_weight(vp, out_psize, g.min_pixel_sizes ? g.min_pixel_sizes[i] : -1.f,
+                                      g.max_pixel_sizes ? g.max_pixel_sizes[i] : -1.f,
+                                      g.base_mask ? g.base_mask[i] != 0 : false);
+        if (!(w > 0.f)) break;                                       // SPEC M2/M3: dropped, radii stays 0
+        const float o_eff = o * w;
+        float rgb[3];
+        if (g.colors_precomp) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = g.colors_precomp[3 * i + c];
+        } else {
+            const float dx = p[0] - cm.cam[0], dy = p[1] - cm.cam[1], dz = p[2] - cm.cam[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float x = dx / len, y = dy / len, z = dz / len;
+            const float* sh = g.shs + (size_t)3 * vp.sh_coeffs * i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float r = sh_channel(vp.sh_degree, sh, c, x, y, z) + 0.5f;
+                if (r < 0.0f) { out_flags |= (1u << c); r = 0.0f; }
+                rgb[c] = r;
+            }
+        }
+        // exact tile-overlap count (this build's replacement for tiles_touched = rect area): a tile
+        // is kept only if the alpha >= 1/255 level set reaches one of its pixel centres.
+        const float v255 = 255.0f * o_eff;
+        float tau = -1.0f;
+        uint32_t count = 0;
+        const bool psd = conA > 0.f && conC > 0.f && (conA * conC - conB * conB) > 0.f;
+        if (v255 > 1.0f) {
+            tau = logf(v255);
+            tau = tau + (1e-5f * tau + 1e-3f);
+            if (psd) {
+                for (int ty = miny; ty < maxy; ++ty)
+                    for (int tx = minx; tx < maxx; ++tx) {
+                        const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+                        count += ellipse_hits_rect(px, py, conA, conB, conC, tau, x0, x0 + (TILE - 1), y0,
+                                                   y0 + (TILE - 1)) ? 1u : 0u;
+                    }
+            } else {
+                tau = 3.0e38f;                                       // cannot bound: keep the whole rect
+                count = (uint32_t)((maxx - minx) * (maxy - miny));
+            }
+        }
+        rec[i].r0 = make_float4(px, py, conA, conB);
+        rec[i].r1 = make_float4(conC, o_eff, rgb[0], rgb[1]);
+        rec[i].r2 = make_float4(rgb[2], t[2], out_psize, tau);
+        out_radius = (int32_t)my_radius;
+        out_tiles = count;
+        out_key = count ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
+        out_flags |= 8u;
+        out_rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
+        out_weight = w;
+    } while (false);
+
+    radii[i] = out_radius;
+    pixel_sizes[i] = out_psize;
+    rect[i] = out_rect;
+    tiles[i] = out_tiles;
+    key[i] = out_key;
+    flags[i] = out_flags;
+    weight[i] = out_weight;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 + K9
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp, msgs_gaussians_t g,
+                                                                  const int32_t* __restrict__ radii,
+                                                                  const char* __restrict__ geom,
+                                                                  const float* __restrict__ grad_rec,
+                                                                  msgs_grads_t grads) {
+    const int P = g.P;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const GeomLayout L(P);
+    const uint32_t* flags = reinterpret_cast<const uint32_t*>(geom + L.flags);
+    const float* weight = reinterpret_cast<const float*>(geom + L.weight);
+    const int K = vp.sh_coeffs;
+    const int deg = vp.sh_degree;
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float g2x = 0.f, g2y = 0.f, dopac = 0.f;
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dcolr[3] = {0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool rendered = radii[i] > 0;
+    float* dsh = grads.dL_dshs ? grads.dL_dshs + (size_t)3 * K * i : nullptr;
+
+    if (rendered) {
+        Cam cm;
+        load_cam(vp, cm);
+        const float4 ga = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 0];
+        const float4 gb = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 1];
+        const float4 gc = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 2];
+        g2x = ga.x; g2y = ga.y;
+        const float gA = ga.z, gBh = ga.w, gC = gb.x;
+        dopac = weight[i] * gb.y;                                         // SPEC M4
+        dcolr[0] = gb.z; dcolr[1] = gb.w; dcolr[2] = gc.x;
+        const uint32_t fl = flags[i];
+        const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
+
+        float cov3D[6];
+        float R[3][3], S[3] = {0.f, 0.f, 0.f};
+        float qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        if (g.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cov3D[k] = g.cov3D_precomp[6 * i + k];
+        } else {
+            const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
+            qr = q4.x; qx = q4.y; qy = q4.z; qz = q4.w;
+            const float q[4] = {qr, qx, qy, qz};
+            cov3d_from_scale_rot(s, vp.scale_modifier, q, cov3D);
+            S[0] = vp.scale_modifier * s[0]; S[1] = vp.scale_modifier * s[1]; S[2] = vp.scale_modifier * s[2];
+            R[0][0] = 1.f - 2.f * (qy * qy + qz * qz); R[0][1] = 2.f * (qx * qy - qr * qz); R[0][2] = 2.f * (qx * qz + qr * qy);
+            R[1][0] = 2.f * (qx * qy + qr * qz); R[1][1] = 1.f - 2.f * (qx * qx + qz * qz); R[1][2] = 2.f * (qy * qz - qr * qx);
+            R[2][0] = 2.f * (qx * qz - qr * qy); R[2][1] = 2.f * (qy * qz + qr * qx); R[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
+        }
+
+        // ---- 2-D covariance backward ----
+        float t[3];
+        view_point(cm.V, p, t);
+        Cov2D c2;
+        compute_cov2d(t, vp, cov3D, cm.V, c2);
+        const float ca = c2.a, cb = c2.b, cc = c2.c;
+        const float denom = ca * cc - cb * cb;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-cc * cc * gA + 2 * cb * cc * gBh + (denom - ca * cc) * gC);
+            dL_dc = denom2inv * (-ca * ca * gC + 2 * ca * cb * gBh + (denom - ca * cc) * gA);
+            dL_db = denom2inv * 2 * (cb * cc * gA - (denom + 2 * cb * cb) * gBh + ca * cb * gC);
+            const float(*T)[3] = c2.T;
+            dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+            dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+            dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+            dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
+            dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
+            dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
+        }
+        {
+            const float Sg[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]},
+                                    {cov3D[2], cov3D[4], cov3D[5]}};
+            float ST0[3], ST1[3], dT0[3], dT1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ST0[k] = Sg[k][0] * c2.T[0][0] + Sg[k][1] * c2.T[0][1] + Sg[k][2] * c2.T[0][2];
+                ST1[k] = Sg[k][0] * c2.T[1][0] + Sg[k][1] * c2.T[1][1] + Sg[k][2] * c2.T[1][2];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dT0[k] = 2 * ST0[k] * dL_da + ST1[k] * dL_db;
+                dT1[k] = 2 * ST1[k] * dL_dc + ST0[k] * dL_db;
+            }
+            const float* V = cm.V;   // Wr[k][c] = V[4*c + k]
+            const float dJ00 = V[0] * dT0[0] + V[4] * dT0[1] + V[8] * dT0[2];
+            const float dJ02 = V[2] * dT0[0] + V[6] * dT0[1] + V[10] * dT0[2];
+            const float dJ11 = V[1] * dT1[0] + V[5] * dT1[1] + V[9] * dT1[2];
+            const float dJ12 = V[2] * dT1[0] + V[6] * dT1[1] + V[10] * dT1[2];
+            const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+            const float dtx = c2.x_mul * -vp.fx * tz2 * dJ02;                       // Q2
+            const float dty = c2.y_mul * -vp.fy * tz2 * dJ12;
+            const float dtz = -vp.fx * tz2 * dJ00 - vp.fy * tz2 * dJ11 + (2 * vp.fx * c2.tx_c) * tz3 * dJ02 +
+                              (2 * vp.fy * c2.ty_c) * tz3 * dJ12;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dmean[j] += V[4 * j + 0] * dtx + V[4 * j + 1] * dty + V[4 * j + 2] * dtz;
+        }
+        // ---- projection backward ----
+        {
+            float h[4];
+            proj_point(cm.M, p, h);
+            const float m_w = 1.0f / (h[3] + 0.0000001f);
+            const float mul1 = h[0] * m_w * m_w, mul2 = h[1] * m_w * m_w;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dmean[j] += (cm.M[4 * j + 0] * m_w - cm.M[4 * j + 3] * mul1) * g2x +
+                            (cm.M[4 * j + 1] * m_w - cm.M[4 * j + 3] * mul2) * g2y;
+        }
+        // ---- colour backward ----
+        if (!g.colors_precomp) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (fl & (1u << c)) dcolr[c] = 0.f;                                // Q8
+            const float* sh = g.shs + (size_t)3 * K * i;
+            const float dox = p[0] - cm.cam[0], doy = p[1] - cm.cam[1], doz = p[2] - cm.cam[2];
+            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+            const float x = dox / len, y = doy / len, z = doz / len;
+            float ddir[3] = {0.f, 0.f, 0.f};
+            // k-th coefficient: basis value and its direction derivatives
+            auto coef = [&](int k, float basis, float bx, float by, float bz) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (dsh) dsh[k * 3 + c] = basis * dcolr[c];
+                    s += sh[k * 3 + c] * dcolr[c];
+                }
+                ddir[0] += bx * s; ddir[1] += by * s; ddir[2] += bz * s;
+            };
+            coef(0, SH_C0, 0.f, 0.f, 0.f);
+            if (deg > 0) {
+                coef(1, -SH_C1 * y, 0.f, -SH_C1, 0.f);
+                coef(2, SH_C1 * z, 0.f, 0.f, SH_C1);
+                coef(3, -SH_C1 * x, -SH_C1, 0.f, 0.f);
+                if (deg > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    coef(4, SH_C2[0] * xy, SH_C2[0] * y, SH_C2[0] * x, 0.f);
+                    coef(5, SH_C2[1] * yz, 0.f, SH_C2[1] * z, SH_C2[1] * y);
+                    coef(6, SH_C2[2] * (2.f * zz - xx - yy), SH_C2[2] * -2.f * x, SH_C2[2] * -2.f * y, SH_C2[2] * 4.f * z);
+                    coef(7, SH_C2[3] * xz, SH_C2[3] * z, 0.f, SH_C2[3] * x);
+                    coef(8, SH_C2[4] * (xx - yy), SH_C2[4] * 2.f * x, SH_C2[4] * -2.f * y, 0.f);
+                    if (deg > 2) {
+                        coef(9, SH_C3[0] * y * (3.f * xx - yy), SH_C3[0] * 6.f * xy, SH_C3[0] * (3.f * xx - 3.f * yy), 0.f);
+                        coef(10, SH_C3[1] * xy * z, SH_C3[1] * yz, SH_C3[1] * xz, SH_C3[1] * xy);
+                        coef(11, SH_C3[2] * y * (4.f * zz - xx - yy), SH_C3[2] * -2.f * xy, SH_C3[2] * (4.f * zz - xx - 3.f * yy), SH_C3[2] * 8.f * yz);
+                        coef(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), SH_C3[3] * -6.f * xz, SH_C3[3] * -6.f * yz, SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy));
+                        coef(13, SH_C3[4] * x * (4.f * zz - xx - yy), SH_C3[4] * (4.f * zz - 3.f * xx - yy), SH_C3[4] * -2.f * xy, SH_C3[4] * 8.f * xz);
+                        coef(14, SH_C3[5] * z * (xx - yy), SH_C3[5] * 2.f * xz, SH_C3[5] * -2.f * yz, SH_C3[5] * (xx - yy));
+                        coef(15, SH_C3[6] * x * (xx - 3.f * yy), SH_C3[6] * (3.f * xx - 3.f * yy), SH_C3[6] * -6.f * xy, 0.f);
+                    }
+                }
+            }
+            const int ncoef = (deg + 1) * (deg + 1);
+            if (dsh)
+                for (int k = ncoef; k < K; ++k) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+            const float dotv = x * ddir[0] + y * ddir[1] + z * ddir[2];
+            dmean[0] += (ddir[0] - x * dotv) / len;
+            dmean[1] += (ddir[1] - y * dotv) / len;
+            dmean[2] += (ddir[2] - z * dotv) / len;
+        }
+        // ---- 3-D covariance backward ----
+        if (!g.cov3D_precomp) {
+            const float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dM[3][3], dR[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc += Gm[a][k] * (R[k][b] * S[b]);
+                    dM[a][b] = 2.f * acc;
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float ds = dM[0][j] * R[0][j] + dM[1][j] * R[1][j] + dM[2][j] * R[2][j];
+                dscale[j] = vp.scale_modifier * ds;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dR[a][j] = dM[a][j] * S[j];
+            }
+            const float r = qr, x = qx, y = qy, z = qz;
+            dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    } else if (dsh) {
+        for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
+    }
+
+    if (grads.dL_dmeans3D) { grads.dL_dmeans3D[3 * i] = dmean[0]; grads.dL_dmeans3D[3 * i + 1] = dmean[1]; grads.dL_dmeans3D[3 * i + 2] = dmean[2]; }
+    if (grads.dL_dmeans2D) { grads.dL_dmeans2D[3 * i] = g2x; grads.dL_dmeans2D[3 * i + 1] = g2y; grads.dL_dmeans2D[3 * i + 2] = 0.f; }
+    if (grads.dL_dopacities) grads.dL_dopacities[i] = dopac;
+    if (grads.dL_dcolors) { grads.dL_dcolors[3 * i] = dcolr[0]; grads.dL_dcolors[3 * i + 1] = dcolr[1]; grads.dL_dcolors[3 * i + 2] = dcolr[2]; }
+    if (grads.dL_dscales) { grads.dL_dscales[3 * i] = dscale[0]; grads.dL_dscales[3 * i + 1] = dscale[1]; grads.dL_dscales[3 * i + 2] = dscale[2]; }
+    if (grads.dL_drotations) reinterpret_cast<float4*>(grads.dL_drotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    if (grads.dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) grads.dL_dcov3D[6 * i + k] = dcov[k];
+    }
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ V,
+                                    uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float Vl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Vl[k] = V[k];
+    float t[3];
+    view_point(Vl, p, t);
+    present[i] = t[2] > 0.2f ? 1 : 0;
+}
+
+}  // namespace
+
+hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
+                             char* geom, hipStream_t s) {
+    if (g.P == 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
+                                      const char* geom, const float* grad_rec, const msgs_grads_t& grads,
+                                      hipStream_t s) {
+    if (g.P == 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
+                       grad_rec, grads);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                               uint8_t* present, hipStream_t s) {
+    (void)projmatrix;
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+    return hipGetLastError();
+}
+
+}  // namespace msgs

@@ -1,0 +1,258 @@
+"""MI355X-native drop-in for the `diff_gaussian_rasterization` package the reference imports at
+/root/reference/gaussian_renderer/__init__.py:14 (the MS-GS fork of the 3DGS rasterizer, an
+un-vendored CUDA submodule: /root/reference/.gitmodules:4-6).
+
+Same public surface:
+  * GaussianRasterizationSettings — NamedTuple with the 15 fields constructed at
+    gaussian_renderer/__init__.py:37-53 (the 12 upstream fields + filter_small, filter_large,
+    fade_size);
+  * GaussianRasterizer(raster_settings=...) — nn.Module called by keyword with the 13 kwargs of
+    gaussian_renderer/__init__.py:95-107, returning the 5-tuple
+    (rendered_image [3,H,W], acc_pixel_size [H,W], depth [H,W], radii [P] int32, pixel_sizes [P]);
+  * rasterize_gaussians(...) / GaussianRasterizer.markVisible(positions).
+
+Host code is Python on PyTorch-ROCm; all device work is hand-written HIP for gfx950 behind the C
+ABI of include/msgs.h (ms-gs_amd/csrc, loaded with ctypes by _backend.py).  PyTorch only provides
+device memory (caching allocator), streams and autograd plumbing.  There is NO fallback: importing
+this package without lib/libmsgs_hip.so raises ImportError, and calling it with CPU tensors raises.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _backend as _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    filter_small: bool = False
+    filter_large: bool = False
+    fade_size: float = 1.0
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _opt(t):
+    """None and empty tensors both mean 'not provided' (upstream passes torch.Tensor([]))."""
+    if t is None or t.numel() == 0:
+        return None
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _bytes(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
+
+
+class _Call:
+    """Marshals one (settings, tensors) pair into the C structs; keeps the tensors alive."""
+
+    def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                 max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask):
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("diff_gaussian_rasterization (MI355X build): tensors must live on a HIP device "
+                               "('cuda'); there is no CPU path")
+        self.device = dev
+        P = int(means3D.shape[0])
+        self.P = P
+        self.means3D = _f32c(means3D)
+        self.sh = _f32c(sh) if sh is not None else None
+        self.colors = _f32c(colors_precomp) if colors_precomp is not None else None
+        self.opac = _f32c(opacities).reshape(-1)
+        self.scales = _f32c(scales) if scales is not None else None
+        self.rot = _f32c(rotations) if rotations is not None else None
+        self.cov = _f32c(cov3D_precomp) if cov3D_precomp is not None else None
+        self.maxps = _f32c(max_pixel_sizes).reshape(-1) if max_pixel_sizes is not None else None
+        self.minps = _f32c(min_pixel_sizes).reshape(-1) if min_pixel_sizes is not None else None
+        self.occ = _f32c(occ_multiplier) if occ_multiplier is not None else None
+        self.dcd = _f32c(dc_delta) if dc_delta is not None else None
+        self.base = base_mask.to(torch.uint8).contiguous() if base_mask is not None else None
+        for name, t, n in (("opacities", self.opac, P), ("max_pixel_sizes", self.maxps, P),
+                           ("min_pixel_sizes", self.minps, P), ("base_mask", self.base, P)):
+            if t is not None and t.numel() != n:
+                raise ValueError(f"{name} must have {n} elements, got {tuple(t.shape)}")
+        self.K = int(self.sh.shape[1]) if self.sh is not None else 0
+        self.bg = _f32c(rs.bg.to(dev))
+        self.vm = _f32c(rs.viewmatrix.to(dev))
+        self.pm = _f32c(rs.projmatrix.to(dev))
+        self.cp = _f32c(rs.campos.to(dev))
+        self.W, self.H = int(rs.image_width), int(rs.image_height)
+        self.view = _C.View(self.H, self.W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+                            float(rs.fade_size), int(rs.sh_degree), self.K,
+                            int(bool(rs.filter_small)), int(bool(rs.filter_large)), int(bool(rs.prefiltered)),
+                            int(bool(rs.debug)), _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
+        self.g = _C.Gaussians(P, 0, _ptr(self.means3D), _ptr(self.sh), _ptr(self.colors), _ptr(self.opac),
+                              _ptr(self.scales), _ptr(self.rot), _ptr(self.cov), _ptr(self.maxps),
+                              _ptr(self.minps), _ptr(self.occ), _ptr(self.dcd), _ptr(self.base))
+
+
+def _forward_impl(call):
+    dev, P, W, H = call.device, call.P, call.W, call.H
+    lib = _C.lib
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        pixel_sizes = torch.empty(P, dtype=torch.float32, device=dev)
+        geom = _bytes(lib.msgs_geom_bytes(P), dev)
+        scratch1 = _bytes(lib.msgs_stage1_scratch_bytes(P), dev)
+        D = C.c_int64(0)
+        _C.check(lib.msgs_forward_stage1(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(pixel_sizes),
+                                         _ptr(geom), geom.numel(), _ptr(scratch1), scratch1.numel(),
+                                         C.byref(D), _C.timer_ptr(), stream), "msgs_forward_stage1")
+        D = int(D.value)
+        del scratch1
+        binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
+        scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
+        image = _bytes(lib.msgs_image_bytes(W, H), dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        acc_ps = torch.empty(H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+        _C.check(lib.msgs_forward_stage2(C.byref(call.view), C.byref(call.g), _ptr(geom), geom.numel(), D,
+                                         _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
+                                         _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                         _C.timer_ptr(), stream), "msgs_forward_stage2")
+    return color, acc_ps, depth, radii, pixel_sizes, (geom, binning, image, D)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
+        if means3D.shape[0] == 0:
+            # nothing to rasterize: background image, no native call (every per-Gaussian tensor is empty,
+            # which upstream's convention cannot tell apart from "not provided")
+            rs = raster_settings
+            dev = means3D.device
+            if dev.type != "cuda":
+                raise RuntimeError("diff_gaussian_rasterization (MI355X build): tensors must live on a HIP device")
+            H, W = int(rs.image_height), int(rs.image_width)
+            color = rs.bg.to(dev, torch.float32).view(3, 1, 1).expand(3, H, W).contiguous()
+            ctx.empty = True
+            ctx.in_shapes = [t.shape for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                               cov3Ds_precomp)]
+            ctx.dev = dev
+            outs = (color, torch.zeros(H, W, device=dev), torch.zeros(H, W, device=dev),
+                    torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, device=dev))
+            ctx.mark_non_differentiable(*outs[1:])
+            return outs
+        ctx.empty = False
+        call = _Call(raster_settings, means3D, _opt(sh), _opt(colors_precomp), opacities, _opt(scales),
+                     _opt(rotations), _opt(cov3Ds_precomp), _opt(max_pixel_sizes), _opt(min_pixel_sizes),
+                     _opt(occ_multiplier), _opt(dc_delta), _opt(base_mask))
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
+        ctx.call = call
+        ctx.state = state
+        ctx.radii = radii
+        ctx.shapes = (means2D.shape, opacities.shape)
+        ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
+        return color, acc_ps, depth, radii, pixel_sizes
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
+        if ctx.empty:
+            return tuple(torch.zeros(s, device=ctx.dev) for s in ctx.in_shapes) + (None,) * 6
+        call = ctx.call
+        geom, binning, image, D = ctx.state
+        dev, P, K = call.device, call.P, call.K
+        lib = _C.lib
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            dL = _f32c(grad_color)
+            g_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
+            g_means2D = torch.empty(P, 3, dtype=torch.float32, device=dev)
+            g_opac = torch.empty(P, dtype=torch.float32, device=dev)
+            g_sh = torch.empty(P, K, 3, dtype=torch.float32, device=dev) if call.sh is not None else None
+            g_col = torch.empty(P, 3, dtype=torch.float32, device=dev) if call.colors is not None else None
+            g_scales = torch.empty(P, 3, dtype=torch.float32, device=dev) if call.scales is not None else None
+            g_rot = torch.empty(P, 4, dtype=torch.float32, device=dev) if call.rot is not None else None
+            g_cov = torch.empty(P, 6, dtype=torch.float32, device=dev) if call.cov is not None else None
+            scratch = _bytes(lib.msgs_backward_scratch_bytes(P), dev)
+            grads = _C.Grads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
+                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov))
+            _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
+                                       geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
+                                       image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
+                                       _C.timer_ptr(), stream), "msgs_backward")
+        m2_shape, op_shape = ctx.shapes
+        # occ_multiplier / dc_delta / pixel-size inputs / masks receive no gradient (DESIGN.md SPEC M5)
+        return (g_means3D, g_means2D.view(m2_shape) if g_means2D.shape == m2_shape else g_means2D,
+                g_sh, g_col, g_opac.view(op_shape), g_scales, g_rot, g_cov,
+                None, None, None, None, None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta,
+                                     base_mask, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of points in front of the near plane (upstream markVisible; unused by the
+        reference's Python)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32c(positions)
+            dev = pos.device
+            if dev.type != "cuda":
+                raise RuntimeError("markVisible: positions must live on a HIP device")
+            vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
+            out = torch.empty(pos.shape[0], dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _C.check(_C.lib.msgs_mark_visible(int(pos.shape[0]), _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out),
+                                                  stream), "msgs_mark_visible")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, max_pixel_sizes=None, min_pixel_sizes=None, occ_multiplier=None,
+                dc_delta=None, base_mask=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        return rasterize_gaussians(
+            means3D, means2D,
+            shs if shs is not None else empty,
+            colors_precomp if colors_precomp is not None else empty,
+            opacities,
+            scales if scales is not None else empty,
+            rotations if rotations is not None else empty,
+            cov3D_precomp if cov3D_precomp is not None else empty,
+            max_pixel_sizes if max_pixel_sizes is not None else empty,
+            min_pixel_sizes if min_pixel_sizes is not None else empty,
+            occ_multiplier if occ_multiplier is not None else empty,
+            dc_delta if dc_delta is not None else empty,
+            base_mask if base_mask is not None else empty,
+            rs)

@@ -1,0 +1,148 @@
+"""ctypes binding of lib/libmsgs_hip.so (C ABI: include/msgs.h).
+
+This is the ONLY compute backend of the package: there is no CPU or PyTorch fallback.  If the
+shared library is missing or cannot be loaded the import fails loudly.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind to the SAME libamdhip64.so.7
+#                     instance (matched by SONAME) that PyTorch-ROCm loaded, since streams cross the boundary
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
+
+ABI_VERSION = 1
+
+K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
+           "preprocess_bwd")
+K_COUNT = len(K_NAMES)
+
+
+class View(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("fade_size", C.c_float),
+                ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+                ("filter_small", C.c_int32), ("filter_large", C.c_int32),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class Gaussians(C.Structure):
+    _fields_ = [("P", C.c_int32), ("reserved", C.c_int32),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+                ("cov3D_precomp", C.c_void_p), ("max_pixel_sizes", C.c_void_p),
+                ("min_pixel_sizes", C.c_void_p), ("occ_multiplier", C.c_void_p),
+                ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+                ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("ev", C.c_void_p * (2 * K_COUNT))]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"diff_gaussian_rasterization: HIP library not found at {_LIB_PATH}. Build it with "
+            f"`make -C {os.path.dirname(_PKG)}` (hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(_LIB_PATH)
+    sz = C.c_size_t
+    vp = C.c_void_p
+    lib.msgs_abi_version.restype = C.c_int
+    lib.msgs_error_string.restype = C.c_char_p
+    lib.msgs_error_string.argtypes = [C.c_int]
+    for name, args in (("msgs_geom_bytes", [C.c_int32]), ("msgs_stage1_scratch_bytes", [C.c_int32]),
+                       ("msgs_binning_bytes", [C.c_int64, C.c_int32, C.c_int32]),
+                       ("msgs_stage2_scratch_bytes", [C.c_int64, C.c_int32, C.c_int32]),
+                       ("msgs_image_bytes", [C.c_int32, C.c_int32]),
+                       ("msgs_backward_scratch_bytes", [C.c_int32])):
+        f = getattr(lib, name)
+        f.restype = sz
+        f.argtypes = args
+    lib.msgs_forward_stage1.restype = C.c_int
+    lib.msgs_forward_stage1.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz,
+                                        C.POINTER(C.c_int64), C.POINTER(Timing), vp]
+    lib.msgs_forward_stage2.restype = C.c_int
+    lib.msgs_forward_stage2.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, sz, C.c_int64, vp, sz, vp, sz,
+                                        vp, sz, vp, vp, vp, C.POINTER(Timing), vp]
+    lib.msgs_backward.restype = C.c_int
+    lib.msgs_backward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, sz, C.c_int64, vp, sz, vp, sz,
+                                  vp, vp, sz, C.POINTER(Grads), C.POINTER(Timing), vp]
+    lib.msgs_mark_visible.restype = C.c_int
+    lib.msgs_mark_visible.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
+    lib.msgs_binning_stats.restype = C.c_int
+    lib.msgs_binning_stats.argtypes = [C.POINTER(View), C.c_int32, vp, vp, sz, vp, sz, vp, sz,
+                                       C.POINTER(C.c_int64), vp]
+    for name in ("msgs_timing_create", "msgs_timing_destroy"):
+        f = getattr(lib, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(Timing)]
+    lib.msgs_timing_read.restype = C.c_int
+    lib.msgs_timing_read.argtypes = [C.POINTER(Timing), C.POINTER(C.c_float)]
+    got = lib.msgs_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libmsgs_hip.so ABI version {got} != expected {ABI_VERSION}; rebuild the library")
+    return lib
+
+
+lib = _load()
+
+EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_stage1_scratch_bytes",
+           "msgs_binning_bytes", "msgs_stage2_scratch_bytes", "msgs_image_bytes", "msgs_backward_scratch_bytes",
+           "msgs_forward_stage1", "msgs_forward_stage2", "msgs_backward", "msgs_mark_visible",
+           "msgs_binning_stats", "msgs_timing_create", "msgs_timing_destroy", "msgs_timing_read")
+
+
+def check(rc, where):
+    if rc == 0:
+        return
+    msg = lib.msgs_error_string(int(rc)).decode()
+    if rc in (-1, -4):
+        raise ValueError(f"{where}: {msg}")
+    raise RuntimeError(f"{where}: error {rc}: {msg}")
+
+
+# ---- optional per-kernel timing (used by bench.py; thread-local so backward picks it up too) ----
+class KernelTimer:
+    """Owns 2*K_COUNT HIP events; pass to set_timer() to have the next forward/backward record them."""
+
+    def __init__(self):
+        self.t = Timing()
+        check(lib.msgs_timing_create(C.byref(self.t)), "msgs_timing_create")
+
+    def read_ms(self):
+        out = (C.c_float * K_COUNT)()
+        check(lib.msgs_timing_read(C.byref(self.t), out), "msgs_timing_read")
+        return {K_NAMES[k]: float(out[k]) for k in range(K_COUNT)}
+
+    def __del__(self):
+        try:
+            lib.msgs_timing_destroy(C.byref(self.t))
+        except Exception:
+            pass
+
+
+_timer_lock = threading.Lock()
+_active_timer = None
+
+
+def set_timer(timer):
+    """Process-wide (forward runs on the main thread, backward on autograd's)."""
+    global _active_timer
+    with _timer_lock:
+        _active_timer = timer
+
+
+def timer_ptr():
+    t = _active_timer
+    return C.byref(t.t) if t is not None else None

@@ -1,0 +1,228 @@
+"""GPU parity tests: the HIP path (through the drop-in Python API and the C ABI) against the CPU
+oracle on the same seeded inputs.  Run on the MI355X box with `pytest -m gpu`."""
+import math
+
+import pytest
+import torch
+
+import scenes
+from parity_utils import (PIPE, check_backward, check_forward, hip_render, rel_err, small_scene)
+
+pytestmark = pytest.mark.gpu
+
+ST0 = dict(filter_small=False, filter_large=False, fade_size=1.0)
+
+
+def _oracle(scene, cam, st, bg, dL=None, **kw):
+    from oracle import oracle_ctypes as oc
+    r = oc.rasterize(scene, cam, st, bg, **kw)
+    g = oc.backward(r, dL) if dL is not None else None
+    return r, g
+
+
+def test_library_is_the_hip_one():
+    import diff_gaussian_rasterization as dgr
+    assert dgr._C._LIB_PATH.endswith("libmsgs_hip.so")
+    assert dgr._C.lib.msgs_abi_version() == 1
+
+
+@pytest.mark.parametrize("P,W,H,seed,deg,bgv", [
+    (300, 48, 40, 11, 3, (0.2, 0.5, 0.7)),
+    (2000, 100, 75, 12, 3, (0.0, 0.0, 0.0)),
+    (5000, 160, 128, 13, 2, (1.0, 1.0, 1.0)),
+    (3000, 128, 128, 14, 1, (0.0, 0.0, 0.0)),
+    (3000, 130, 70, 15, 0, (0.1, 0.1, 0.1)),
+])
+def test_forward_backward_vs_oracle(P, W, H, seed, deg, bgv):
+    sc, cam = small_scene(P, W, H, seed, sh_degree=deg)
+    bg = torch.tensor(bgv)
+    dL = scenes.grad_seed(W, H, seed)
+    out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
+    orc, og = _oracle(sc, cam, ST0, bg, dL)
+    check_forward(out, orc, f"seed{seed}")
+    check_backward(pc, m2, og, f"seed{seed}")
+
+
+def test_config_c1_forward():
+    """BASELINE.json configs[0]: 10k Gaussians, 256x256, SH degree 0, forward only."""
+    sc, cam, st = scenes.config("C1")
+    bg = torch.zeros(3)
+    out, _, _ = hip_render(sc, cam, st, bg)
+    orc, _ = _oracle(sc, cam, st, bg)
+    check_forward(out, orc, "C1")
+
+
+def test_multiscale_filters():
+    W, H = 160, 96
+    sc, cam = small_scene(4000, W, H, 21, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.15)
+    bg = torch.tensor([0.3, 0.3, 0.3])
+    dL = scenes.grad_seed(W, H, 21)
+    for st in (dict(filter_small=True, filter_large=True, fade_size=0.0),
+               dict(filter_small=True, filter_large=True, fade_size=1.0),
+               dict(filter_small=True, filter_large=False, fade_size=0.5),
+               dict(filter_small=False, filter_large=True, fade_size=0.0)):
+        out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+        orc, og = _oracle(sc, cam, st, bg, dL)
+        check_forward(out, orc, str(st))
+        check_backward(pc, m2, og, str(st))
+    # the filters must actually drop something in this scene
+    out_nf, _, _ = hip_render(sc, cam, ST0, bg)
+    out_f, _, _ = hip_render(sc, cam, dict(filter_small=True, filter_large=True, fade_size=0.0), bg)
+    assert (out_f["radii"] > 0).sum() < (out_nf["radii"] > 0).sum()
+    # pixel_sizes is reported for filtered Gaussians too (train.py:290-299 relies on it)
+    dropped = (out_nf["radii"] > 0) & (out_f["radii"] == 0)
+    assert dropped.any() and (out_f["pixel_sizes"][dropped] >= 0).all()
+    assert torch.equal(out_f["pixel_sizes"], out_nf["pixel_sizes"])
+
+
+def test_base_mask_exempts_small_filter():
+    W, H = 96, 96
+    sc, cam = small_scene(1500, W, H, 22, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.1)
+    sc.min_pixel_sizes[:] = 50.0           # everything is "too small"
+    bg = torch.zeros(3)
+    st = dict(filter_small=True, filter_large=False, fade_size=0.0)
+    out, _, _ = hip_render(sc, cam, st, bg)
+    assert (out["radii"] > 0).sum() == 0
+    assert torch.allclose(out["render"], torch.zeros_like(out["render"]))
+    sc.base_mask[::2] = True
+    out2, _, _ = hip_render(sc, cam, st, bg)
+    orc, _ = _oracle(sc, cam, st, bg)
+    check_forward(out2, orc, "base_mask")
+    assert (out2["radii"][1::2] == 0).all() and (out2["radii"][::2] > 0).any()
+
+
+def test_python_side_cov_and_colors():
+    """pipe.compute_cov3D_python / convert_SHs_python paths (render() :68-91)."""
+    import types
+    W, H = 96, 64
+    sc, cam = small_scene(1500, W, H, 31)
+    bg = torch.tensor([0.5, 0.1, 0.9])
+    dL = scenes.grad_seed(W, H, 31)
+    ref_out, ref_pc, ref_m2 = hip_render(sc, cam, ST0, bg, dL)
+    for pipe in (types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False),
+                 types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=True, debug=False),
+                 types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True, debug=True)):
+        out, pc, m2 = hip_render(sc, cam, ST0, bg, dL, pipe=pipe)
+        assert (out["render"] - ref_out["render"]).abs().max().item() <= 2e-5
+        assert torch.equal(out["radii"], ref_out["radii"])
+        # the Python-side activations differentiate through torch: end-to-end grads must agree with the
+        # in-op path up to float32 rounding of two different formula orderings
+        for n in ("_xyz", "_opacity", "_scaling", "_rotation", "_features_dc", "_features_rest"):
+            assert rel_err(getattr(pc, n).grad, getattr(ref_pc, n).grad) <= 5e-4, n
+
+
+def test_precomputed_inputs_vs_oracle():
+    from oracle import torch_oracle as to
+    W, H = 80, 64
+    sc, cam = small_scene(1200, W, H, 32)
+    bg = torch.tensor([0.0, 0.3, 0.0])
+    dL = scenes.grad_seed(W, H, 32)
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda"
+    camd = cam.to(dev)
+    cov = to.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), 1.0).float()
+    d = sc.means3D.double() - cam.camera_center.double()[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    col = torch.clamp_min(to.eval_sh_color(sc.sh_degree, sc.shs.double(), d) + 0.5, 0).float()
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                                       tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev), scale_modifier=1.0,
+                                       viewmatrix=camd.world_view_transform, projmatrix=camd.full_proj_transform,
+                                       sh_degree=sc.sh_degree, campos=camd.camera_center, prefiltered=False,
+                                       debug=False)
+    t = lambda x: x.to(dev).requires_grad_(True)
+    means, opac, covd, cold = t(sc.means3D), t(sc.opacities), t(cov), t(col)
+    m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+    img, aps, dep, radii, psz = GaussianRasterizer(rs)(means3D=means, means2D=m2, opacities=opac,
+                                                        colors_precomp=cold, cov3D_precomp=covd)
+    (img * dL.to(dev)).sum().backward()
+    orc, og = _oracle(sc, cam, ST0, bg, dL, use_cov_precomp=True, use_colors_precomp=True, cov3D_precomp=cov,
+                      colors_precomp=col)
+    out = dict(render=img, acc_pixel_size=aps, depth=dep, radii=radii, visibility_filter=radii > 0, pixel_sizes=psz)
+    check_forward(out, orc, "precomp")
+    for name, g, ref in (("means3D", means.grad, og["means3D"]), ("opac", opac.grad, og["opacities"]),
+                         ("cov", covd.grad, og["cov3D_precomp"]), ("col", cold.grad, og["colors_precomp"]),
+                         ("m2", m2.grad, og["means2D"])):
+        assert rel_err(g, ref) <= 1e-4, (name, rel_err(g, ref))
+
+
+def test_scale_modifier_and_ring_camera():
+    W, H = 96, 64
+    sc = scenes.ball_scene(2500, seed=41, log_s=-1.6)
+    cam = scenes.ring_camera(3, 8, W, H)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    dL = scenes.grad_seed(W, H, 41)
+    out, pc, m2 = hip_render(sc, cam, ST0, bg, dL, scaling_modifier=0.7)
+    from oracle import oracle_ctypes as oc
+    r = oc.rasterize(sc, cam, ST0, bg, scale_modifier=0.7)
+    g = oc.backward(r, dL)
+    check_forward(out, r, "ring")
+    check_backward(pc, m2, g, "ring")
+
+
+def test_edge_cases_empty_and_culled():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = 40, 24
+    cam = scenes.front_camera(W, H).to("cuda")
+    bg = torch.tensor([0.25, 0.5, 0.75], device="cuda")
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                                       tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,
+                                       viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                                       sh_degree=0, campos=cam.camera_center, prefiltered=False, debug=True)
+    # all Gaussians behind the camera: pure background, radii 0, zero gradients
+    sc, _ = small_scene(64, W, H, 51)
+    sc.means3D[:, 2] = -1.0
+    out, pc, m2 = hip_render(sc, scenes.front_camera(W, H), ST0, bg.cpu(), scenes.grad_seed(W, H, 51))
+    assert (out["radii"] == 0).all() and (out["pixel_sizes"] == 0).all()
+    assert torch.allclose(out["render"], bg[:, None, None].expand(3, H, W))
+    assert all(p.grad is not None and (p.grad == 0).all() for p in pc.parameters())
+    # P == 0
+    e = lambda *s: torch.zeros(*s, device="cuda")
+    img, aps, dep, radii, psz = GaussianRasterizer(rs)(means3D=e(0, 3), means2D=e(0, 3), opacities=e(0, 1),
+                                                        shs=e(0, 16, 3), scales=e(0, 3), rotations=e(0, 4))
+    assert torch.allclose(img, bg[:, None, None].expand(3, H, W)) and radii.numel() == 0
+    # API errors mirror upstream
+    with pytest.raises(Exception):
+        GaussianRasterizer(rs)(means3D=e(4, 3), means2D=e(4, 3), opacities=e(4, 1), scales=e(4, 3), rotations=e(4, 4))
+    with pytest.raises(Exception):
+        GaussianRasterizer(rs)(means3D=e(4, 3), means2D=e(4, 3), opacities=e(4, 1), shs=e(4, 16, 3),
+                               colors_precomp=e(4, 3), scales=e(4, 3), rotations=e(4, 4))
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(rs)(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), opacities=torch.zeros(4, 1),
+                               shs=torch.zeros(4, 16, 3), scales=torch.zeros(4, 3), rotations=torch.zeros(4, 4))
+
+
+def test_huge_and_tiny_gaussians():
+    """Gaussians covering the whole image (tile-overflow path) together with sub-pixel ones."""
+    W, H = 200, 120
+    sc, cam = small_scene(600, W, H, 61)
+    sc.scales[:40] *= 60.0
+    sc.scales[40:200] *= 0.02
+    bg = torch.zeros(3)
+    dL = scenes.grad_seed(W, H, 61)
+    out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
+    orc, og = _oracle(sc, cam, ST0, bg, dL)
+    check_forward(out, orc, "huge")
+    check_backward(pc, m2, og, "huge")
+
+
+def test_mark_visible():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = 64, 64
+    sc, cam = small_scene(1000, W, H, 71)
+    camd = cam.to("cuda")
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=1.0, tanfovy=1.0,
+                                       bg=torch.zeros(3, device="cuda"), scale_modifier=1.0,
+                                       viewmatrix=camd.world_view_transform, projmatrix=camd.full_proj_transform,
+                                       sh_degree=0, campos=camd.camera_center, prefiltered=False, debug=False)
+    vis = GaussianRasterizer(rs).markVisible(sc.means3D.to("cuda"))
+    assert torch.equal(vis.cpu(), sc.means3D[:, 2] > 0.2)
+
+
+def test_determinism_of_forward():
+    W, H = 128, 96
+    sc, cam = small_scene(4000, W, H, 81)
+    bg = torch.zeros(3)
+    a, _, _ = hip_render(sc, cam, ST0, bg)
+    b, _, _ = hip_render(sc, cam, ST0, bg)
+    for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
+        assert torch.equal(a[k], b[k]), k
