@@ -13,8 +13,9 @@
 // are unchanged.
 //
 // Backward: per (wave, record) the nine partial gradients are reduced across the 64 lanes with a
-// DPP reduce-scatter (8 values: 2 halving steps inside quads, then row and cross-row all-reduce on
-// the remaining 2 values per lane; the 9th value with a plain DPP reduction) and committed with two
+// DPP reduce-scatter (8 values: 2 halving steps inside quads, then a row all-reduce with row_ror and a
+// cross-row all-reduce with v_permlane16/32_swap on the remaining 2 values per lane; the 9th value with
+// a plain reduction) and committed with two
 // global_atomic_add_f32 instructions (4 + 5 lanes) into a 48-byte per-Gaussian gradient record —
 // one atomic per (quadrant, Gaussian, component) instead of the reference's one per (pixel,
 // Gaussian, component).
@@ -274,13 +275,13 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
                 r[k] = keep + dpp_mov<0x4E>(send);
                 r[k] += dpp_mov<0x124>(r[k]);
                 r[k] += dpp_mov<0x128>(r[k]);
-                r[k] += dpp_mov<0x142, 0xA>(r[k]);
-                r[k] += dpp_mov<0x143, 0xC>(r[k]);
+                r[k] = cross_row_allreduce(r[k]);
             }
-            const float v8 = wave_sum_to_row3(v[8]);
+            const float v8 = wave_allreduce_sum(v[8]);
+            // lanes 0..3 hold the totals of components vbase, vbase+1 (0,1 | 4,5 | 2,3 | 6,7); lane 4 adds #8
             float* gdst = grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS;
-            if (lane >= 48 && lane < 52) unsafeAtomicAdd(gdst + vbase, r[0]);
-            if (lane >= 48 && lane < 53) unsafeAtomicAdd(gdst + (lane == 52 ? 8 : vbase + 1), lane == 52 ? v8 : r[1]);
+            if (lane < 4) unsafeAtomicAdd(gdst + vbase, r[0]);
+            if (lane < 5) unsafeAtomicAdd(gdst + (lane == 4 ? 8 : vbase + 1), lane == 4 ? v8 : r[1]);
         }
     }
 }

@@ -158,15 +158,26 @@ __device__ __forceinline__ unsigned dpp_mov_u(unsigned v, unsigned old = 0u) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND);
 }
 
-// After this, lanes 48..63 hold the wave total (lane 63 always does).
-__device__ __forceinline__ float wave_sum_to_row3(float v) {
+// Position-preserving all-reduce across the four 16-lane rows of a wave64: lane l ends up with
+// x[l%16] + x[l%16+16] + x[l%16+32] + x[l%16+48].  gfx950's v_permlane16_swap exchanges the odd rows of
+// its first operand with the even rows of its second, v_permlane32_swap the upper half of the first
+// with the lower half of the second; fed the same value twice, the two results add up to the pair sum
+// in every lane.  (DPP row_bcast15/31 cannot be used here: it broadcasts ONE lane to a whole row.)
+__device__ __forceinline__ float cross_row_allreduce(float x) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = __uint_as_float(a.x) + __uint_as_float(a.y);
+    const u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
+
+// every lane receives the wave total
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
     v += dpp_mov<0xB1>(v);            // xor 1
     v += dpp_mov<0x4E>(v);            // xor 2
     v += dpp_mov<0x124>(v);           // + quad (q-1)
     v += dpp_mov<0x128>(v);           // + quads (q-2, q-3): every lane = row sum
-    v += dpp_mov<0x142, 0xA>(v);      // rows 1,3 += row 0,2
-    v += dpp_mov<0x143, 0xC>(v);      // rows 2,3 += row 1 (= rows 0+1)
-    return v;
+    return cross_row_allreduce(v);
 }
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {

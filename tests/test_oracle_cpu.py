@@ -1,0 +1,217 @@
+"""CPU tests of the oracle itself (no GPU): the float32 C++ restatement against the float64 autograd
+oracle, both against the committed golden fixtures, and the restated helpers against the fixtures that
+were generated from the reference's own importable functions (tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from oracle import oracle_ctypes as oc
+from oracle import torch_oracle as to
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ST0 = dict(filter_small=False, filter_large=False, fade_size=1.0)
+
+
+def _k(W, f=0.5):
+    return 0.004 * 1920.0 / W * f
+
+
+# ------------------------------------------------------------------ reference-pinned fixtures ------
+def test_sh_polynomial_matches_reference_eval_sh():
+    """sh_colors.npz was produced by /root/reference/utils/sh_utils.py::eval_sh."""
+    z = np.load(os.path.join(GOLD, "sh_colors.npz"))
+    sh = torch.from_numpy(z["sh"])            # [N, 3, 16] reference layout
+    dirs = torch.from_numpy(z["dirs"])
+    from gaussian_renderer.sh import eval_sh, RGB2SH
+    for deg in range(4):
+        want_raw = torch.from_numpy(z[f"raw_deg{deg}"])
+        # torch oracle takes [N, K, 3]
+        got = to.eval_sh_color(deg, sh.transpose(1, 2), dirs)
+        assert (got - want_raw).abs().max() < 1e-13
+        assert (eval_sh(deg, sh, dirs) - want_raw).abs().max() < 1e-13
+        want = torch.from_numpy(z[f"rgb_deg{deg}"])
+        assert (torch.clamp_min(got + 0.5, 0) - want).abs().max() < 1e-13
+    assert np.allclose(RGB2SH(torch.linspace(0, 1, 11, dtype=torch.float64)).numpy(), z["rgb2sh"])
+
+
+def test_sh_in_c_oracle_matches_reference_fixture():
+    """The C++ oracle's SH->RGB (through its forward) against the reference-generated colours."""
+    z = np.load(os.path.join(GOLD, "sh_colors.npz"))
+    N = z["sh"].shape[0]
+    W = H = 32
+    cam = scenes.front_camera(W, H)
+    dirs = torch.from_numpy(z["dirs"]).float()
+    dirs = torch.where(dirs[:, 2:3] < 0, -dirs, dirs)          # put the points in front of the camera
+    sc = scenes.frustum_scene(N, W, H, seed=1, sh_degree=3, scale_k=_k(W))
+    sc.means3D = (dirs * 3.0 + cam.camera_center[None]).contiguous()
+    sc.means3D[:, 2] = sc.means3D[:, 2].abs() + 0.5
+    d = sc.means3D.double() - cam.camera_center.double()[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    sc.shs = torch.from_numpy(z["sh"]).float().transpose(1, 2).contiguous()
+    from gaussian_renderer.sh import eval_sh
+    for deg in range(4):
+        sc.sh_degree = deg
+        r = oc.rasterize(sc, cam, ST0, torch.zeros(3))
+        got = r._arr("rgb", (N, 3), torch.float32)
+        want = torch.clamp_min(eval_sh(deg, torch.from_numpy(z["sh"]), d) + 0.5, 0).float()
+        vis = r.radii > 0
+        assert vis.sum() > N // 2
+        assert (got[vis] - want[vis]).abs().max() < 2e-6
+
+
+def test_camera_matrices_match_reference():
+    """cameras.npz was produced by /root/reference/utils/graphics_utils.py + scene/cameras.py:54-57."""
+    z = np.load(os.path.join(GOLD, "cameras.npz"))
+    for i in range(4):
+        fovx, fovy = z[f"fov{i}"]
+        cam = scenes.make_camera(z[f"R{i}"], z[f"T{i}"], float(fovx), float(fovy), 64, 48)
+        assert np.array_equal(cam.world_view_transform.numpy(), z[f"wvt{i}"])
+        assert np.allclose(cam.full_proj_transform.numpy(), z[f"full{i}"], rtol=0, atol=1e-6)
+        assert np.allclose(cam.camera_center.numpy(), z[f"center{i}"], rtol=0, atol=1e-6)
+
+
+def test_covariance_packing_matches_reference():
+    """cov3d.npz was produced by /root/reference/utils/general_utils.py build_scaling_rotation/strip_symmetric."""
+    z = np.load(os.path.join(GOLD, "cov3d.npz"))
+    s, q = torch.from_numpy(z["scales"]), torch.from_numpy(z["quats"])
+    qn = q / q.norm(dim=1, keepdim=True)          # the reference normalises inside build_rotation
+    assert np.allclose(to.quat_to_rot(qn.double()).numpy(), z["rot"], atol=1e-6)
+    cov = to.cov3d_from_scale_rot(s.double(), qn.double(), float(z["modifier"]))
+    assert np.allclose(cov.numpy(), z["cov"], rtol=1e-5, atol=1e-8)
+    from synthetic_model import _build_rotation, _strip_symmetric
+    L = _build_rotation(q) * (float(z["modifier"]) * s)[:, None, :]
+    assert np.allclose(_strip_symmetric(L @ L.transpose(1, 2)).numpy(), z["cov"], rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------ C++ oracle vs autograd oracle ---
+def _compare(sc, cam, st, bgv, cov=False, col=False, seed=3):
+    W, H = cam.image_width, cam.image_height
+    bg = torch.tensor(bgv, dtype=torch.float32)
+    dL = scenes.grad_seed(W, H, seed) * W * H
+    outs, grads = to.forward_backward(sc, cam, st, bg, dL, use_cov_precomp=cov, use_colors_precomp=col)
+    kw = {}
+    if cov:
+        kw["cov3D_precomp"] = to.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), 1.0).float()
+    if col:
+        d = sc.means3D.double() - cam.camera_center.double()[None]
+        d = d / d.norm(dim=1, keepdim=True)
+        kw["colors_precomp"] = torch.clamp_min(to.eval_sh_color(sc.sh_degree, sc.shs.double(), d) + 0.5, 0).float()
+    r = oc.rasterize(sc, cam, st, bg, use_cov_precomp=cov, use_colors_precomp=col, **kw)
+    g = oc.backward(r, dL)
+    ok = ~(outs["borderline"] | r.borderline.bool())
+    assert ok.float().mean() > 0.97
+    assert (r.color.double() - outs["color"]).abs()[:, ok].max() < 1e-5
+    assert (r.acc_pixel_size.double() - outs["acc_pixel_size"]).abs()[ok].max() < 2e-4
+    assert (r.depth.double() - outs["depth"]).abs()[ok].max() < 1e-4
+    assert (r.radii != outs["radii"]).sum() == 0
+    assert (r.pixel_sizes.double() - outs["pixel_sizes"]).abs().max() < 1e-3
+    for k in g:
+        ref = grads[k].reshape(g[k].shape)
+        err = (g[k].double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err < 1e-4, (k, err)
+    return r, outs
+
+
+@pytest.mark.parametrize("variant", ["base", "cov", "col", "sh0", "sh1", "sh2", "white_bg"])
+def test_c_oracle_matches_autograd(variant):
+    W, H = 56, 40
+    cam = scenes.front_camera(W, H)
+    deg = {"sh0": 0, "sh1": 1, "sh2": 2}.get(variant, 3)
+    sc = scenes.frustum_scene(260, W, H, seed={"base": 1, "cov": 2, "col": 3, "sh0": 4, "sh1": 14, "sh2": 24, "white_bg": 7}[variant], sh_degree=deg, scale_k=_k(W))
+    _compare(sc, cam, ST0, (1, 1, 1) if variant in ("col", "white_bg") else (0.1, 0.3, 0.6),
+             cov=variant == "cov", col=variant == "col")
+
+
+@pytest.mark.parametrize("st", [dict(filter_small=True, filter_large=True, fade_size=0.0),
+                                dict(filter_small=True, filter_large=True, fade_size=1.0),
+                                dict(filter_small=False, filter_large=True, fade_size=0.3)])
+def test_c_oracle_multiscale_filters(st):
+    W, H = 56, 40
+    cam = scenes.front_camera(W, H)
+    sc = scenes.frustum_scene(350, W, H, seed=5, scale_k=_k(W, 0.15), multiscale=True)
+    r, _ = _compare(sc, cam, st, (0.3, 0.3, 0.3))
+    r0 = oc.rasterize(sc, cam, ST0, torch.zeros(3))
+    assert (r.radii > 0).sum() < (r0.radii > 0).sum()          # the filters drop something
+    assert torch.equal(r.pixel_sizes, r0.pixel_sizes)          # sizes are reported before filtering
+
+
+def test_c_oracle_clamped_projection_and_ring_camera():
+    W, H = 56, 40
+    sc = scenes.frustum_scene(300, W, H, seed=6, scale_k=_k(W, 1.5))
+    sc.means3D[:, 0] *= 1.25
+    sc.means3D[:, 1] *= 1.25                                    # pushes t.x/t.z past 1.3 tanfov (quirk Q2)
+    _compare(sc, scenes.front_camera(W, H), ST0, (0, 0, 0))
+    _compare(scenes.ball_scene(300, seed=9, log_s=-1.5), scenes.ring_camera(1, 8, W, H), ST0, (0.1, 0.2, 0.3))
+
+
+def test_autograd_oracle_against_finite_differences():
+    """The float64 oracle's autograd against central differences on a handful of scalars."""
+    W, H = 24, 16
+    cam = scenes.front_camera(W, H)
+    sc = scenes.frustum_scene(12, W, H, seed=8, scale_k=_k(W, 1.0), sh_degree=2)
+    sc.means3D[:, 2] = sc.means3D[:, 2].abs() + 1.0
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    dL = scenes.grad_seed(W, H, 8) * W * H
+    _, grads = to.forward_backward(sc, cam, ST0, bg, dL)
+
+    def loss_of(scene):
+        outs, _ = to.forward_backward(scene, cam, ST0, bg, dL)
+        return (outs["color"] * dL.double()).sum().item()
+
+    import copy
+    checked = 0
+    for name, gname, idx in (("means3D", "means3D", (3, 0)), ("means3D", "means3D", (5, 2)),
+                             ("scales", "scales", (2, 1)), ("opacities", "opacities", (4, 0)),
+                             ("shs", "shs", (1, 3, 2)), ("rotations", "rotations", (6, 2))):
+        base = getattr(sc, name).double()
+        h = 1e-5 * max(1.0, abs(base[idx].item()))
+        vals = []
+        for sgn in (+1, -1):
+            s2 = copy.copy(sc)
+            t = base.clone()
+            t[idx] += sgn * h
+            setattr(s2, name, t)
+            vals.append(loss_of(s2))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        an = grads[gname][idx].item()
+        if abs(an) > 1e-6:
+            assert abs(fd - an) <= 2e-4 * max(abs(an), abs(fd)) + 1e-7, (name, idx, fd, an)
+            checked += 1
+    assert checked >= 3
+
+
+# ------------------------------------------------------------------ committed raster pins ----------
+@pytest.mark.parametrize("name", ["raster_base", "raster_ms", "raster_fade"])
+def test_c_oracle_matches_committed_vectors(name):
+    """tests/golden/raster_*.npz: float64 autograd-oracle outputs+gradients (self-generated regression pins;
+    the reference rasterizer is un-vendored => parity unpinned)."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, P = int(z["W"]), int(z["H"]), int(z["P"])
+    sc = scenes.frustum_scene(P, W, H, seed=int(z["seed"]), sh_degree=int(z["deg"]), multiscale=bool(z["ms"]),
+                              scale_k=float(z["scale_k"]))
+    cam = scenes.front_camera(W, H)
+    st = dict(filter_small=bool(z["filter_small"]), filter_large=bool(z["filter_large"]), fade_size=float(z["fade_size"]))
+    bg = torch.from_numpy(z["bg"])
+    dL = scenes.grad_seed(W, H, int(z["seed"]))
+    r = oc.rasterize(sc, cam, st, bg)
+    g = oc.backward(r, dL)
+    ok = ~(torch.from_numpy(z["out_borderline"]) | r.borderline.bool())
+    assert (r.color.double() - torch.from_numpy(z["out_color"])).abs()[:, ok].max() < 1e-5
+    assert torch.equal(r.radii, torch.from_numpy(z["out_radii"]))
+    for k in g:
+        ref = torch.from_numpy(z["grad_" + k]).reshape(g[k].shape)
+        err = (g[k].double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err < 1e-4, (k, err)
+
+
+def test_oracle_error_conventions():
+    W = H = 16
+    sc = scenes.frustum_scene(4, W, H, seed=1, scale_k=_k(W))
+    cam = scenes.front_camera(W, H)
+    with pytest.raises(RuntimeError):          # both colour inputs
+        oc.rasterize(sc, cam, ST0, torch.zeros(3), use_colors_precomp=False, colors_precomp=None,
+                     use_cov_precomp=True, cov3D_precomp=None)

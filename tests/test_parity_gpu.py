@@ -78,7 +78,7 @@ def test_multiscale_filters():
 def test_base_mask_exempts_small_filter():
     W, H = 96, 96
     sc, cam = small_scene(1500, W, H, 22, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.1)
-    sc.min_pixel_sizes[:] = 50.0           # everything is "too small"
+    sc.min_pixel_sizes[:] = 1.0e6         # everything is "too small"
     bg = torch.zeros(3)
     st = dict(filter_small=True, filter_large=False, fade_size=0.0)
     out, _, _ = hip_render(sc, cam, st, bg)
