@@ -111,7 +111,9 @@ def main():
     scene = scenes.frustum_scene(P, W, H, seed=2, sh_degree=3, multiscale=True)
     cam = yawed_front_camera(scenes, W, H, rank, world).to(dev)
     pc = SyntheticGaussians(scene, dev, requires_grad=True)
-    bucket = FlatGradBucket(pc.parameters())
+    # N > 1: parameter .grad tensors are views into ONE flat bucket that is all-reduced once per step.
+    # N = 1: nothing to reduce -> grads are left to autograd (set-to-None each step, like optimizer.zero_grad).
+    bucket = FlatGradBucket(pc.parameters()) if world > 1 else None
     bg = torch.zeros(3, device=dev)
     dL = scenes.grad_seed(W, H, 2).to(dev)
     torch.cuda.synchronize()
@@ -120,10 +122,14 @@ def main():
 
     def step(timer=None):
         dgr._C.set_timer(timer)
-        bucket.zero()
+        if bucket is not None:
+            bucket.zero()
+        else:
+            for p_ in pc.parameters():
+                p_.grad = None
         out = render(cam, pc, PIPE, bg, **settings)
-        (out["render"] * dL).sum().backward()
-        if world > 1:
+        out["render"].backward(dL)               # fixed dL/dimage (SURVEY §8(d) 'backward seed')
+        if bucket is not None:
             bucket.all_reduce(average_over=world)
         return out
 

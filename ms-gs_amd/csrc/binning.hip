@@ -34,12 +34,12 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
     const float4 r0 = rec[gi].r0;
     const float conC = rec[gi].r1.x;
-    const float tau = rec[gi].r2.w;
-    const bool test = tau < 1.0e38f;
+    const float tau2 = rec[gi].r2.w;
+    const bool test = tau2 > -1.0e38f;
     for (int ty = miny; ty < maxy && off < end; ++ty)
         for (int tx = minx; tx < maxx && off < end; ++tx) {
             const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-            if (!test || ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, conC, tau, x0, x0 + (TILE - 1), y0, y0 + (TILE - 1))) {
+            if (!test || levelset_hits_rect(r0.x, r0.y, r0.z, r0.w, conC, tau2, x0, x0 + (TILE - 1), y0, y0 + (TILE - 1))) {
                 keys[off] = (uint32_t)(ty * vp.gx + tx);
                 ids[off] = gi;
                 ++off;

@@ -6,22 +6,29 @@
 // 8x8 pixel QUADRANT (lane l -> pixel (l & 7, l >> 3) of the quadrant).  The tile's depth-sorted
 // Gaussian list is staged through LDS in batches of 256 records (coalesced 4-B id loads, then three
 // 16-B gathers per record).  The loading thread also classifies its record against the four
-// quadrants with the exact alpha >= 1/255 ellipse test, and every wave compacts the batch to the
+// quadrants with the exact alpha >= 1/255 level-set test, and every wave compacts the batch to the
 // entries that can touch ITS quadrant (64-bit ballot + popcount prefix), so the per-pixel loop only
 // visits records that matter for that wave.  Skipping a record whose alpha is < 1/255 on every
 // pixel of the quadrant is exactly what the per-pixel `continue` of the reference does, so results
 // are unchanged.
 //
-// Backward: per (wave, record) the nine partial gradients are reduced across the 64 lanes with a
-// DPP reduce-scatter (8 values: 2 halving steps inside quads, then a row all-reduce with row_ror and a
-// cross-row all-reduce with v_permlane16/32_swap on the remaining 2 values per lane; the 9th value with
-// a plain reduction) and committed with two
-// global_atomic_add_f32 instructions (4 + 5 lanes) into a 48-byte per-Gaussian gradient record —
-// one atomic per (quadrant, Gaussian, component) instead of the reference's one per (pixel,
-// Gaussian, component).
+// Both kernels are VALU-issue bound (rocprofv3 PMC, profiles/), so the per-(pixel, Gaussian) math is
+// kept minimal: the record carries the conic pre-scaled into the log2 domain and log2(opacity), so
+//     alpha_raw = exp2( dx*u + dy*w + log2 o ),  u = A'dx + B'dy,  w = C'dy + B'dx
+// is six FMA-class ops and one v_exp_f32; u and w double as the screen-space gradient directions in
+// the backward, and every per-Gaussian constant factor (0.5 W, -1/2, 1/o, 2 ln 2) is applied once per
+// Gaussian in preprocess_backward_kernel instead of once per pixel here.
+//
+// Backward reduction: per (wave, record) the nine partial sums are reduced across the 64 lanes with a
+// DPP reduce-scatter (two halving steps inside quads: 8 -> 4 -> 2 values per lane) and a row_ror
+// all-reduce inside each 16-lane row, a cross-row all-reduce with v_permlane16/32_swap, and two
+// global_atomic_add_f32 instructions (4 + 5 lanes) into the 48-byte per-Gaussian gradient record — one
+// atomic per (quadrant, Gaussian, component) instead of the reference's one per (pixel, Gaussian,
+// component).  (Template variant LDS_ACC accumulates the four row partials in LDS and commits once per
+// batch; measured slower, kept for A/B runs.)
 //
 // Roofline: HBM-bound by contract (BASELINE.json); algorithmic bytes K6 = 48*D_trav + 28*N + 8*tiles,
-// K7 = 48*D_trav + 20*N + 36*V.  In practice both are VALU/transcendental-bound.
+// K7 = 48*D_trav + 20*N + 36*V.
 #include "msgs_internal.h"
 
 namespace msgs {
@@ -32,26 +39,25 @@ constexpr int BATCH = 256;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_MIN = 0.0001f;
 
-__device__ __forceinline__ float fast_exp(float x) {
-    return __builtin_amdgcn_exp2f(__fmul_rn(x, 1.4426950408889634f));
+// Shared by forward and backward so both take bit-identical skip decisions: explicit FMA order.
+//   p = dx*u + dy*w + lo   with u = A'dx + Bh'dy, w = C'dy + Bh'dx   (log2 of the unclamped alpha)
+struct PairEval { float u, w, p; };
+__device__ __forceinline__ PairEval eval_pair(float A, float Bh, float C, float lo, float dx, float dy) {
+    PairEval e;
+    e.u = __fmaf_rn(A, dx, __fmul_rn(Bh, dy));
+    e.w = __fmaf_rn(C, dy, __fmul_rn(Bh, dx));
+    e.p = __fmaf_rn(dx, e.u, __fmaf_rn(dy, e.w, lo));
+    return e;
 }
-
-// power = -1/2 (A dx^2 + C dy^2) - B dx dy with a fixed operation order, so that the forward and the
-// backward kernel take bit-identical skip decisions (alpha < 1/255) whatever the compiler contracts.
-__device__ __forceinline__ float gauss_power(float A, float B, float C, float dx, float dy) {
-    const float s = __fmaf_rn(__fmul_rn(A, dx), dx, __fmul_rn(__fmul_rn(C, dy), dy));
-    return __fmaf_rn(-0.5f, s, -__fmul_rn(__fmul_rn(B, dx), dy));
-}
-__device__ __forceinline__ float gauss_alpha(float opacity, float G) { return fminf(0.99f, __fmul_rn(opacity, G)); }
 
 // quadrant hit mask of one record (bit q: quadrant q = qx + 2*qy of the tile at (tx0, ty0))
-__device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, float conC, float tau, float tx0, float ty0) {
-    if (!(tau < 1.0e38f)) return 0xFu;
+__device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, float C, float tau2, float tx0, float ty0) {
+    if (!(tau2 > -1.0e38f)) return 0xFu;
     uint32_t m = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x0 = tx0 + (float)((q & 1) * 8), y0 = ty0 + (float)((q >> 1) * 8);
-        if (ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, conC, tau, x0, x0 + 7.0f, y0, y0 + 7.0f)) m |= 1u << q;
+        if (levelset_hits_rect(r0.x, r0.y, r0.z, r0.w, C, tau2, x0, x0 + 7.0f, y0, y0 + 7.0f)) m |= 1u << q;
     }
     return m;
 }
@@ -122,16 +128,16 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             const int e = s_list[w][j];
             const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
             const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const float power = gauss_power(r0.z, r0.w, r1.x, dx, dy);
-            const float alpha = gauss_alpha(r1.y, fast_exp(power));
-            const bool valid = !done && power <= 0.0f && alpha >= ALPHA_MIN;
-            const float test_T = T * (1.0f - alpha);
+            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
+            const bool valid = !done && ev.p <= r1.y && alpha >= ALPHA_MIN;   // power <= 0, alpha >= 1/255
+            const float test_T = __fmaf_rn(-T, alpha, T);
             const bool stop = valid && test_T < T_MIN;
             done = done || stop;
             const bool blend = valid && !stop;
             const float wgt = blend ? alpha * T : 0.0f;
-            C0 += r1.z * wgt; C1 += r1.w * wgt; C2 += r2.x * wgt;
-            adp += r2.y * wgt; aps += r2.z * wgt;
+            C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
+            adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
             T = blend ? test_T : T;
             last = blend ? (uint32_t)(base + e + 1) : last;
         }
@@ -152,6 +158,13 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
+// Gradient record components accumulated here (scaled to dL/d{mean2D, conic, opacity} per Gaussian
+// in preprocess_backward_kernel):
+//   [0] sum q u   [1] sum q w   [2] sum q dx dx   [3] sum q dx dy   [4] sum q dy dy   [5] sum q
+//   [6..8] sum alpha T dL/dC_c                     with q = alpha_raw * dL/dalpha
+constexpr int ACC_STRIDE = BATCH + 1;
+
+template <bool LDS_ACC>
 __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                              const uint32_t* __restrict__ ids,
                                                              const uint2* __restrict__ ranges,
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     __shared__ uint32_t s_mask[BATCH];
     __shared__ uint16_t s_list[4][BATCH];
     __shared__ uint32_t s_wmax[4];
+    __shared__ float s_acc[LDS_ACC ? 9 * ACC_STRIDE : 1];
 
     const int num_tiles = vp.gx * vp.gy;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -184,24 +198,25 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     const uint32_t last = inside ? n_contrib[pix] : 0u;
     float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
     if (inside) { dL0 = dL_dcolor[pix]; dL1 = dL_dcolor[N + pix]; dL2 = dL_dcolor[2 * N + pix]; }
-    const float bg_dot = vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2;
-    const float ddelx_dx = 0.5f * vp.W, ddely_dy = 0.5f * vp.H;
+    const float nTf_bg = -T_final * (vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2);
 
     const uint32_t wave_last = wave_max_u32(last);
     if (lane == 0) s_wmax[w] = wave_last;
+    if (LDS_ACC) {
+        for (int k = tid; k < 9 * ACC_STRIDE; k += 256) s_acc[k] = 0.f;
+    }
     __syncthreads();
     const uint32_t tile_last = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
     float T = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;       // accum_rec
-    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;          // last_color
-    float last_alpha = 0.f;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;       // accum_rec as the NEXT (nearer) entry will see it
     const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
     const int vbase = 4 * (int)p0 + 2 * (int)p1;
+    const int sub = lane & 15;                       // position inside the 16-lane row
 
     const int nb = ((int)tile_last + BATCH - 1) / BATCH;
     for (int b = nb - 1; b >= 0; --b) {
-        __syncthreads();                              // previous batch fully consumed
+        __syncthreads();                              // previous batch fully consumed (and flushed)
         const int base = b * BATCH;
         const int n = min(BATCH, (int)tile_last - base);
         if (tid < n) {
@@ -226,40 +241,29 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const float4 r0 = s_r0[e], r1 = s_r1[e];
             const float cb = s_b[e];
             const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const float power = gauss_power(r0.z, r0.w, r1.x, dx, dy);
-            const float G = fast_exp(power);
-            const float alpha = gauss_alpha(r1.y, G);
-            const bool valid = (uint32_t)(base + e) < last && power <= 0.0f && alpha >= ALPHA_MIN;
+            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+            const float a_raw = __builtin_amdgcn_exp2f(ev.p);
+            const float alpha = fminf(0.99f, a_raw);
+            const bool valid = (uint32_t)(base + e) < last && ev.p <= r1.y && alpha >= ALPHA_MIN;
             if (__ballot(valid) == 0) continue;
+            const float alpha_m = valid ? alpha : 0.0f;            // masked lanes: no state change, zero output
+            const float a_m = valid ? a_raw : 0.0f;
             const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
             const float Tn = T * inv;
-            const float dch = alpha * Tn;
-            const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            const float a2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            float dL_dalpha = ((r1.z - a0) * dL0 + (r1.w - a1) * dL1 + (cb - a2) * dL2) * Tn;
-            dL_dalpha += (-T_final * inv) * bg_dot;
-            const float dL_dG = r1.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
-            const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+            T = valid ? Tn : T;
+            const float dch = alpha_m * Tn;
+            const float d0 = r1.z - acc0, d1 = r1.w - acc1, d2 = cb - acc2;
+            const float s = fmaf(d2, dL2, fmaf(d1, dL1, d0 * dL0));
+            const float dL_dalpha = fmaf(s, Tn, nTf_bg * inv);
+            acc0 = fmaf(alpha_m, d0, acc0); acc1 = fmaf(alpha_m, d1, acc1); acc2 = fmaf(alpha_m, d2, acc2);
+            const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
+            const float h = q * dx, qy = q * dy;
             float v[9];
-            v[0] = valid ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
-            v[1] = valid ? dL_dG * dG_ddely * ddely_dy : 0.f;
-            v[2] = valid ? -0.5f * gdx * dx * dL_dG : 0.f;
-            v[3] = valid ? -0.5f * gdx * dy * dL_dG : 0.f;
-            v[4] = valid ? -0.5f * gdy * dy * dL_dG : 0.f;
-            v[5] = valid ? G * dL_dalpha : 0.f;
-            v[6] = valid ? dch * dL0 : 0.f;
-            v[7] = valid ? dch * dL1 : 0.f;
-            v[8] = valid ? dch * dL2 : 0.f;
-            if (valid) {
-                T = Tn;
-                acc0 = a0; acc1 = a1; acc2 = a2;
-                lc0 = r1.z; lc1 = r1.w; lc2 = cb;
-                last_alpha = alpha;
-            }
-            // ---- 64-lane reduce-scatter of v[0..7], plain reduction of v[8] ----
+            v[0] = q * ev.u; v[1] = q * ev.w;
+            v[2] = h * dx; v[3] = h * dy; v[4] = qy * dy;
+            v[5] = q;
+            v[6] = dch * dL0; v[7] = dch * dL1; v[8] = dch * dL2;
+            // ---- reduce-scatter of v[0..7] inside quads, v[8] all-reduced alongside ----
             float a[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -267,21 +271,45 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
                 const float send = p0 ? v[k] : v[4 + k];
                 a[k] = keep + dpp_mov<0xB1>(send);
             }
-            float r[2];
+            float r[3];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const float keep = p1 ? a[2 + k] : a[k];
                 const float send = p1 ? a[k] : a[2 + k];
                 r[k] = keep + dpp_mov<0x4E>(send);
+            }
+            r[2] = v[8] + dpp_mov<0xB1>(v[8]);
+            r[2] += dpp_mov<0x4E>(r[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {                          // all-reduce inside each 16-lane row
                 r[k] += dpp_mov<0x124>(r[k]);
                 r[k] += dpp_mov<0x128>(r[k]);
-                r[k] = cross_row_allreduce(r[k]);
             }
-            const float v8 = wave_allreduce_sum(v[8]);
-            // lanes 0..3 hold the totals of components vbase, vbase+1 (0,1 | 4,5 | 2,3 | 6,7); lane 4 adds #8
-            float* gdst = grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS;
-            if (lane < 4) unsafeAtomicAdd(gdst + vbase, r[0]);
-            if (lane < 5) unsafeAtomicAdd(gdst + (lane == 4 ? 8 : vbase + 1), lane == 4 ? v8 : r[1]);
+            // positions 0..3 of every row hold components (vbase, vbase+1) = (0,1 | 4,5 | 2,3 | 6,7), position 4 adds #8
+            if (LDS_ACC) {
+                if (sub < 4) atomicAdd(&s_acc[vbase * ACC_STRIDE + e], r[0]);
+                if (sub < 5) atomicAdd(&s_acc[(sub == 4 ? 8 : vbase + 1) * ACC_STRIDE + e], sub == 4 ? r[2] : r[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r[k] = cross_row_allreduce(r[k]);
+                float* gdst = grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS;
+                if (lane < 4) unsafeAtomicAdd(gdst + vbase, r[0]);
+                if (lane < 5) unsafeAtomicAdd(gdst + (lane == 4 ? 8 : vbase + 1), lane == 4 ? r[2] : r[1]);
+            }
+        }
+        if (LDS_ACC) {
+            __syncthreads();
+            // commit the batch: 16 lanes per record (9 active) -> 4 records per wave instruction
+            for (int i = tid; i < n * 16; i += 256) {
+                const int e = i >> 4, k = i & 15;
+                if (k < 9) {
+                    const float val = s_acc[k * ACC_STRIDE + e];
+                    if (val != 0.0f) {
+                        s_acc[k * ACC_STRIDE + e] = 0.0f;
+                        unsafeAtomicAdd(grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS + k, val);
+                    }
+                }
+            }
         }
     }
 }
@@ -330,8 +358,16 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T, n_contrib,
-                       dL_dcolor, grad_rec);
+    // Default: cross-row reduction in registers + direct global atomics (664 us at C3).  MSGS_BWD_LDS_ACC=1
+    // selects the per-batch LDS accumulator variant (4x fewer global atomics but an extra barrier and a
+    // flush pass per batch: 903 us at C3, profiles/r1_notes.md) for A/B measurements.
+    static const bool direct = [] { const char* e = getenv("MSGS_BWD_LDS_ACC"); return !(e && e[0] == '1'); }();
+    if (direct)
+        hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
+                           n_contrib, dL_dcolor, grad_rec);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
+                           n_contrib, dL_dcolor, grad_rec);
     return hipGetLastError();
 }
 

@@ -15,14 +15,18 @@ constexpr int WAVE = 64;
 // ---------------------------------------------------------------------------------------------
 // Per-Gaussian record read by the blend kernels: 3 x float4 = 48 B, one aligned AoS record so a
 // gather costs three 16-B loads from one or two 64-B lines.
-//   r0 = { px, py, conic.A, conic.B }
-//   r1 = { conic.C, opacity_eff, r, g }
-//   r2 = { b, depth, pixel_size, tau }      tau = ln(255*opacity_eff) + margin (exact-cull bound)
+// The conic is stored pre-scaled into the log2 domain (k = -1/2 log2 e):
+//   r0 = { px, py, k*conic.A, k*conic.B }
+//   r1 = { k*conic.C, log2(opacity_eff), r, g }
+//   r2 = { b, depth, pixel_size, tau2 }     tau2 = -log2(255*opacity_eff) - margin (exact-cull bound;
+//                                           > 0 if the Gaussian can never reach alpha 1/255, -3e38 if the
+//                                           form is not negative definite and cannot be bounded)
 struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2; };
 
 // Per-Gaussian 2-D gradient record accumulated by the blend backward: 12 floats = 48 B.
-//   [0..1] dL/dmean2D (NDC-ish units)  [2..4] dL/dconic (A, B-half, C)  [5] dL/dopacity_eff
-//   [6..8] dL/drgb   [9..11] pad
+//   [0] sum q u  [1] sum q w  [2] sum q dx^2  [3] sum q dx dy  [4] sum q dy^2  [5] sum q  [6..8] dL/drgb
+//   [9..11] pad, with q = alpha_raw dL/dalpha; preprocess_backward_kernel turns [0..5] into
+//   dL/dmean2D (NDC-ish units), dL/dconic (A, B-half, C) and dL/dopacity with per-Gaussian factors.
 constexpr int GRAD_REC_FLOATS = 12;
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -117,33 +121,35 @@ struct ImageLayout {
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
 
-// Exact-culling test: does the alpha >= 1/255 level set  q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy <= tau
-// of a Gaussian centred at (gx, gy) intersect the rectangle of pixel centres [x0,x1] x [y0,y1]?
-// Conservative by construction (tau carries a safety margin), written with explicit roundings so
-// that every caller (count, emit) gets bit-identical answers whatever the surrounding code is.
-__device__ __forceinline__ bool ellipse_hits_rect(float gx, float gy, float A, float B, float C,
-                                                  float tau, float x0, float x1, float y0, float y1) {
+// Exact-culling test in the log2 domain.  The record stores the NEGATIVE-definite form
+//   f(d) = A dx^2 + 2 Bh dx dy + C dy^2  = log2 G(d)     (A, Bh, C = -1/2 log2(e) x conic)
+// and alpha(d) >= 1/255  <=>  f(d) >= tau2 = -log2(255 o).  Does the level set {f >= tau2} of a Gaussian
+// centred at (gx, gy) reach a pixel centre of the rectangle [x0,x1] x [y0,y1]?  f is concave with its
+// maximum (0) at the centre, so the maximum over a rectangle that does not contain the centre lies on
+// one of the (at most two) edges facing it.  Conservative by construction (tau2 carries a safety
+// margin), written with explicit roundings so that every caller (count, emit, quadrant masks) gets
+// bit-identical answers whatever the surrounding code is.
+__device__ __forceinline__ bool levelset_hits_rect(float gx, float gy, float A, float Bh, float C,
+                                                   float tau2, float x0, float x1, float y0, float y1) {
     const float dxlo = __fsub_rn(gx, x1), dxhi = __fsub_rn(gx, x0);
     const float dylo = __fsub_rn(gy, y1), dyhi = __fsub_rn(gy, y0);
     const float cx = fminf(fmaxf(0.0f, dxlo), dxhi);
     const float cy = fminf(fmaxf(0.0f, dylo), dyhi);
     if (cx == 0.0f && cy == 0.0f) return true;          // centre inside the rectangle
-    float qmin = 3.0e38f;
+    float fbest = -3.0e38f;
     if (cx != 0.0f) {                                    // facing vertical edge dx = cx
-        float dy = __fdiv_rn(-__fmul_rn(B, cx), C);
+        float dy = __fdiv_rn(-__fmul_rn(Bh, cx), C);
         dy = fminf(fmaxf(dy, dylo), dyhi);
-        const float q = __fmaf_rn(__fmul_rn(B, cx), dy,
-                                  __fmul_rn(0.5f, __fmaf_rn(__fmul_rn(A, cx), cx, __fmul_rn(__fmul_rn(C, dy), dy))));
-        qmin = fminf(qmin, q);
+        const float u = __fmaf_rn(A, cx, __fmul_rn(Bh, dy)), w = __fmaf_rn(C, dy, __fmul_rn(Bh, cx));
+        fbest = fmaxf(fbest, __fmaf_rn(cx, u, __fmul_rn(dy, w)));
     }
     if (cy != 0.0f) {                                    // facing horizontal edge dy = cy
-        float dx = __fdiv_rn(-__fmul_rn(B, cy), A);
+        float dx = __fdiv_rn(-__fmul_rn(Bh, cy), A);
         dx = fminf(fmaxf(dx, dxlo), dxhi);
-        const float q = __fmaf_rn(__fmul_rn(B, dx), cy,
-                                  __fmul_rn(0.5f, __fmaf_rn(__fmul_rn(A, dx), dx, __fmul_rn(__fmul_rn(C, cy), cy))));
-        qmin = fminf(qmin, q);
+        const float u = __fmaf_rn(A, dx, __fmul_rn(Bh, cy)), w = __fmaf_rn(C, cy, __fmul_rn(Bh, dx));
+        fbest = fmaxf(fbest, __fmaf_rn(dx, u, __fmul_rn(cy, w)));
     }
-    return qmin <= tau;
+    return fbest >= tau2;
 }
 
 // DPP move helper (gfx9 DPP controls: quad_perm 0x00-0xFF, row_shl 0x101-0x10F, row_shr 0x111-0x11F,

@@ -244,28 +244,30 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         }
         // exact tile-overlap count (this build's replacement for tiles_touched = rect area): a tile
         // is kept only if the alpha >= 1/255 level set reaches one of its pixel centres.
+        constexpr float KLOG = -0.72134752044448170368f;            // -1/2 log2(e)
+        const float sA = KLOG * conA, sBh = KLOG * conB, sC = KLOG * conC;
         const float v255 = 255.0f * o_eff;
-        float tau = -1.0f;
+        float tau2 = 1.0f;                                           // > 0: unreachable
         uint32_t count = 0;
-        const bool psd = conA > 0.f && conC > 0.f && (conA * conC - conB * conB) > 0.f;
+        const bool nd = sA < 0.f && sC < 0.f && (sA * sC - sBh * sBh) > 0.f;
         if (v255 > 1.0f) {
-            tau = logf(v255);
-            tau = tau + (1e-5f * tau + 1e-3f);
-            if (psd) {
+            tau2 = -__log2f(v255);
+            tau2 = tau2 - (1e-5f * fabsf(tau2) + 2e-3f);
+            if (nd) {
                 for (int ty = miny; ty < maxy; ++ty)
                     for (int tx = minx; tx < maxx; ++tx) {
                         const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-                        count += ellipse_hits_rect(px, py, conA, conB, conC, tau, x0, x0 + (TILE - 1), y0,
-                                                   y0 + (TILE - 1)) ? 1u : 0u;
+                        count += levelset_hits_rect(px, py, sA, sBh, sC, tau2, x0, x0 + (TILE - 1), y0,
+                                                    y0 + (TILE - 1)) ? 1u : 0u;
                     }
             } else {
-                tau = 3.0e38f;                                       // cannot bound: keep the whole rect
+                tau2 = -3.0e38f;                                     // cannot bound: keep the whole rect
                 count = (uint32_t)((maxx - minx) * (maxy - miny));
             }
         }
-        rec[i].r0 = make_float4(px, py, conA, conB);
-        rec[i].r1 = make_float4(conC, o_eff, rgb[0], rgb[1]);
-        rec[i].r2 = make_float4(rgb[2], t[2], out_psize, tau);
+        rec[i].r0 = make_float4(px, py, sA, sBh);
+        rec[i].r1 = make_float4(sC, __log2f(o_eff), rgb[0], rgb[1]);
+        rec[i].r2 = make_float4(rgb[2], t[2], out_psize, tau2);
         out_radius = (int32_t)my_radius;
         out_tiles = count;
         out_key = count ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
@@ -296,7 +298,6 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     if (i >= P) return;
     const GeomLayout L(P);
     const uint32_t* flags = reinterpret_cast<const uint32_t*>(geom + L.flags);
-    const float* weight = reinterpret_cast<const float*>(geom + L.weight);
     const int K = vp.sh_coeffs;
     const int deg = vp.sh_degree;
 
@@ -315,9 +316,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
         const float4 ga = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 0];
         const float4 gb = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 1];
         const float4 gc = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 2];
-        g2x = ga.x; g2y = ga.y;
-        const float gA = ga.z, gBh = ga.w, gC = gb.x;
-        dopac = weight[i] * gb.y;                                         // SPEC M4
+        // blend_backward_kernel accumulates [sum q u, sum q w, sum q dx^2, sum q dx dy, sum q dy^2, sum q]
+        // with q = alpha_raw dL/dalpha; the per-Gaussian constant factors are applied here (blend.hip).
+        constexpr float LN2 = 0.69314718055994530942f;
+        g2x = ga.x * (LN2 * vp.W); g2y = ga.y * (LN2 * vp.H);           // 2 ln2 * 0.5 W  (NDC-ish units)
+        const float gA = -0.5f * ga.z, gBh = -0.5f * ga.w, gC = -0.5f * gb.x;
+        const float o_in = g.opacities[i];
+        dopac = o_in > 0.f ? gb.y / o_in : 0.f;                         // (q / (o w)) * w, SPEC M4
         dcolr[0] = gb.z; dcolr[1] = gb.w; dcolr[2] = gc.x;
         const uint32_t fl = flags[i];
         const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
