@@ -1,8 +1,8 @@
 // binning.hip — instance emission and tile ranges (App. A.2).
 //
 // emit_kernel walks the Gaussians in DEPTH ORDER (order[] from the depth sort) and writes one
-// (tile id, Gaussian id) pair per tile whose pixel centres the Gaussian's alpha >= 1/255 level set
-// reaches, at the slot given by the exclusive scan of the per-Gaussian counts.  The subsequent
+// (tile id, Gaussian id) pair per tile that the Gaussian's alpha >= 1/255 level set reaches (the same
+// per-row extents preprocess_kernel counted), at the slot given by the exclusive scan of the per-Gaussian counts.  The subsequent
 // stable sort by tile id (sort.hip) then produces, inside every tile, the reference order
 // (depth bits ascending, ties by Gaussian index).
 //
@@ -14,40 +14,72 @@ namespace msgs {
 
 namespace {
 
+// Block b handles ranks [256 b, 256 b + 256): their output slots form ONE contiguous range
+// [offs[first], offs[last] + tiles[last]).  When that range fits the LDS stage (the normal case: ~4 tiles
+// per Gaussian) every thread deposits its pairs in LDS and the block streams the stage out with fully
+// coalesced stores; otherwise (huge Gaussians) threads store straight to global memory.
+constexpr int EMIT_STAGE = 3072;   // pairs: 24 KB of LDS
+
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids,
                                                    int64_t D) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
+    __shared__ uint32_t s_keys[EMIT_STAGE];
+    __shared__ uint32_t s_ids[EMIT_STAGE];
+    __shared__ int64_t s_range[2];
     const GeomLayout L(P);
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
     const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
     const uint32_t* tiles = reinterpret_cast<const uint32_t*>(geom + L.tiles);
     const uint2* rect = reinterpret_cast<const uint2*>(geom + L.rect);
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + L.rec);
-    const uint32_t gi = order[r];
-    const uint32_t count = tiles[gi];
-    if (count == 0) return;
-    int64_t off = offs[r];
-    const int64_t end = min((int64_t)off + count, D);
-    const uint2 rc = rect[gi];
-    const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
-    const float4 r0 = rec[gi].r0;
-    const float conC = rec[gi].r1.x;
-    const float tau2 = rec[gi].r2.w;
-    const bool test = tau2 > -1.0e38f;
-    for (int ty = miny; ty < maxy && off < end; ++ty)
-        for (int tx = minx; tx < maxx && off < end; ++tx) {
-            const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-            if (!test || levelset_hits_rect(r0.x, r0.y, r0.z, r0.w, conC, tau2, x0, x0 + (TILE - 1), y0, y0 + (TILE - 1))) {
-                keys[off] = (uint32_t)(ty * vp.gx + tx);
-                ids[off] = gi;
+
+    const int r0 = blockIdx.x * blockDim.x;
+    const int r = r0 + threadIdx.x;
+    const int rlast = min(r0 + (int)blockDim.x, P) - 1;
+    uint32_t gi = 0, count = 0;
+    int64_t off = 0;
+    if (r < P) { gi = order[r]; count = tiles[gi]; off = offs[r]; }
+    if (threadIdx.x == 0) s_range[0] = off;
+    if (r == rlast) s_range[1] = min((int64_t)off + count, D);
+    __syncthreads();
+    const int64_t blk_lo = s_range[0], blk_hi = s_range[1];
+    const int64_t blk_len = blk_hi - blk_lo;
+    if (blk_len <= 0) return;
+    const bool staged = blk_len <= EMIT_STAGE;
+
+    if (count) {
+        const int64_t end = min((int64_t)off + count, D);
+        const uint2 rc = rect[gi];
+        const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
+        const float4 q0 = rec[gi].r0;
+        const float conC = rec[gi].r1.x;
+        const float tau2 = rec[gi].r2.w;
+        const bool test = tau2 > -1.0e38f;
+        const LevelSetRows ls = test ? levelset_rows_setup(q0.z, q0.w, conC, tau2) : LevelSetRows{};
+        for (int ty = miny; ty < maxy && off < end; ++ty) {
+            int tlo = minx, thi = maxx - 1;
+            if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, tlo, thi)) continue;
+            for (int tx = tlo; tx <= thi && off < end; ++tx) {
+                const uint32_t k = (uint32_t)(ty * vp.gx + tx);
+                if (staged) { s_keys[off - blk_lo] = k; s_ids[off - blk_lo] = gi; }
+                else { keys[off] = k; ids[off] = gi; }
                 ++off;
             }
         }
-    // Defensive: the count and this loop evaluate the same deterministic predicate, so the slots are
-    // always filled exactly; should they ever not be, park the leftovers on a sentinel tile.
-    for (; off < end; ++off) { keys[off] = (uint32_t)(vp.gx * vp.gy); ids[off] = gi; }
+        // Defensive: the count and this loop evaluate the same deterministic predicate, so the slots are
+        // always filled exactly; should they ever not be, park the leftovers on a sentinel tile.
+        for (; off < end; ++off) {
+            const uint32_t k = (uint32_t)(vp.gx * vp.gy);
+            if (staged) { s_keys[off - blk_lo] = k; s_ids[off - blk_lo] = gi; }
+            else { keys[off] = k; ids[off] = gi; }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)blk_len; i += blockDim.x) {
+        keys[blk_lo + i] = s_keys[i];
+        ids[blk_lo + i] = s_ids[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ keys, int64_t D,

@@ -152,6 +152,46 @@ __device__ __forceinline__ bool levelset_hits_rect(float gx, float gy, float A, 
     return fbest >= tau2;
 }
 
+// Per-tile-ROW extent of the same level set (used by the overlap count in preprocess_kernel and by
+// emit_kernel; both must agree bit for bit, hence the explicit roundings).  {f >= tau2} is an ellipse; its
+// intersection with the horizontal band of one tile row is convex, so the tiles it reaches in that row
+// form ONE interval [tlo, thi]: the x-range of (ellipse ∩ band) is bounded by the ellipse's extreme
+// points when they fall inside the band and by the band edges' chords otherwise.  O(rows) work per
+// Gaussian instead of O(tiles).  Conservative w.r.t. the per-pixel test (continuous rectangle + margin).
+struct LevelSetRows {
+    float A, Bh, C, Atau, det, invA, dymax, dyR;
+};
+__device__ __forceinline__ LevelSetRows levelset_rows_setup(float A, float Bh, float C, float tau2) {
+    LevelSetRows r;
+    r.A = A; r.Bh = Bh; r.C = C;
+    r.det = __fsub_rn(__fmul_rn(A, C), __fmul_rn(Bh, Bh));          // > 0 (negative definite form)
+    r.Atau = __fmul_rn(A, tau2);                                     // > 0
+    r.invA = __frcp_rn(A);
+    r.dymax = __fsqrt_rn(__fdiv_rn(r.Atau, r.det));
+    const float dx_ext = __fsqrt_rn(__fdiv_rn(__fmul_rn(C, tau2), r.det));
+    r.dyR = __fdiv_rn(-__fmul_rn(Bh, dx_ext), C);                    // dy where dx is extreme (+dx_ext)
+    return r;
+}
+// tile row ty (pixel rows 16 ty .. 16 ty + 15); returns false when the row is not reached
+__device__ __forceinline__ bool levelset_row_interval(const LevelSetRows& r, float gx, float gy, int ty, int minx,
+                                                      int maxx, int& tlo, int& thi) {
+    const float y0 = (float)(ty * TILE);
+    const float lo = fmaxf(__fsub_rn(gy, y0 + (float)(TILE - 1)), -r.dymax);
+    const float hi = fminf(__fsub_rn(gy, y0), r.dymax);
+    if (lo > hi) return false;
+    const float dyr = fminf(fmaxf(r.dyR, lo), hi);                   // where dx is largest inside the band
+    const float dyl = fminf(fmaxf(-r.dyR, lo), hi);                  // where dx is smallest
+    const float sr = __fsqrt_rn(fmaxf(0.0f, __fmaf_rn(-r.det, __fmul_rn(dyr, dyr), r.Atau)));
+    const float sl = __fsqrt_rn(fmaxf(0.0f, __fmaf_rn(-r.det, __fmul_rn(dyl, dyl), r.Atau)));
+    const float dx_max = __fmul_rn(__fsub_rn(-__fmul_rn(r.Bh, dyr), sr), r.invA);   // A < 0
+    const float dx_min = __fmul_rn(__fadd_rn(-__fmul_rn(r.Bh, dyl), sl), r.invA);
+    const float xl = __fsub_rn(__fsub_rn(gx, dx_max), 0.02f);        // pixel x = gx - dx
+    const float xr = __fadd_rn(__fsub_rn(gx, dx_min), 0.02f);
+    tlo = max(minx, (int)ceilf(__fmul_rn(__fsub_rn(xl, (float)(TILE - 1)), 1.0f / TILE)));
+    thi = min(maxx - 1, (int)floorf(__fmul_rn(xr, 1.0f / TILE)));
+    return tlo <= thi;
+}
+
 // DPP move helper (gfx9 DPP controls: quad_perm 0x00-0xFF, row_shl 0x101-0x10F, row_shr 0x111-0x11F,
 // row_ror 0x121-0x12F, row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143)
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = false>

@@ -156,6 +156,65 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, flo
     return r;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative movement of 192-byte SH rows (K = 16 coefficients x 3 channels) between HBM and
+// LDS.  A thread-per-Gaussian float4 access at a 192-B stride touches 64 different cache lines per
+// instruction (TA-bound, measured 25 % of HBM rate); here n4 consecutive lanes move one row's n4
+// float4 so every instruction covers 64/n4 whole rows.  LDS rows have a stride of 49 floats so the
+// later one-thread-per-row 4-byte accesses are bank-conflict free.
+// ---------------------------------------------------------------------------------------------
+// LDS hand-off between lanes of ONE wave: the hardware executes a wave's LDS operations in order; this
+// keeps the compiler from reordering across the phase boundary as well.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int ROW_F = 48;          // floats per SH row in HBM (K = 16)
+constexpr int ROW_LDS = 49;        // floats per row in LDS
+
+__device__ __forceinline__ int sh_row_float4s(int deg) { return deg == 0 ? 1 : deg == 1 ? 3 : deg == 2 ? 7 : 12; }
+
+// rows listed in idx[0..nrow) (lane numbers inside the wave) are loaded from g_rows + lane*48
+__device__ __forceinline__ void coop_load_rows(float* lds_rows, const float* g_rows, const uint8_t* idx, int nrow,
+                                               int n4, int lane) {
+    const int rpi = 64 / n4;
+    const int sub = lane / n4, c = lane - sub * n4;
+    for (int it = 0; it * rpi < nrow; ++it) {
+        const int slot = it * rpi + sub;
+        if (sub < rpi && slot < nrow) {
+            const int sl = idx[slot];
+            const float4 v = *reinterpret_cast<const float4*>(g_rows + (size_t)sl * ROW_F + 4 * c);
+            float* d = lds_rows + sl * ROW_LDS + 4 * c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+}
+
+// rows 0..nrow of the wave are stored to g_rows (all 12 float4 of every row); a row whose bit in
+// `live` is clear, and every float at or beyond nfloat, is written as zero
+__device__ __forceinline__ void coop_store_rows(const float* lds_rows, float* g_rows, int nrow, uint64_t live,
+                                                int nfloat, int lane) {
+    constexpr int n4 = ROW_F / 4, rpi = 64 / n4;            // 12 float4 per row, 5 rows per instruction
+    const int sub = lane / n4, c = lane - sub * n4;
+    for (int it = 0; it * rpi < nrow; ++it) {
+        const int row = it * rpi + sub;
+        if (sub < rpi && row < nrow) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((live >> row) & 1ull) {
+                const float* sp = lds_rows + row * ROW_LDS + 4 * c;
+                v.x = 4 * c + 0 < nfloat ? sp[0] : 0.f;
+                v.y = 4 * c + 1 < nfloat ? sp[1] : 0.f;
+                v.z = 4 * c + 2 < nfloat ? sp[2] : 0.f;
+                v.w = 4 * c + 3 < nfloat ? sp[3] : 0.f;
+            }
+            *reinterpret_cast<float4*>(g_rows + (size_t)row * ROW_F + 4 * c) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
@@ -163,9 +222,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                                                          int32_t* __restrict__ radii,
                                                          float* __restrict__ pixel_sizes,
                                                          char* __restrict__ geom) {
+    __shared__ float s_rows[4][64 * ROW_LDS];
+    __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in_range = i < P;
     const GeomLayout L(P);
     GaussRec* rec = reinterpret_cast<GaussRec*>(geom + L.rec);
     uint2* rect = reinterpret_cast<uint2*>(geom + L.rect);
@@ -183,11 +245,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     uint2 out_rect = make_uint2(0, 0);
     float out_weight = 0.f;
 
-    const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
-    float t[3];
-    view_point(cm.V, p, t);
+    // ---- phase A: geometry, pixel size, multi-scale filters (one lane per Gaussian) ----
+    bool alive = false;
+    float p[3] = {0.f, 0.f, 1.f}, t[3] = {0.f, 0.f, 0.f};
+    float conA = 0.f, conB = 0.f, conC = 0.f, px = 0.f, py = 0.f, my_radius = 0.f, w = 0.f, o_eff = 0.f;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (in_range) {
+        p[0] = g.means3D[3 * i]; p[1] = g.means3D[3 * i + 1]; p[2] = g.means3D[3 * i + 2];
+        view_point(cm.V, p, t);
+    }
     do {
-        if (t[2] <= 0.2f) break;                                    // Q1 near-plane cull
+        if (!in_range || t[2] <= 0.2f) break;                       // Q1 near-plane cull
         float h[4];
         proj_point(cm.M, p, h);
         const float pw = 1.0f / (h[3] + 0.0000001f);
@@ -197,35 +265,52 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 #pragma unroll
             for (int k = 0; k < 6; ++k) cov3D[k] = g.cov3D_precomp[6 * i + k];
         } else {
-            const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
+            const float sc[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
             const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
             const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            cov3d_from_scale_rot(s, vp.scale_modifier, q, cov3D);
+            cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov3D);
         }
         Cov2D c2;
         compute_cov2d(t, vp, cov3D, cm.V, c2);
         const float det = c2.a * c2.c - c2.b * c2.b;
         if (det == 0.0f) break;
         const float det_inv = 1.f / det;
-        const float conA = c2.c * det_inv, conB = -c2.b * det_inv, conC = c2.a * det_inv;
+        conA = c2.c * det_inv; conB = -c2.b * det_inv; conC = c2.a * det_inv;
         const float mid = 0.5f * (c2.a + c2.c);
         const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
         const float lam1 = mid + root, lam2 = mid - root;
-        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
-        const float px = ((ndc_x + 1.0f) * vp.W - 1.0f) * 0.5f;
-        const float py = ((ndc_y + 1.0f) * vp.H - 1.0f) * 0.5f;
+        my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+        px = ((ndc_x + 1.0f) * vp.W - 1.0f) * 0.5f;
+        py = ((ndc_y + 1.0f) * vp.H - 1.0f) * 0.5f;
         const float o = g.opacities[i];
         out_psize = pixel_size_of(o, conA, conC);                    // SPEC M1 (before any filter)
-        const int minx = min(vp.gx, max(0, (int)((px - my_radius) / TILE)));
-        const int miny = min(vp.gy, max(0, (int)((py - my_radius) / TILE)));
-        const int maxx = min(vp.gx, max(0, (int)((px + my_radius + TILE - 1) / TILE)));
-        const int maxy = min(vp.gy, max(0, (int)((py + my_radius + TILE - 1) / TILE)));
+        minx = min(vp.gx, max(0, (int)((px - my_radius) / TILE)));
+        miny = min(vp.gy, max(0, (int)((py - my_radius) / TILE)));
+        maxx = min(vp.gx, max(0, (int)((px + my_radius + TILE - 1) / TILE)));
+        maxy = min(vp.gy, max(0, (int)((py + my_radius + TILE - 1) / TILE)));
         if ((maxx - minx) * (maxy - miny) == 0) break;
-        const float w = filter_weight(vp, out_psize, g.min_pixel_sizes ? g.min_pixel_sizes[i] : -1.f,
-                                      g.max_pixel_sizes ? g.max_pixel_sizes[i] : -1.f,
-                                      g.base_mask ? g.base_mask[i] != 0 : false);
+        w = filter_weight(vp, out_psize, g.min_pixel_sizes ? g.min_pixel_sizes[i] : -1.f,
+                          g.max_pixel_sizes ? g.max_pixel_sizes[i] : -1.f,
+                          g.base_mask ? g.base_mask[i] != 0 : false);
         if (!(w > 0.f)) break;                                       // SPEC M2/M3: dropped, radii stays 0
-        const float o_eff = o * w;
+        o_eff = o * w;
+        alive = true;
+    } while (false);
+
+    // ---- phase B: SH rows of the surviving Gaussians, HBM -> LDS, coalesced per row ----
+    const bool staged_sh = g.shs != nullptr && vp.sh_coeffs == 16;   // wave-uniform
+    if (staged_sh) {
+        const uint64_t need = __ballot(alive);
+        if (alive) s_idx[wv][__popcll(need & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        wave_lds_fence();
+        const int wave_first = blockIdx.x * blockDim.x + wv * 64;
+        coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(need),
+                       sh_row_float4s(vp.sh_degree), lane);
+        wave_lds_fence();
+    }
+
+    // ---- phase C: colour, exact tile-overlap count, record ----
+    if (alive) {
         float rgb[3];
         if (g.colors_precomp) {
 #pragma unroll
@@ -234,7 +319,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
             const float dx = p[0] - cm.cam[0], dy = p[1] - cm.cam[1], dz = p[2] - cm.cam[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             const float x = dx / len, y = dy / len, z = dz / len;
-            const float* sh = g.shs + (size_t)3 * vp.sh_coeffs * i;
+            const float* sh = staged_sh ? (const float*)&s_rows[wv][lane * ROW_LDS]
+                                        : g.shs + (size_t)3 * vp.sh_coeffs * i;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float r = sh_channel(vp.sh_degree, sh, c, x, y, z) + 0.5f;
@@ -243,7 +329,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
             }
         }
         // exact tile-overlap count (this build's replacement for tiles_touched = rect area): a tile
-        // is kept only if the alpha >= 1/255 level set reaches one of its pixel centres.
+        // is kept only if the alpha >= 1/255 level set reaches it (per-row analytic extents).
         constexpr float KLOG = -0.72134752044448170368f;            // -1/2 log2(e)
         const float sA = KLOG * conA, sBh = KLOG * conB, sC = KLOG * conC;
         const float v255 = 255.0f * o_eff;
@@ -254,12 +340,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
             tau2 = -__log2f(v255);
             tau2 = tau2 - (1e-5f * fabsf(tau2) + 2e-3f);
             if (nd) {
-                for (int ty = miny; ty < maxy; ++ty)
-                    for (int tx = minx; tx < maxx; ++tx) {
-                        const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-                        count += levelset_hits_rect(px, py, sA, sBh, sC, tau2, x0, x0 + (TILE - 1), y0,
-                                                    y0 + (TILE - 1)) ? 1u : 0u;
-                    }
+                const LevelSetRows ls = levelset_rows_setup(sA, sBh, sC, tau2);
+                for (int ty = miny; ty < maxy; ++ty) {
+                    int tlo, thi;
+                    if (levelset_row_interval(ls, px, py, ty, minx, maxx, tlo, thi)) count += (uint32_t)(thi - tlo + 1);
+                }
             } else {
                 tau2 = -3.0e38f;                                     // cannot bound: keep the whole rect
                 count = (uint32_t)((maxx - minx) * (maxy - miny));
@@ -274,15 +359,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         out_flags |= 8u;
         out_rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
         out_weight = w;
-    } while (false);
-
-    radii[i] = out_radius;
-    pixel_sizes[i] = out_psize;
-    rect[i] = out_rect;
-    tiles[i] = out_tiles;
-    key[i] = out_key;
-    flags[i] = out_flags;
-    weight[i] = out_weight;
+    }
+    if (in_range) {
+        radii[i] = out_radius;
+        pixel_sizes[i] = out_psize;
+        rect[i] = out_rect;
+        tiles[i] = out_tiles;
+        key[i] = out_key;
+        flags[i] = out_flags;
+        weight[i] = out_weight;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,9 +379,12 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
                                                                   const char* __restrict__ geom,
                                                                   const float* __restrict__ grad_rec,
                                                                   msgs_grads_t grads) {
+    __shared__ float s_rows[4][64 * ROW_LDS];
+    __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in_range = i < P;
     const GeomLayout L(P);
     const uint32_t* flags = reinterpret_cast<const uint32_t*>(geom + L.flags);
     const int K = vp.sh_coeffs;
@@ -307,8 +396,21 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     float dcolr[3] = {0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool rendered = radii[i] > 0;
-    float* dsh = grads.dL_dshs ? grads.dL_dshs + (size_t)3 * K * i : nullptr;
+    const bool rendered = in_range && radii[i] > 0;
+    // SH rows in / dSH rows out through LDS with coalesced wave-cooperative transfers (K == 16 only;
+    // other layouts take the direct per-thread path)
+    const bool staged_sh = g.shs != nullptr && grads.dL_dshs != nullptr && K == 16;   // wave-uniform
+    const int wave_first = blockIdx.x * blockDim.x + wv * 64;
+    const uint64_t live = __ballot(rendered);
+    if (staged_sh) {
+        if (rendered) s_idx[wv][__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        wave_lds_fence();
+        coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(live),
+                       sh_row_float4s(deg), lane);
+        wave_lds_fence();
+    }
+    float* dsh = staged_sh ? &s_rows[wv][lane * ROW_LDS]
+                           : (grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr);
 
     if (rendered) {
         Cam cm;
@@ -409,7 +511,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 if (fl & (1u << c)) dcolr[c] = 0.f;                                // Q8
-            const float* sh = g.shs + (size_t)3 * K * i;
+            const float* sh = staged_sh ? (const float*)&s_rows[wv][lane * ROW_LDS] : g.shs + (size_t)3 * K * i;
             const float dox = p[0] - cm.cam[0], doy = p[1] - cm.cam[1], doz = p[2] - cm.cam[2];
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
             const float x = dox / len, y = doy / len, z = doz / len;
@@ -419,8 +521,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
                 float s = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
+                    const float shv = sh[k * 3 + c];          // read first: sh and dsh share the LDS row
                     if (dsh) dsh[k * 3 + c] = basis * dcolr[c];
-                    s += sh[k * 3 + c] * dcolr[c];
+                    s += shv * dcolr[c];
                 }
                 ddir[0] += bx * s; ddir[1] += by * s; ddir[2] += bz * s;
             };
@@ -448,7 +551,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
                 }
             }
             const int ncoef = (deg + 1) * (deg + 1);
-            if (dsh)
+            if (dsh && !staged_sh)
                 for (int k = ncoef; k < K; ++k) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
             const float dotv = x * ddir[0] + y * ddir[1] + z * ddir[2];
             dmean[0] += (ddir[0] - x * dotv) / len;
@@ -483,9 +586,17 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
             dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
             dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
-    } else if (dsh) {
+    } else if (dsh && !staged_sh) {
         for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
     }
+    if (staged_sh) {
+        wave_lds_fence();
+        const int nrow = min(64, P - wave_first);
+        if (nrow > 0)
+            coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)wave_first * ROW_F, nrow, live,
+                            3 * (deg + 1) * (deg + 1), lane);
+    }
+    if (!in_range) return;
 
     if (grads.dL_dmeans3D) { grads.dL_dmeans3D[3 * i] = dmean[0]; grads.dL_dmeans3D[3 * i + 1] = dmean[1]; grads.dL_dmeans3D[3 * i + 2] = dmean[2]; }
     if (grads.dL_dmeans2D) { grads.dL_dmeans2D[3 * i] = g2x; grads.dL_dmeans2D[3 * i + 1] = g2y; grads.dL_dmeans2D[3 * i + 2] = 0.f; }
