@@ -46,6 +46,7 @@ extern "C" {
 #define MSGS_ERR_CAPACITY (-2)     /* a caller-supplied buffer is smaller than the size query says   */
 #define MSGS_ERR_TOO_MANY (-3)     /* more than 2^32-1 tile instances                                */
 #define MSGS_ERR_SH_DEGREE (-4)    /* sh_degree outside 0..3 or (sh_degree+1)^2 > sh_coeffs          */
+#define MSGS_ERR_INTERNAL (-5)     /* a bounded inter-workgroup wait expired (sort/scan look-back)     */
 
 #define MSGS_TILE 16               /* 16x16 pixel tiles                     */
 

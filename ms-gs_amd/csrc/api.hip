@@ -70,6 +70,7 @@ const char* msgs_error_string(int code) {
         case MSGS_ERR_CAPACITY: return "a caller-supplied buffer is smaller than its size query";
         case MSGS_ERR_TOO_MANY: return "more than 2^32-1 tile instances";
         case MSGS_ERR_SH_DEGREE: return "sh_degree must be 0..3 and (sh_degree+1)^2 <= sh_coeffs";
+        case MSGS_ERR_INTERNAL: return "internal error: a look-back wait in the sort/scan kernels timed out";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -126,9 +127,19 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s));
     tm.end(MSGS_K_SCAN);
 
-    uint64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    // one synchronisation, one D2H copy: {instance count, look-back watchdog flags} (sort.hip)
+    uint64_t host_status[2] = {0, 0};
+    uint64_t* status_dev = total_dev + 2;
+    const SortScratch SSL(P);
+    const bool classic = use_classic_sort();
+    HIP_TRY(launch_collect_status(total_dev,
+                                  classic ? nullptr : (const uint32_t*)(scratch + SL.sort + SSL.hist) + 4 * 256 + 4,
+                                  classic ? nullptr : (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
+                                  status_dev, s));
+    HIP_TRY(hipMemcpyAsync(host_status, status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t total = host_status[0];
+    if (host_status[1] != 0) return MSGS_ERR_INTERNAL;
     if (total > 0xFFFFFFFFull) return MSGS_ERR_TOO_MANY;
     *num_instances_host = (int64_t)total;
     return MSGS_OK;

@@ -66,7 +66,9 @@ struct SortScratch {
         int64_t nb = sort_blocks(n > 0 ? n : 1);
         keys_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
         vals_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
-        hist = o;     o = align256(o + 4 * (size_t)256 * nb);
+        // classic path: 256 x nb block histograms; onesweep path: 4x256 digit histograms + tickets + error
+        // flag (64 words) + up to 4 passes x nb x 256 look-back status words
+        hist = o;     o = align256(o + 4 * ((size_t)4 * 256 + 64 + (size_t)4 * 256 * nb));
         partials = o; o = align256(o + 8 * (size_t)(scan_blocks(256 * nb) + 2));
         total = o;
     }
@@ -79,7 +81,7 @@ struct Stage1Scratch {
         keys_a = o;        o = align256(o + 4 * (size_t)(P > 0 ? P : 1));
         sort = o;          o = align256(o + SortScratch(P).total);
         scan_partials = o; o = align256(o + 8 * (size_t)(scan_blocks(P > 0 ? P : 1) + 2));
-        total_out = o;     o = align256(o + 16);
+        total_out = o;     o = align256(o + 64);    // {scan total} and the collected status block
         total = o;
     }
 };
@@ -279,6 +281,9 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
 // out[r] = exclusive sum of in[gather ? gather[r] : r]; *total (device, u64) = grand total
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s);
+bool use_classic_sort();
+hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
+                                 uint64_t* out, hipStream_t s);
 // binning.hip
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s);

@@ -207,13 +207,242 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// single-pass ("onesweep") variants with decoupled look-back
+// ---------------------------------------------------------------------------------------------
+// Inter-workgroup protocol (cdna_hip_programming.md §6 G16, form R2 "the data IS the flag"): every
+// exchanged quantity is ONE naturally aligned word {2-bit state | value} written with a single relaxed
+// agent-scope atomic store and polled with relaxed agent-scope atomic loads, so no payload ordering or
+// fence is needed.  Workgroups take their logical index from an atomic ticket, so a workgroup only ever
+// waits for workgroups that started before it (no dependence on dispatch order or placement).  All
+// status words and tickets are zeroed by a memset node ahead of the launch.  Spins are bounded: on
+// expiry the kernel raises *err and gives up (results are then garbage and the host reports it).
+constexpr uint32_t LB_AGG = 1u, LB_INC = 2u;
+constexpr uint32_t LB_VALUE_MASK = 0x3FFFFFFFu;
+constexpr int LB_MAX_SPINS = 1 << 24;
+
+__device__ __forceinline__ void lb_store32(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t lb_load32(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lb_store64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_load64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// digit histograms of up to 4 digit places in one pass over the keys: out[pass][256]
+__global__ __launch_bounds__(256) void radix_hist_all_kernel(const uint32_t* __restrict__ keys, int64_t n,
+                                                             int begin_bit, int end_bit, int passes,
+                                                             uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_hist[4][256];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s_hist[p][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = keys[i];
+        for (int p = 0; p < passes; ++p) {
+            const int shift = begin_bit + 8 * p;
+            const int bits = min(8, end_bit - shift);
+            atomicAdd(&s_hist[p][(k >> shift) & ((1u << bits) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t c = s_hist[p][threadIdx.x];
+        if (c) atomicAdd(&out[p * 256 + threadIdx.x], c);
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, int64_t n,
+                                                                int shift, uint32_t mask,
+                                                                const uint32_t* __restrict__ digit_hist,
+                                                                uint32_t* __restrict__ status,
+                                                                uint32_t* __restrict__ ticket,
+                                                                uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_cnt[4][256];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_block;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_block = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t b = s_block;
+    const int64_t chunk_base = (int64_t)b * SORT_CHUNK;
+
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = elem_index(chunk_base, w, r, lane);
+        const bool valid = i < n;
+        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+        const uint32_t d = (key[r] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const uint64_t m = __ballot((d >> bb) & 1u);
+            peers &= ((d >> bb) & 1u) ? m : ~m;
+        }
+        const uint32_t prev = s_cnt[w][d];
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        rank[r] = prev + before;
+        if (valid && before == 0) s_cnt[w][d] = prev + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    {   // thread t owns digit t
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+        const uint32_t total = c0 + c1 + c2 + c3;
+        uint32_t* my = status + (size_t)b * 256 + d;
+        lb_store32(my, ((b == 0 ? LB_INC : LB_AGG) << 30) | total);
+        // position of digit d in the output = (keys with a smaller digit) + (same digit in earlier chunks)
+        uint32_t dummy;
+        const uint32_t digit_base = block_exclusive_scan(digit_hist[d], s_wave, &dummy);
+        uint32_t excl = 0;
+        if (b > 0) {
+            int64_t p = (int64_t)b - 1;
+            int spins = 0;
+            while (true) {
+                const uint32_t sv = lb_load32(status + (size_t)p * 256 + d);
+                const uint32_t st = sv >> 30;
+                if (st == 0) {
+                    if (++spins > LB_MAX_SPINS) { atomicExch(err, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += sv & LB_VALUE_MASK;
+                if (st == LB_INC || p == 0) break;
+                --p;
+            }
+            lb_store32(my, (LB_INC << 30) | ((excl + total) & LB_VALUE_MASK));
+        }
+        const uint32_t base = digit_base + excl;
+        s_cnt[0][d] = base;
+        s_cnt[1][d] = base + c0;
+        s_cnt[2][d] = base + c0 + c1;
+        s_cnt[3][d] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t i = elem_index(chunk_base, w, r, lane);
+        if (i < n) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t pos = s_cnt[w][d] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = val[r];
+        }
+    }
+}
+
+// single-pass exclusive scan with look-back; status words are {2-bit state | 62-bit value}
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint32_t* __restrict__ in,
+                                                                     const uint32_t* __restrict__ gather,
+                                                                     uint32_t* __restrict__ out, int64_t n,
+                                                                     unsigned long long* __restrict__ status,
+                                                                     uint32_t* __restrict__ ticket,
+                                                                     uint64_t* __restrict__ total_out,
+                                                                     uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_block;
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_block = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t b = s_block;
+    const int64_t nb = scan_blocks(n);
+    const int64_t base = (int64_t)b * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        v[k] = i < n ? (gather ? in[gather[i]] : in[i]) : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    const uint32_t local = block_exclusive_scan(sum, s_wave, &total);
+    if (threadIdx.x == 0) {
+        constexpr unsigned long long VM = (1ull << 62) - 1ull;
+        lb_store64(status + b, ((unsigned long long)(b == 0 ? LB_INC : LB_AGG) << 62) | total);
+        unsigned long long excl = 0;
+        if (b > 0) {
+            int64_t p = (int64_t)b - 1;
+            int spins = 0;
+            while (true) {
+                const unsigned long long sv = lb_load64(status + p);
+                const uint32_t st = (uint32_t)(sv >> 62);
+                if (st == 0) {
+                    if (++spins > LB_MAX_SPINS) { atomicExch(err, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += sv & VM;
+                if (st == LB_INC || p == 0) break;
+                --p;
+            }
+            lb_store64(status + b, ((unsigned long long)LB_INC << 62) | ((excl + total) & VM));
+        }
+        s_excl = excl;
+        if ((int64_t)b == nb - 1 && total_out) *total_out = excl + total;
+    }
+    __syncthreads();
+    uint32_t run = local + (uint32_t)s_excl;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+    }
+}
+
 }  // namespace
+
+// Default: the three-kernel-per-pass path (no inter-workgroup waiting).  MSGS_SORT_ONESWEEP=1 selects the
+// single-kernel-per-pass look-back variants; on MI355X they measured the same per-pass time (every
+// workgroup of a 1-4 M key pass is resident at once, so the per-digit look-back walk costs ~0.1 us per
+// workgroup and cancels the saved launches: profiles/r1_notes.md), so the spin-free path is the default.
+bool use_classic_sort() {
+    static const bool v = [] { const char* e = getenv("MSGS_SORT_ONESWEEP"); return !(e && e[0] == '1'); }();
+    return v;
+}
+
+// stage-1 status block {u64 total, u32 sort watchdog, u32 scan watchdog, ...}: one D2H copy for the host
+__global__ void collect_status_kernel(const uint64_t* __restrict__ total, const uint32_t* __restrict__ sort_err,
+                                      const uint32_t* __restrict__ scan_err, uint64_t* __restrict__ out) {
+    out[0] = *total;
+    out[1] = (uint64_t)(sort_err ? *sort_err : 0u) | ((uint64_t)(scan_err ? *scan_err : 0u) << 32);
+}
+
+hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
+                                 uint64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(collect_status_kernel, dim3(1), dim3(1), 0, s, total, sort_err, scan_err, out);
+    return hipGetLastError();
+}
 
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s) {
     const int64_t nb = scan_blocks(n > 0 ? n : 1);
     if (n <= 0) {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total);
+        return hipGetLastError();
+    }
+    if (!use_classic_sort()) {
+        // partials[0..nb) = status words, partials[nb] = ticket (low half) + error flag (high half)
+        hipError_t e = hipMemsetAsync(partials, 0, sizeof(uint64_t) * (size_t)(nb + 2), s);
+        if (e != hipSuccess) return e;
+        uint32_t* tk = reinterpret_cast<uint32_t*>(partials + nb);
+        hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n,
+                           reinterpret_cast<unsigned long long*>(partials), tk, total, tk + 1);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials);
@@ -233,6 +462,20 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     const int64_t nb = sort_blocks(n);
     int passes = (end_bit - begin_bit + 7) / 8;
     if (passes < 1) passes = 1;
+    const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
+    // onesweep carve-up of the `hist` region: [4][256] digit histograms, [4] tickets, [1] error flag,
+    // then per pass nb x 256 status words
+    uint32_t* digit_hist = hist;
+    uint32_t* tickets = hist + 4 * 256;
+    uint32_t* err = tickets + 4;
+    uint32_t* status = hist + 4 * 256 + 64;
+    if (onesweep) {
+        hipError_t e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * (4 * 256 + 64 + (size_t)passes * 256 * nb), s);
+        if (e != hipSuccess) return e;
+        const int hb = (int)(nb < 1024 ? nb : 1024);
+        hipLaunchKernelGGL(radix_hist_all_kernel, dim3(hb), dim3(256), 0, s, keys_in, n, begin_bit, end_bit, passes,
+                           digit_hist);
+    }
     // ping-pong so that the LAST pass writes keys_out/vals_out
     const uint32_t* src_k = keys_in;
     const uint32_t* src_v = vals_in;
@@ -243,11 +486,16 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         uint32_t* dst_k = to_out ? keys_out : keys_alt;
         uint32_t* dst_v = to_out ? vals_out : vals_alt;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist);
-        hipError_t e = exclusive_scan_u32(hist, nullptr, hist, 256 * nb, partials, nullptr, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k,
-                           dst_v, n, shift, mask, nb, hist);
+        if (onesweep) {
+            hipLaunchKernelGGL(onesweep_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k, dst_v,
+                               n, shift, mask, digit_hist + p * 256, status + (size_t)p * 256 * nb, tickets + p, err);
+        } else {
+            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist);
+            hipError_t e = exclusive_scan_u32(hist, nullptr, hist, 256 * nb, partials, nullptr, s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k,
+                               dst_v, n, shift, mask, nb, hist);
+        }
         src_k = dst_k;
         src_v = dst_v;
     }
