@@ -79,6 +79,7 @@ struct msgs_oracle_state {
     // flat copies for introspection
     std::vector<float> depths, conic_opacity, rgb, means2D, cov3D;
     std::vector<int32_t> rects;
+    std::vector<uint8_t> borderline_gauss;  // Gaussian had an alpha within rounding distance of 1/255 on some pixel
     int64_t traversed = 0;
 };
 
@@ -321,6 +322,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     // ---- K6 blend forward (App. A.2) ----
     st->final_T.assign((size_t)W * H, 1.0f);
     st->n_contrib.assign((size_t)W * H, 0);
+    st->borderline_gauss.assign(P, 0);
     const float bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
     int64_t traversed = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : traversed)
@@ -343,7 +345,12 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                     float power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                     if (power > 0.0f) continue;
                     float alpha = std::min(0.99f, ge.opacity * std::exp(power));        // Q6
-                    if (std::fabs(alpha * 255.0f - 1.0f) < 2e-5f) flag = true;
+                    if (std::fabs(alpha * 255.0f - 1.0f) < 2e-5f) {
+                        flag = true;
+                        uint8_t* bg_flag = &st->borderline_gauss[st->list[k]];
+#pragma omp atomic write
+                        *bg_flag = 1;
+                    }
                     if (alpha < 1.0f / 255.0f) continue;                                 // Q7
                     float test_T = T * (1 - alpha);
                     if (std::fabs(test_T - 0.0001f) < 2e-8f) flag = true;
@@ -652,4 +659,5 @@ extern "C" const float* msgs_oracle_rgb(const msgs_oracle_state_t* s) { return s
 extern "C" const float* msgs_oracle_means2D(const msgs_oracle_state_t* s) { return s->means2D.data(); }
 extern "C" const float* msgs_oracle_cov3D(const msgs_oracle_state_t* s) { return s->cov3D.data(); }
 extern "C" const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* s) { return s->rects.data(); }
+extern "C" const uint8_t* msgs_oracle_borderline_gaussians(const msgs_oracle_state_t* s) { return s->borderline_gauss.data(); }
 extern "C" void msgs_oracle_free(msgs_oracle_state_t* s) { delete s; }

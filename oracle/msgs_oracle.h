@@ -42,6 +42,10 @@ const float* msgs_oracle_rgb(const msgs_oracle_state_t* state);            /* [P
 const float* msgs_oracle_means2D(const msgs_oracle_state_t* state);        /* [P,2] */
 const float* msgs_oracle_cov3D(const msgs_oracle_state_t* state);          /* [P,6] */
 const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* state);        /* [P,4] minx,miny,maxx,maxy */
+/* [P] 1 = some pixel evaluated this Gaussian with alpha within 2e-5 (relative) of the 1/255 skip threshold:
+ * a different float32 implementation may legitimately take the other branch there, which moves this
+ * Gaussian's conic-derived gradients by about one rim pixel's worth */
+const uint8_t* msgs_oracle_borderline_gaussians(const msgs_oracle_state_t* state);
 void msgs_oracle_free(msgs_oracle_state_t* state);
 
 #ifdef __cplusplus

