@@ -31,6 +31,8 @@
 // K7 = 48*D_trav + 20*N + 36*V.
 #include "msgs_internal.h"
 
+#include <algorithm>
+
 namespace msgs {
 
 namespace {
@@ -315,6 +317,270 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// v2 kernels: ONE wave64 per tile, four pixels per lane (lane l owns pixel (l & 7, l >> 3) of each of the
+// four 8x8 quadrants).  Everything that is uniform over the tile — record fetch from LDS, loop control,
+// and in the backward the 64-lane reduction and the atomics — is paid once per (tile, Gaussian) instead of
+// once per (quadrant, Gaussian); the quadrant hit mask becomes a wave-uniform branch per quadrant; there is
+// no workgroup barrier (a single wave owns the tile) and the next batch of 64 records is prefetched into
+// registers while the current one is consumed.  The four per-quadrant evaluations are independent, which
+// gives the scheduler four-way ILP.
+// ---------------------------------------------------------------------------------------------
+constexpr int WB = 64;   // records per batch (one per lane)
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// per-quadrant pixel state kept as independent scalars (arrays indexed by an unrolled q made the compiler
+// pack them into register tuples and copy whole tuples at every branch merge)
+struct FwdQuad {
+    float T, C0, C1, C2, aps, adp;
+    uint32_t last;
+    bool done;
+};
+
+// one (pixel, Gaussian) forward step; returns true (wave-uniform) when the quadrant just became fully done
+__device__ __forceinline__ bool fwd_quad_step(FwdQuad& s, const float4& r0, const float4& r1, const float4& r2,
+                                              float dx, float dy, uint32_t pos) {
+    const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+    const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
+    const bool valid = !s.done && ev.p <= r1.y && alpha >= ALPHA_MIN;      // power <= 0, alpha >= 1/255
+    const float test_T = __fmaf_rn(-s.T, alpha, s.T);
+    const bool stop = valid && test_T < T_MIN;
+    s.done = s.done || stop;
+    const bool blend = valid && !stop;
+    const float wgt = blend ? alpha * s.T : 0.0f;
+    s.C0 = fmaf(r1.z, wgt, s.C0); s.C1 = fmaf(r1.w, wgt, s.C1); s.C2 = fmaf(r2.x, wgt, s.C2);
+    s.adp = fmaf(r2.y, wgt, s.adp); s.aps = fmaf(r2.z, wgt, s.aps);
+    s.T = blend ? test_T : s.T;
+    s.last = blend ? pos : s.last;
+    return __ballot(stop) != 0 && __ballot(!s.done) == 0;
+}
+
+__device__ __forceinline__ void fwd_quad_store(const FwdQuad& s, int px, int py, const ViewParams& vp,
+                                               float* out_color, float* out_ps, float* out_depth, float* final_T,
+                                               uint32_t* n_contrib) {
+    if (px < vp.W && py < vp.H) {
+        const size_t N = (size_t)vp.W * vp.H;
+        const size_t pix = (size_t)py * vp.W + px;
+        out_color[pix] = s.C0 + s.T * vp.bg[0];
+        out_color[N + pix] = s.C1 + s.T * vp.bg[1];
+        out_color[2 * N + pix] = s.C2 + s.T * vp.bg[2];
+        out_ps[pix] = s.aps;
+        out_depth[pix] = s.adp;
+        final_T[pix] = s.T;
+        n_contrib[pix] = s.last;
+    }
+}
+
+__global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                                const uint32_t* __restrict__ ids,
+                                                                const uint2* __restrict__ ranges,
+                                                                float* __restrict__ out_color,
+                                                                float* __restrict__ out_ps,
+                                                                float* __restrict__ out_depth,
+                                                                float* __restrict__ final_T,
+                                                                uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 s_r0[WB], s_r1[WB], s_r2[WB];
+    const int num_tiles = vp.gx * vp.gy;
+    const int lane = threadIdx.x;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);     // pixel of quadrant 0
+    const float bxf = (float)bx, byf = (float)by;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+
+    FwdQuad q0, q1, q2, q3;
+    uint32_t alive = 0;                                   // wave-uniform: quadrants with a live pixel
+    {
+        auto init = [&](FwdQuad& s, int qi) {
+            s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.aps = s.adp = 0.f; s.last = 0;
+            s.done = !(bx + (qi & 1) * 8 < vp.W && by + (qi >> 1) * 8 < vp.H);
+            if (__ballot(!s.done) != 0) alive |= 1u << qi;
+        };
+        init(q0, 0); init(q1, 1); init(q2, 2); init(q3, 3);
+    }
+
+    // prefetch of the first batch
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    if (lane < len) {
+        const uint32_t id = ids[range.x + lane];
+        n0 = rec[id].r0; n1 = rec[id].r1; n2 = rec[id].r2;
+    }
+    for (int base = 0; base < len && alive; base += WB) {
+        const int n = min(WB, len - base);
+        wave_fence();                                     // previous batch fully consumed
+        s_r0[lane] = n0; s_r1[lane] = n1; s_r2[lane] = n2;
+        // quadrant hit masks of the whole batch as four 64-bit ballots (bit e = record e): wave-uniform, in SGPRs
+        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
+        const uint64_t h0 = __ballot(mymask & 1u), h1 = __ballot(mymask & 2u), h2 = __ballot(mymask & 4u),
+                       h3 = __ballot(mymask & 8u);
+        wave_fence();
+        if (base + WB + lane < len) {                     // prefetch the next batch
+            const uint32_t id = ids[range.x + base + WB + lane];
+            n0 = rec[id].r0; n1 = rec[id].r1; n2 = rec[id].r2;
+        }
+        uint64_t todo = h0 | h1 | h2 | h3;
+        while (todo && alive) {
+            const int e = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint64_t bit = 1ull << e;
+            const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+            const float dx = r0.x - bxf, dy = r0.y - byf;
+            const uint32_t pos = (uint32_t)(base + e + 1);
+            if ((h0 & bit) && (alive & 1u)) { if (fwd_quad_step(q0, r0, r1, r2, dx, dy, pos)) alive &= ~1u; }
+            if ((h1 & bit) && (alive & 2u)) { if (fwd_quad_step(q1, r0, r1, r2, dx - 8.0f, dy, pos)) alive &= ~2u; }
+            if ((h2 & bit) && (alive & 4u)) { if (fwd_quad_step(q2, r0, r1, r2, dx, dy - 8.0f, pos)) alive &= ~4u; }
+            if ((h3 & bit) && (alive & 8u)) { if (fwd_quad_step(q3, r0, r1, r2, dx - 8.0f, dy - 8.0f, pos)) alive &= ~8u; }
+        }
+    }
+    fwd_quad_store(q0, bx, by, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    fwd_quad_store(q1, bx + 8, by, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    fwd_quad_store(q2, bx, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    fwd_quad_store(q3, bx + 8, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+}
+
+struct BwdQuad {
+    float T, acc0, acc1, acc2, dL0, dL1, dL2, nTf_bg;
+    uint32_t last;
+};
+
+struct BwdSums { float v0, v1, v2, v3, v4, v5, v6, v7, v8; };
+
+// one (pixel, Gaussian) backward step accumulated into the per-lane partial sums; returns the lane's validity
+// (no wave-level early-out here: every ballot-driven branch is a VALU -> SALU -> branch round trip, and the
+// quadrant hit masks already removed the quadrants the record cannot touch)
+__device__ __forceinline__ bool bwd_quad_step(BwdQuad& s, BwdSums& v, const float4& r0, const float4& r1, float cb,
+                                              float dx, float dy, uint32_t pos0) {
+    const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+    const float a_raw = __builtin_amdgcn_exp2f(ev.p);
+    const float alpha = fminf(0.99f, a_raw);
+    const bool valid = pos0 < s.last && ev.p <= r1.y && alpha >= ALPHA_MIN;
+    const float alpha_m = valid ? alpha : 0.0f;               // masked lanes: no state change, zero output
+    const float a_m = valid ? a_raw : 0.0f;
+    const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+    const float Tn = s.T * inv;
+    s.T = valid ? Tn : s.T;
+    const float dch = alpha_m * Tn;
+    const float d0 = r1.z - s.acc0, d1 = r1.w - s.acc1, d2 = cb - s.acc2;
+    const float sm = fmaf(d2, s.dL2, fmaf(d1, s.dL1, d0 * s.dL0));
+    const float dL_dalpha = fmaf(sm, Tn, s.nTf_bg * inv);
+    s.acc0 = fmaf(alpha_m, d0, s.acc0); s.acc1 = fmaf(alpha_m, d1, s.acc1); s.acc2 = fmaf(alpha_m, d2, s.acc2);
+    const float qq = a_m * dL_dalpha;                         // Q6: gradient passes the 0.99 clamp
+    const float h = qq * dx, qy = qq * dy;
+    v.v0 = fmaf(qq, ev.u, v.v0); v.v1 = fmaf(qq, ev.w, v.v1);
+    v.v2 = fmaf(h, dx, v.v2); v.v3 = fmaf(h, dy, v.v3); v.v4 = fmaf(qy, dy, v.v4);
+    v.v5 += qq;
+    v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
+    return valid;
+}
+
+__global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                                 const uint32_t* __restrict__ ids,
+                                                                 const uint2* __restrict__ ranges,
+                                                                 const float* __restrict__ final_T,
+                                                                 const uint32_t* __restrict__ n_contrib,
+                                                                 const float* __restrict__ dL_dcolor,
+                                                                 float* __restrict__ grad_rec) {
+    __shared__ float4 s_r0[WB], s_r1[WB];
+    __shared__ float s_b[WB];
+    __shared__ uint32_t s_id[WB];
+    const int num_tiles = vp.gx * vp.gy;
+    const int lane = threadIdx.x;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
+    const float bxf = (float)bx, byf = (float)by;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const size_t N = (size_t)vp.W * vp.H;
+
+    BwdQuad q0, q1, q2, q3;
+    uint32_t ql0, ql1, ql2, ql3;                           // wave-uniform: last blended position per quadrant
+    {
+        auto init = [&](BwdQuad& s, int qi) -> uint32_t {
+            const int px = bx + (qi & 1) * 8, py = by + (qi >> 1) * 8;
+            const bool inside = px < vp.W && py < vp.H;
+            const size_t pix = (size_t)py * vp.W + px;
+            const float Tf = inside ? final_T[pix] : 1.0f;
+            s.last = inside ? n_contrib[pix] : 0u;
+            s.dL0 = inside ? dL_dcolor[pix] : 0.f;
+            s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
+            s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
+            s.nTf_bg = -Tf * (vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2);
+            s.T = Tf; s.acc0 = s.acc1 = s.acc2 = 0.f;
+            return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
+        };
+        ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
+    }
+    const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
+    const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
+    const int vbase = 4 * (int)p0 + 2 * (int)p1;
+
+    const int nb = ((int)tile_last + WB - 1) / WB;
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    uint32_t nid = 0;
+    if (nb > 0) {
+        const int i0 = (nb - 1) * WB + lane;
+        if (i0 < (int)tile_last) { nid = ids[range.x + i0]; n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2; }
+    }
+    for (int b = nb - 1; b >= 0; --b) {
+        const int base = b * WB;
+        const int n = min(WB, (int)tile_last - base);
+        wave_fence();
+        s_r0[lane] = n0; s_r1[lane] = n1; s_b[lane] = n2.x; s_id[lane] = nid;
+        // quadrant hit masks of the batch as four 64-bit ballots; a record beyond the last blended entry of a
+        // quadrant cannot matter to that quadrant
+        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
+        const uint32_t mypos = (uint32_t)(base + lane);
+        const uint64_t h0 = __ballot((mymask & 1u) && mypos < ql0), h1 = __ballot((mymask & 2u) && mypos < ql1),
+                       h2 = __ballot((mymask & 4u) && mypos < ql2), h3 = __ballot((mymask & 8u) && mypos < ql3);
+        wave_fence();
+        if (b > 0) {                                      // prefetch the next (nearer) batch: always full
+            nid = ids[range.x + base - WB + lane];
+            n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2;
+        }
+        uint64_t todo = h0 | h1 | h2 | h3;
+        while (todo) {
+            const int e = 63 - __builtin_clzll(todo);     // back to front
+            const uint64_t bit = 1ull << e;
+            todo &= ~bit;
+            const uint32_t pos0 = (uint32_t)(base + e);   // 0-based position in the tile list
+            const float4 r0 = s_r0[e], r1 = s_r1[e];
+            const float cb = s_b[e];
+            const float dx = r0.x - bxf, dy = r0.y - byf;
+            BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool any = false;
+            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
+            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
+            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
+            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
+            if (__ballot(any) == 0) continue;              // the ONE sync point per (tile, Gaussian)
+            // ---- one 64-lane reduce-scatter per (tile, Gaussian) ----
+            const float a0 = (p0 ? v.v4 : v.v0) + dpp_mov<0xB1>(p0 ? v.v0 : v.v4);
+            const float a1 = (p0 ? v.v5 : v.v1) + dpp_mov<0xB1>(p0 ? v.v1 : v.v5);
+            const float a2 = (p0 ? v.v6 : v.v2) + dpp_mov<0xB1>(p0 ? v.v2 : v.v6);
+            const float a3 = (p0 ? v.v7 : v.v3) + dpp_mov<0xB1>(p0 ? v.v3 : v.v7);
+            float r0s = (p1 ? a2 : a0) + dpp_mov<0x4E>(p1 ? a0 : a2);
+            float r1s = (p1 ? a3 : a1) + dpp_mov<0x4E>(p1 ? a1 : a3);
+            float r2s = v.v8 + dpp_mov<0xB1>(v.v8);
+            r2s += dpp_mov<0x4E>(r2s);
+            r0s += dpp_mov<0x124>(r0s); r1s += dpp_mov<0x124>(r1s); r2s += dpp_mov<0x124>(r2s);
+            r0s += dpp_mov<0x128>(r0s); r1s += dpp_mov<0x128>(r1s); r2s += dpp_mov<0x128>(r2s);
+            r0s = cross_row_allreduce(r0s); r1s = cross_row_allreduce(r1s); r2s = cross_row_allreduce(r2s);
+            // lanes 0..3 hold components (vbase, vbase+1) = (0,1 | 4,5 | 2,3 | 6,7); lane 4 adds #8
+            float* gdst = grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS;
+            if (lane < 4) unsafeAtomicAdd(gdst + vbase, r0s);
+            if (lane < 5) unsafeAtomicAdd(gdst + (lane == 4 ? 8 : vbase + 1), lane == 4 ? r2s : r1s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // statistics for the algorithmic-bytes formula: D_trav = sum_tiles max_pixels n_contrib, V = #radii>0
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_stats_kernel(ViewParams vp, const uint32_t* __restrict__ n_contrib,
@@ -341,14 +607,29 @@ __global__ __launch_bounds__(256) void visible_count_kernel(int P, const int32_t
 
 }  // namespace
 
+// Two generations of blend kernels exist (A/B numbers in profiles/r1_notes.md):
+//   gen 1: one 256-thread workgroup per tile, one quadrant per wave        (forward 229 us, backward 663 us at C3)
+//   gen 2: one wave64 per tile, four pixels per lane, reduction per tile   (forward 405 us, backward ~550 us)
+// Default = gen-1 forward + gen-2 backward.  MSGS_FWD_GEN / MSGS_BWD_GEN = 1 | 2 override for measurements.
+static int env_gen(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : dflt;
+}
+static bool blend_v1() { static const bool v = env_gen("MSGS_FWD_GEN", 1) == 1; return v; }
+static bool bwd_v1() { static const bool v = env_gen("MSGS_BWD_GEN", 2) == 1; return v; }
+
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
                                 uint32_t* n_contrib, hipStream_t s) {
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                       out_depth, final_T, n_contrib);
+    if (blend_v1())
+        hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib);
+    else
+        hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
+                           out_ps, out_depth, final_T, n_contrib);
     return hipGetLastError();
 }
 
@@ -362,7 +643,10 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     // selects the per-batch LDS accumulator variant (4x fewer global atomics but an extra barrier and a
     // flush pass per batch: 903 us at C3, profiles/r1_notes.md) for A/B measurements.
     static const bool direct = [] { const char* e = getenv("MSGS_BWD_LDS_ACC"); return !(e && e[0] == '1'); }();
-    if (direct)
+    if (!bwd_v1())
+        hipLaunchKernelGGL(blend_backward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
+                           n_contrib, dL_dcolor, grad_rec);
+    else if (direct)
         hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
     else

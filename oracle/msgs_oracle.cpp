@@ -81,6 +81,8 @@ struct msgs_oracle_state {
     std::vector<int32_t> rects;
     std::vector<uint8_t> borderline_gauss;  // Gaussian had an alpha within rounding distance of 1/255 on some pixel
     int64_t traversed = 0;
+    int64_t valid_pairs = 0;      // (pixel, Gaussian) evaluations with alpha >= 1/255 before the pixel terminated
+    int64_t evaluated_pairs = 0;  // all evaluations of the reference algorithm (sum over pixels of n_contrib-ish)
 };
 
 namespace {
@@ -324,8 +326,8 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     st->n_contrib.assign((size_t)W * H, 0);
     st->borderline_gauss.assign(P, 0);
     const float bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
-    int64_t traversed = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : traversed)
+    int64_t traversed = 0, valid_pairs = 0, evaluated_pairs = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : traversed, valid_pairs, evaluated_pairs)
     for (int tile = 0; tile < gx * gy; ++tile) {
         const int tx = tile % gx, ty = tile / gx;
         const uint32_t lo = st->range_lo[tile], hi = st->range_hi[tile];
@@ -340,6 +342,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                 bool flag = false;
                 for (uint32_t k = lo; k < hi; ++k) {
                     ++contributor;
+                    ++evaluated_pairs;
                     const Geom& ge = st->geom[st->list[k]];
                     float dx = ge.px - pxf, dy = ge.py - pyf;
                     float power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
@@ -352,6 +355,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                         *bg_flag = 1;
                     }
                     if (alpha < 1.0f / 255.0f) continue;                                 // Q7
+                    ++valid_pairs;
                     float test_T = T * (1 - alpha);
                     if (std::fabs(test_T - 0.0001f) < 2e-8f) flag = true;
                     if (test_T < 0.0001f) break;                                         // Q7: not blended
@@ -374,6 +378,8 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
         traversed += tile_max;
     }
     st->traversed = traversed;
+    st->valid_pairs = valid_pairs;
+    st->evaluated_pairs = evaluated_pairs;
 
     // flat copies for the tests
     st->depths.resize(P); st->conic_opacity.resize((size_t)4 * P); st->rgb.resize((size_t)3 * P);
@@ -651,6 +657,8 @@ extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_vi
 
 extern "C" int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* s) { return (int64_t)s->list.size(); }
 extern "C" int64_t msgs_oracle_traversed(const msgs_oracle_state_t* s) { return s->traversed; }
+extern "C" int64_t msgs_oracle_valid_pairs(const msgs_oracle_state_t* s) { return s->valid_pairs; }
+extern "C" int64_t msgs_oracle_evaluated_pairs(const msgs_oracle_state_t* s) { return s->evaluated_pairs; }
 extern "C" const float* msgs_oracle_final_T(const msgs_oracle_state_t* s) { return s->final_T.data(); }
 extern "C" const uint32_t* msgs_oracle_n_contrib(const msgs_oracle_state_t* s) { return s->n_contrib.data(); }
 extern "C" const float* msgs_oracle_depths(const msgs_oracle_state_t* s) { return s->depths.data(); }

@@ -34,6 +34,8 @@ int msgs_oracle_backward(const msgs_oracle_state_t* state, const msgs_view_t* vi
  * per-Gaussian rect and float32 depth */
 int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* state);
 int64_t msgs_oracle_traversed(const msgs_oracle_state_t* state);   /* sum_tiles max_pixels n_contrib */
+int64_t msgs_oracle_valid_pairs(const msgs_oracle_state_t* state);      /* pairs with alpha >= 1/255 before termination */
+int64_t msgs_oracle_evaluated_pairs(const msgs_oracle_state_t* state);  /* all pairs the reference algorithm evaluates */
 const float* msgs_oracle_final_T(const msgs_oracle_state_t* state);
 const uint32_t* msgs_oracle_n_contrib(const msgs_oracle_state_t* state);
 const float* msgs_oracle_depths(const msgs_oracle_state_t* state);

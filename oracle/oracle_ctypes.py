@@ -65,8 +65,10 @@ def lib():
                                            C.POINTER(Grads), C.c_int]
         L.msgs_oracle_num_instances.restype = C.c_int64
         L.msgs_oracle_num_instances.argtypes = [C.c_void_p]
-        L.msgs_oracle_traversed.restype = C.c_int64
-        L.msgs_oracle_traversed.argtypes = [C.c_void_p]
+        for name in ("traversed", "valid_pairs", "evaluated_pairs"):
+            f = getattr(L, "msgs_oracle_" + name)
+            f.restype = C.c_int64
+            f.argtypes = [C.c_void_p]
         for name in ("final_T", "n_contrib", "depths", "conic_opacity", "rgb", "means2D", "cov3D", "rects",
                      "borderline_gaussians"):
             f = getattr(L, "msgs_oracle_" + name)
@@ -117,6 +119,14 @@ class OracleResult:
     @property
     def traversed(self):
         return int(lib().msgs_oracle_traversed(self.state))
+
+    @property
+    def valid_pairs(self):
+        return int(lib().msgs_oracle_valid_pairs(self.state))
+
+    @property
+    def evaluated_pairs(self):
+        return int(lib().msgs_oracle_evaluated_pairs(self.state))
 
 
 def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_precomp=False,
