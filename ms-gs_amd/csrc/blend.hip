@@ -611,11 +611,13 @@ __global__ __launch_bounds__(256) void visible_count_kernel(int P, const int32_t
 //   gen 1: one 256-thread workgroup per tile, one quadrant per wave        (forward 229 us, backward 663 us at C3)
 //   gen 2: one wave64 per tile, four pixels per lane, reduction per tile   (forward 405 us, backward ~550 us)
 // Default = gen-1 forward + gen-2 backward.  MSGS_FWD_GEN / MSGS_BWD_GEN = 1 | 2 override for measurements.
+// (A packed-fp32 forward with two pixels per lane was also built and measured: correct but 17 % slower —
+// v_pk_*_f32 is not full rate on gfx950 — and removed; for the same reason this library is compiled with
+// -fno-slp-vectorize, which alone took the backward from 558 to 495 us.)
 static int env_gen(const char* name, int dflt) {
     const char* e = getenv(name);
-    return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : dflt;
+    return (e && e[0] >= '1' && e[0] <= '2') ? e[0] - '0' : dflt;
 }
-static bool blend_v1() { static const bool v = env_gen("MSGS_FWD_GEN", 1) == 1; return v; }
 static bool bwd_v1() { static const bool v = env_gen("MSGS_BWD_GEN", 2) == 1; return v; }
 
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
@@ -624,7 +626,8 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
-    if (blend_v1())
+    static const int fwd_gen = env_gen("MSGS_FWD_GEN", 1);
+    if (fwd_gen == 1)
         hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
     else
