@@ -1,8 +1,8 @@
 // binning.hip — instance emission and tile ranges (App. A.2).
 //
 // emit_kernel walks the Gaussians in DEPTH ORDER (order[] from the depth sort) and writes one
-// (tile id, Gaussian id) pair per tile that the Gaussian's alpha >= 1/255 level set reaches (the same
-// per-row extents preprocess_kernel counted), at the slot given by the exclusive scan of the per-Gaussian counts.  The subsequent
+// (tile id, Gaussian id) pair per tile that the Gaussian's alpha >= 1/255 level set reaches (per-row extents
+// with a slightly smaller margin than the count, see msgs_internal.h), at the slot given by the exclusive scan of the per-Gaussian counts.  The subsequent
 // stable sort by tile id (sort.hip) then produces, inside every tile, the reference order
 // (depth bits ascending, ties by Gaussian index).
 //
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
         const LevelSetRows ls = test ? levelset_rows_setup(q0.z, q0.w, conC, tau2) : LevelSetRows{};
         for (int ty = miny; ty < maxy && off < end; ++ty) {
             int tlo = minx, thi = maxx - 1;
-            if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, tlo, thi)) continue;
+            if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi)) continue;
             for (int tx = tlo; tx <= thi && off < end; ++tx) {
                 const uint32_t k = (uint32_t)(ty * vp.gx + tx);
                 if (staged) { s_keys[off - blk_lo] = k; s_ids[off - blk_lo] = gi; }
@@ -66,8 +66,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
                 ++off;
             }
         }
-        // Defensive: the count and this loop evaluate the same deterministic predicate, so the slots are
-        // always filled exactly; should they ever not be, park the leftovers on a sentinel tile.
+        // count >= emitted by construction (larger margin in the count): park the surplus slots on the sentinel tile
         for (; off < end; ++off) {
             const uint32_t k = (uint32_t)(vp.gx * vp.gy);
             if (staged) { s_keys[off - blk_lo] = k; s_ids[off - blk_lo] = gi; }

@@ -45,6 +45,7 @@ constexpr float T_MIN = 0.0001f;
 //   p = dx*u + dy*w + lo   with u = A'dx + Bh'dy, w = C'dy + Bh'dx   (log2 of the unclamped alpha)
 struct PairEval { float u, w, p; };
 __device__ __forceinline__ PairEval eval_pair(float A, float Bh, float C, float lo, float dx, float dy) {
+#pragma clang fp contract(off)   // only the explicit FMAs below; nothing else may be fused differently per kernel
     PairEval e;
     e.u = __fmaf_rn(A, dx, __fmul_rn(Bh, dy));
     e.w = __fmaf_rn(C, dy, __fmul_rn(Bh, dx));

@@ -133,6 +133,7 @@ struct ImageLayout {
 // bit-identical answers whatever the surrounding code is.
 __device__ __forceinline__ bool levelset_hits_rect(float gx, float gy, float A, float Bh, float C,
                                                    float tau2, float x0, float x1, float y0, float y1) {
+#pragma clang fp contract(off)   // HIP's __f*_rn are plain operators: pin contraction here, not per TU
     const float dxlo = __fsub_rn(gx, x1), dxhi = __fsub_rn(gx, x0);
     const float dylo = __fsub_rn(gy, y1), dyhi = __fsub_rn(gy, y0);
     const float cx = fminf(fmaxf(0.0f, dxlo), dxhi);
@@ -154,16 +155,23 @@ __device__ __forceinline__ bool levelset_hits_rect(float gx, float gy, float A, 
     return fbest >= tau2;
 }
 
-// Per-tile-ROW extent of the same level set (used by the overlap count in preprocess_kernel and by
-// emit_kernel; both must agree bit for bit, hence the explicit roundings).  {f >= tau2} is an ellipse; its
+// Per-tile-ROW extent of the same level set, used by the overlap count in preprocess_kernel and by emit_kernel.
+// The two inlined copies are NOT guaranteed to round identically (observed: one tile in 55 M at C5, where an
+// extent ended exactly on a tile boundary), so the scheme does not rely on it: the COUNT is taken with a larger
+// safety margin (LEVELSET_MARGIN_COUNT) than the EMIT (LEVELSET_MARGIN_EMIT), hence count >= emitted always; the
+// emit is still a superset of the exact tile set, and the surplus slots are parked on the sentinel tile id
+// (= number of tiles), which sorts behind every real tile and is ignored by ranges_kernel.  {f >= tau2} is an ellipse; its
 // intersection with the horizontal band of one tile row is convex, so the tiles it reaches in that row
 // form ONE interval [tlo, thi]: the x-range of (ellipse ∩ band) is bounded by the ellipse's extreme
 // points when they fall inside the band and by the band edges' chords otherwise.  O(rows) work per
 // Gaussian instead of O(tiles).  Conservative w.r.t. the per-pixel test (continuous rectangle + margin).
+constexpr float LEVELSET_MARGIN_EMIT = 0.02f;    // pixels
+constexpr float LEVELSET_MARGIN_COUNT = 0.03f;   // pixels (> emit)
 struct LevelSetRows {
     float A, Bh, C, Atau, det, invA, dymax, dyR;
 };
 __device__ __forceinline__ LevelSetRows levelset_rows_setup(float A, float Bh, float C, float tau2) {
+#pragma clang fp contract(off)   // count (preprocess.hip) and emit (binning.hip) must agree bit for bit
     LevelSetRows r;
     r.A = A; r.Bh = Bh; r.C = C;
     r.det = __fsub_rn(__fmul_rn(A, C), __fmul_rn(Bh, Bh));          // > 0 (negative definite form)
@@ -176,10 +184,12 @@ __device__ __forceinline__ LevelSetRows levelset_rows_setup(float A, float Bh, f
 }
 // tile row ty (pixel rows 16 ty .. 16 ty + 15); returns false when the row is not reached
 __device__ __forceinline__ bool levelset_row_interval(const LevelSetRows& r, float gx, float gy, int ty, int minx,
-                                                      int maxx, int& tlo, int& thi) {
+                                                      int maxx, float margin, int& tlo, int& thi) {
+#pragma clang fp contract(off)
     const float y0 = (float)(ty * TILE);
-    const float lo = fmaxf(__fsub_rn(gy, y0 + (float)(TILE - 1)), -r.dymax);
-    const float hi = fminf(__fsub_rn(gy, y0), r.dymax);
+    const float dym = r.dymax + margin;
+    const float lo = fmaxf(__fsub_rn(gy, y0 + (float)(TILE - 1)), -dym);
+    const float hi = fminf(__fsub_rn(gy, y0), dym);
     if (lo > hi) return false;
     const float dyr = fminf(fmaxf(r.dyR, lo), hi);                   // where dx is largest inside the band
     const float dyl = fminf(fmaxf(-r.dyR, lo), hi);                  // where dx is smallest
@@ -187,8 +197,8 @@ __device__ __forceinline__ bool levelset_row_interval(const LevelSetRows& r, flo
     const float sl = __fsqrt_rn(fmaxf(0.0f, __fmaf_rn(-r.det, __fmul_rn(dyl, dyl), r.Atau)));
     const float dx_max = __fmul_rn(__fsub_rn(-__fmul_rn(r.Bh, dyr), sr), r.invA);   // A < 0
     const float dx_min = __fmul_rn(__fadd_rn(-__fmul_rn(r.Bh, dyl), sl), r.invA);
-    const float xl = __fsub_rn(__fsub_rn(gx, dx_max), 0.02f);        // pixel x = gx - dx
-    const float xr = __fadd_rn(__fsub_rn(gx, dx_min), 0.02f);
+    const float xl = __fsub_rn(__fsub_rn(gx, dx_max), margin);       // pixel x = gx - dx
+    const float xr = __fadd_rn(__fsub_rn(gx, dx_min), margin);
     tlo = max(minx, (int)ceilf(__fmul_rn(__fsub_rn(xl, (float)(TILE - 1)), 1.0f / TILE)));
     thi = min(maxx - 1, (int)floorf(__fmul_rn(xr, 1.0f / TILE)));
     return tlo <= thi;

@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                 const LevelSetRows ls = levelset_rows_setup(sA, sBh, sC, tau2);
                 for (int ty = miny; ty < maxy; ++ty) {
                     int tlo, thi;
-                    if (levelset_row_interval(ls, px, py, ty, minx, maxx, tlo, thi)) count += (uint32_t)(thi - tlo + 1);
+                    if (levelset_row_interval(ls, px, py, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi))
+                        count += (uint32_t)(thi - tlo + 1);
                 }
             } else {
                 tau2 = -3.0e38f;                                     // cannot bound: keep the whole rect
