@@ -51,6 +51,7 @@ struct GeomLayout {
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 8;
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;
+constexpr int SORT_MAX_GROUPS = 128;   // group sums per digit (grouped radix path)
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
@@ -68,7 +69,8 @@ struct SortScratch {
         vals_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
         // classic path: 256 x nb block histograms; onesweep path: 4x256 digit histograms + tickets + error
         // flag (64 words) + up to 4 passes x nb x 256 look-back status words
-        hist = o;     o = align256(o + 4 * ((size_t)4 * 256 + 64 + (size_t)4 * 256 * nb));
+        // (grouped path: 256 x nb block histograms followed by 4 x 256 x SORT_MAX_GROUPS group sums — smaller)
+        hist = o;     o = align256(o + 4 * ((size_t)4 * 256 + 64 + (size_t)4 * 256 * nb + (size_t)4 * 256 * SORT_MAX_GROUPS));
         partials = o; o = align256(o + 8 * (size_t)(scan_blocks(256 * nb) + 2));
         total = o;
     }

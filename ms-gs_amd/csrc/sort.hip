@@ -15,6 +15,8 @@
 // Every kernel is HBM-streaming: 4 B (hist) + 8 B read + 8 B write per pair per pass.
 #include "msgs_internal.h"
 
+#include <algorithm>
+
 namespace msgs {
 
 namespace {
@@ -131,9 +133,13 @@ __device__ __forceinline__ int64_t elem_index(int64_t chunk_base, int w, int r, 
     return chunk_base + (int64_t)w * (64 * SORT_ITEMS) + r * 64 + lane;
 }
 
+// With `gsum` (grouped path) the block histograms are stored block-major (hist[block][digit]) and the
+// per-(group of `gsize` blocks, digit) sums gsum[group][digit] are accumulated with atomics: with those every
+// scatter block derives its own output bases (no scan kernels at all).
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
                                                                   int shift, uint32_t mask, int64_t nblocks,
-                                                                  uint32_t* __restrict__ hist) {
+                                                                  uint32_t* __restrict__ hist,
+                                                                  uint32_t* __restrict__ gsum, int gsize, int ngroups) {
     __shared__ uint32_t s_hist[256];
     s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -145,7 +151,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
         if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
+    const uint32_t c = s_hist[threadIdx.x];
+    if (gsum) {       // grouped path: both tables are [block or group][digit] so that thread = digit accesses coalesce
+        hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
+        if (c) atomicAdd(&gsum[(int64_t)(blockIdx.x / gsize) * 256 + threadIdx.x], c);
+    } else {
+        hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = c;
+    }
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
@@ -153,8 +165,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
                                                                      uint32_t* __restrict__ keys_out,
                                                                      uint32_t* __restrict__ vals_out, int64_t n,
                                                                      int shift, uint32_t mask, int64_t nblocks,
-                                                                     const uint32_t* __restrict__ hist_scanned) {
+                                                                     const uint32_t* __restrict__ hist_scanned,
+                                                                     const uint32_t* __restrict__ gsum, int gsize,
+                                                                     int ngroups) {
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, later per-wave global bases
+    __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t chunk_base = (int64_t)blockIdx.x * SORT_CHUNK;
 #pragma unroll
@@ -186,7 +201,23 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     __syncthreads();
     {   // digit d = threadIdx.x: turn per-wave counts into per-wave global bases
         const uint32_t d = threadIdx.x;
-        uint32_t base = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
+        uint32_t base;
+        if (gsum) {
+            // base = (keys with a smaller digit) + (same digit in earlier groups) + (same digit in earlier blocks of
+            // this group); hist_scanned holds the RAW block histograms here
+            const int g = blockIdx.x / gsize;
+            uint32_t tot = 0, before = 0;
+            for (int k = 0; k < ngroups; ++k) {
+                const uint32_t v = gsum[(int64_t)k * 256 + d];
+                tot += v;
+                before += k < g ? v : 0u;
+            }
+            for (int64_t bb = (int64_t)g * gsize; bb < blockIdx.x; ++bb) before += hist_scanned[bb * 256 + d];
+            uint32_t dummy;
+            base = block_exclusive_scan(tot, s_wave, &dummy) + before;
+        } else {
+            base = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t c = s_cnt[k][d];
@@ -463,6 +494,16 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     int passes = (end_bit - begin_bit + 7) / 8;
     if (passes < 1) passes = 1;
     const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
+    // grouped variant of the spin-free path (default): group sums live behind the block-histogram table
+    static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
+    const bool grouped = !onesweep && !scan_table && passes <= 4;
+    const int gsize = (int)std::max<int64_t>(16, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
+    const int ngroups = (int)((nb + gsize - 1) / gsize);
+    uint32_t* gsum_all = hist + (size_t)256 * nb;
+    if (grouped) {
+        hipError_t e = hipMemsetAsync(gsum_all, 0, sizeof(uint32_t) * (size_t)passes * 256 * ngroups, s);
+        if (e != hipSuccess) return e;
+    }
     // onesweep carve-up of the `hist` region: [4][256] digit histograms, [4] tickets, [1] error flag,
     // then per pass nb x 256 status words
     uint32_t* digit_hist = hist;
@@ -489,12 +530,20 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
         if (onesweep) {
             hipLaunchKernelGGL(onesweep_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k, dst_v,
                                n, shift, mask, digit_hist + p * 256, status + (size_t)p * 256 * nb, tickets + p, err);
+        } else if (grouped) {
+            // two kernels per pass: block histograms + group sums, then a scatter that derives its own bases
+            uint32_t* gs = gsum_all + (size_t)p * 256 * ngroups;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist,
+                               gs, gsize, ngroups);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k,
+                               dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups);
         } else {
-            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist,
+                               (uint32_t*)nullptr, 1, 1);
             hipError_t e = exclusive_scan_u32(hist, nullptr, hist, 256 * nb, partials, nullptr, s);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k,
-                               dst_v, n, shift, mask, nb, hist);
+                               dst_v, n, shift, mask, nb, hist, (const uint32_t*)nullptr, 1, 1);
         }
         src_k = dst_k;
         src_v = dst_v;

@@ -89,7 +89,12 @@ class _Call:
         self.minps = _f32c(min_pixel_sizes).reshape(-1) if min_pixel_sizes is not None else None
         self.occ = _f32c(occ_multiplier) if occ_multiplier is not None else None
         self.dcd = _f32c(dc_delta) if dc_delta is not None else None
-        self.base = base_mask.to(torch.uint8).contiguous() if base_mask is not None else None
+        if base_mask is None:
+            self.base = None
+        elif base_mask.dtype == torch.bool and base_mask.is_contiguous():
+            self.base = base_mask.view(torch.uint8)            # same bytes, no copy kernel
+        else:
+            self.base = base_mask.to(torch.uint8).contiguous()
         for name, t, n in (("opacities", self.opac, P), ("max_pixel_sizes", self.maxps, P),
                            ("min_pixel_sizes", self.minps, P), ("base_mask", self.base, P)):
             if t is not None and t.numel() != n:
