@@ -204,8 +204,19 @@ def main():
             dom = max(alg, key=lambda k: kernels.get(k, 0.0))
             achieved = alg[dom] / (kernels[dom] * 1e-3) / 1e9
             both = (alg["blend_fwd"] + alg["blend_bwd"]) / ((kernels["blend_fwd"] + kernels["blend_bwd"]) * 1e-3) / 1e9
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
+            # separate passes, corrected per MI355X_MICROARCH.md §HBM); measured offline and committed under
+            # profiles/ because counters cannot be collected from inside the timed process
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r1.json")))["kernels"]
+                key = {"blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_tile_kernel"}[dom]
+                if (P, W, H) == (1_000_000, 1920, 1080) and key in tj:
+                    traffic = int(tj[key]["hbm_bytes"])
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom],
                     "blend_fwd_plus_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
                                            "algorithmic_bytes": alg["blend_fwd"] + alg["blend_bwd"],

@@ -207,12 +207,16 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
             // this group); hist_scanned holds the RAW block histograms here
             const int g = blockIdx.x / gsize;
             uint32_t tot = 0, before = 0;
-            for (int k = 0; k < ngroups; ++k) {
+#pragma unroll 8
+            for (int k = 0; k < ngroups; ++k) {                 // independent coalesced loads, 8 in flight
                 const uint32_t v = gsum[(int64_t)k * 256 + d];
                 tot += v;
                 before += k < g ? v : 0u;
             }
-            for (int64_t bb = (int64_t)g * gsize; bb < blockIdx.x; ++bb) before += hist_scanned[bb * 256 + d];
+            const int nin = (int)(blockIdx.x - (int64_t)g * gsize);
+            const uint32_t* hrow = hist_scanned + ((int64_t)g * gsize) * 256 + d;
+#pragma unroll 8
+            for (int k = 0; k < nin; ++k) before += hrow[(int64_t)k * 256];
             uint32_t dummy;
             base = block_exclusive_scan(tot, s_wave, &dummy) + before;
         } else {
@@ -497,7 +501,10 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     // grouped variant of the spin-free path (default): group sums live behind the block-histogram table
     static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
     const bool grouped = !onesweep && !scan_table && passes <= 4;
-    const int gsize = (int)std::max<int64_t>(16, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
+    // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
+    int gsize = 8;
+    while ((int64_t)gsize * gsize < nb) gsize += 8;
+    gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
     const int ngroups = (int)((nb + gsize - 1) / gsize);
     uint32_t* gsum_all = hist + (size_t)256 * nb;
     if (grouped) {
