@@ -184,6 +184,22 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
+/* ---- voxel-average pooling (large-Gaussian insertion) ------------------------------------------------------
+ * GPU replacement for the eleven CPU calls of open3d.ml.torch.layers.VoxelPooling(position_fn='center',
+ * feature_fn='average') in /root/reference/scene/gaussian_model.py:802-816 (third-party, un-vendored; restated
+ * from its published behaviour: voxel = floor(p / voxel_size), features = mean over the voxel's points).
+ * Build the grouping once per position set, then average any number of [M,F] feature tensors with it.
+ *   order[M]          point ids grouped by voxel (voxels ascending in (z,y,x) voxel index, points ascending by id)
+ *   seg_start[M+1]    first num_voxels+1 entries valid: voxel v owns order[seg_start[v] .. seg_start[v+1])
+ *   voxel_index[M,3]  (nullable) integer voxel coordinates, first num_voxels rows valid
+ * msgs_voxel_pool_build synchronises the stream once to return num_voxels. */
+size_t msgs_voxel_pool_scratch_bytes(int64_t M);
+int msgs_voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,
+                          int32_t* voxel_index, void* scratch, size_t scratch_bytes, int64_t* num_voxels_host,
+                          void* stream);
+int msgs_voxel_pool_average(const float* features, int32_t F, const uint32_t* order, const uint32_t* seg_start,
+                            int64_t num_voxels, float* out, void* stream);
+
 /* timing helpers: create/destroy the 2*MSGS_K_COUNT events and read elapsed ms per kernel class
  * (ms_host[MSGS_K_COUNT]; a class that was not recorded reads as -1).  The caller synchronises
  * the stream before msgs_timing_read. */

@@ -261,6 +261,31 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
     return MSGS_OK;
 }
 
+size_t msgs_voxel_pool_scratch_bytes(int64_t M) { return voxel_pool_scratch_bytes(M); }
+
+int msgs_voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,
+                          int32_t* voxel_index, void* scratch, size_t scratch_bytes, int64_t* num_voxels_host,
+                          void* stream) {
+    if (!num_voxels_host || M < 0 || !(voxel_size > 0.f)) return MSGS_ERR_INVALID_ARG;
+    *num_voxels_host = 0;
+    if (M == 0) return MSGS_OK;
+    if (M > 0x7FFFFFFFll) return MSGS_ERR_TOO_MANY;
+    if (!positions || !order || !seg_start || !scratch) return MSGS_ERR_INVALID_ARG;
+    if (scratch_bytes < voxel_pool_scratch_bytes(M)) return MSGS_ERR_CAPACITY;
+    HIP_TRY(voxel_pool_build(positions, M, voxel_size, order, seg_start, voxel_index, (char*)scratch, num_voxels_host,
+                             (hipStream_t)stream));
+    return MSGS_OK;
+}
+
+int msgs_voxel_pool_average(const float* features, int32_t F, const uint32_t* order, const uint32_t* seg_start,
+                            int64_t num_voxels, float* out, void* stream) {
+    if (F < 0 || num_voxels < 0) return MSGS_ERR_INVALID_ARG;
+    if (F == 0 || num_voxels == 0) return MSGS_OK;
+    if (!features || !order || !seg_start || !out) return MSGS_ERR_INVALID_ARG;
+    HIP_TRY(voxel_pool_average(features, F, order, seg_start, num_voxels, out, (hipStream_t)stream));
+    return MSGS_OK;
+}
+
 int msgs_timing_create(msgs_timing_t* t) {
     if (!t) return MSGS_ERR_INVALID_ARG;
     std::memset(t, 0, sizeof(*t));

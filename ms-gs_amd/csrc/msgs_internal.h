@@ -300,6 +300,12 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s);
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s);
+// voxel_pool.hip
+size_t voxel_pool_scratch_bytes(int64_t M);
+hipError_t voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,
+                            int32_t* voxel_index, char* scratch, int64_t* num_voxels_host, hipStream_t s);
+hipError_t voxel_pool_average(const float* features, int F, const uint32_t* order, const uint32_t* seg_start,
+                              int64_t Mv, float* out, hipStream_t s);
 // blend.hip
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,

@@ -83,6 +83,12 @@ def _load():
     lib.msgs_binning_stats.restype = C.c_int
     lib.msgs_binning_stats.argtypes = [C.POINTER(View), C.c_int32, vp, vp, sz, vp, sz, vp, sz,
                                        C.POINTER(C.c_int64), vp]
+    lib.msgs_voxel_pool_scratch_bytes.restype = sz
+    lib.msgs_voxel_pool_scratch_bytes.argtypes = [C.c_int64]
+    lib.msgs_voxel_pool_build.restype = C.c_int
+    lib.msgs_voxel_pool_build.argtypes = [vp, C.c_int64, C.c_float, vp, vp, vp, vp, sz, C.POINTER(C.c_int64), vp]
+    lib.msgs_voxel_pool_average.restype = C.c_int
+    lib.msgs_voxel_pool_average.argtypes = [vp, C.c_int32, vp, vp, C.c_int64, vp, vp]
     for name in ("msgs_timing_create", "msgs_timing_destroy"):
         f = getattr(lib, name)
         f.restype = C.c_int
@@ -100,7 +106,8 @@ lib = _load()
 EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_stage1_scratch_bytes",
            "msgs_binning_bytes", "msgs_stage2_scratch_bytes", "msgs_image_bytes", "msgs_backward_scratch_bytes",
            "msgs_forward_stage1", "msgs_forward_stage2", "msgs_backward", "msgs_mark_visible",
-           "msgs_binning_stats", "msgs_timing_create", "msgs_timing_destroy", "msgs_timing_read")
+           "msgs_binning_stats", "msgs_timing_create", "msgs_timing_destroy", "msgs_timing_read",
+           "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average")
 
 
 def check(rc, where):
