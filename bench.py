@@ -231,6 +231,28 @@ def main():
                                            "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
         result["roofline"] = roof
         result["kernel_ms"] = kernels
+        # informational: the opt-in raw-parameter entry (render_fused: activations + SH concat inside K1/K9,
+        # SURVEY §8(f) rank 1) on the same workload.  `value` above stays on the reference-API drop-in path.
+        if world == 1:
+            try:
+                from gaussian_renderer import render_fused
+
+                def fused_step():
+                    for p_ in pc.parameters():
+                        p_.grad = None
+                    render_fused(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+                for _ in range(args.warmup):
+                    fused_step()
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                for _ in range(args.steps):
+                    fused_step()
+                torch.cuda.synchronize()
+                tf = (time.perf_counter() - tf) / args.steps
+                result["fused_path"] = {"ms_per_step": round(1e3 * tf, 4), "value": round(W * H / 1e6 / tf, 3),
+                                        "unit": "Mpixels/s", "entry": "GaussianRasterizer.forward_raw"}
+            except Exception as e:
+                result["fused_path"] = {"error": repr(e)}
         result["binning"] = stats
         if world == 1 and not args.no_cpu_baseline:
             try:

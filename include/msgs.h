@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 1
+#define MSGS_ABI_VERSION 2
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -76,7 +76,13 @@ typedef struct msgs_view {
  * the gradient sink, :27-31) and therefore only appears in msgs_backward. */
 typedef struct msgs_gaussians {
     int32_t P;
-    int32_t reserved;
+    int32_t raw_params;            /* 0: activated inputs, the reference's op API.  1: RAW GaussianModel parameters
+                                    * (opt-in): opacities = logits, scales = log-scales,
+                                    * rotations = un-normalised quaternions, SH given as features_dc + features_rest
+                                    * (shs / colors_precomp / cov3D_precomp must be NULL, sh_coeffs = 16); the
+                                    * activations of scene/gaussian_model.py:39-47,127-153 (exp, sigmoid, normalize)
+                                    * and the torch.cat of :144-149 are evaluated inside the kernels and msgs_backward
+                                    * returns gradients w.r.t. the raw parameters */
     const float* means3D;          /* [P,3]                                                          */
     const float* shs;              /* [P,K,3]  xor colors_precomp                                    */
     const float* colors_precomp;   /* [P,3]                                                          */
@@ -89,6 +95,8 @@ typedef struct msgs_gaussians {
     const float* occ_multiplier;   /* [P,4]    accepted; identity semantics (DESIGN.md SPEC M5)      */
     const float* dc_delta;         /* [P,12]   accepted; identity semantics (DESIGN.md SPEC M5)      */
     const uint8_t* base_mask;      /* [P]      bool                                                  */
+    const float* features_dc;      /* [P,1,3]  raw mode only (gaussian_model.py:55)                          */
+    const float* features_rest;    /* [P,15,3] raw mode only (gaussian_model.py:56)                          */
 } msgs_gaussians_t;
 
 /* Gradient outputs of msgs_backward.  Every non-NULL buffer is fully written (zeros for
@@ -102,6 +110,8 @@ typedef struct msgs_grads {
     float* dL_dscales;         /* [P,3]   when scales/rotations were given                           */
     float* dL_drotations;      /* [P,4]                                                              */
     float* dL_dcov3D;          /* [P,6]   when cov3D_precomp was given                               */
+    float* dL_dfeatures_dc;    /* [P,1,3]  raw mode only                                                     */
+    float* dL_dfeatures_rest;  /* [P,15,3] raw mode only                                                     */
 } msgs_grads_t;
 
 /* Optional per-kernel timing (bench.py's roofline leg).  The caller owns the events; the library

@@ -22,6 +22,14 @@ inline int check_inputs(const msgs_view_t* v, const msgs_gaussians_t* g) {
     if (g->P < 0 || v->image_width <= 0 || v->image_height <= 0) return MSGS_ERR_INVALID_ARG;
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) return MSGS_ERR_INVALID_ARG;
     if (g->P > 0 && (!g->means3D || !g->opacities)) return MSGS_ERR_INVALID_ARG;
+    if (g->raw_params) {      // raw GaussianModel parameters: dc + rest SH, log-scales + raw quaternions, nothing precomputed
+        if (!g->features_dc || !g->features_rest || !g->scales || !g->rotations) return MSGS_ERR_INVALID_ARG;
+        if (g->shs || g->colors_precomp || g->cov3D_precomp) return MSGS_ERR_INVALID_ARG;
+        if (v->sh_degree < 0 || v->sh_degree > 3 || v->sh_coeffs != 16) return MSGS_ERR_SH_DEGREE;
+        if ((v->image_width + TILE - 1) / TILE > 65535 || (v->image_height + TILE - 1) / TILE > 65535)
+            return MSGS_ERR_INVALID_ARG;
+        return MSGS_OK;
+    }
     // exactly one of shs / colors_precomp, exactly one of (scales, rotations) / cov3D_precomp
     // (upstream raises on both-or-neither)
     if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return MSGS_ERR_INVALID_ARG;
@@ -210,6 +218,7 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
         image_bytes < msgs_image_bytes(W, H) || scratch_bytes < msgs_backward_scratch_bytes(P))
         return MSGS_ERR_CAPACITY;
     if (g->shs && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
+    if (g->raw_params && (!grads->dL_dfeatures_dc || !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const char* geom = (const char*)geom_v;
     const char* binning = (const char*)binning_v;

@@ -215,6 +215,88 @@ __device__ __forceinline__ void coop_store_rows(const float* lds_rows, float* g_
     }
 }
 
+// ---- raw-parameter mode (msgs_gaussians_t::raw_params): the activations of the reference's GaussianModel getters
+// (scene/gaussian_model.py:39-47,127-153), in the same float32 form torch evaluates them ----
+constexpr int REST_F = 45;         // floats per features_rest row (15 coefficients x 3 channels)
+
+__device__ __forceinline__ float act_opacity(const msgs_gaussians_t& g, int i) {
+    const float x = g.opacities[i];
+    return g.raw_params ? 1.0f / (1.0f + expf(-x)) : x;               // torch.sigmoid
+}
+__device__ __forceinline__ void act_scales(const msgs_gaussians_t& g, int i, float* s) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float x = g.scales[3 * i + k]; s[k] = g.raw_params ? expf(x) : x; }   // torch.exp
+}
+// q = raw / max(||raw||, 1e-12) (torch.nn.functional.normalize); returns the norm used
+__device__ __forceinline__ float act_rotation(const msgs_gaussians_t& g, int i, float* q) {
+    const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    if (!g.raw_params) return 1.0f;
+    const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = q[k] / n;
+    return n;
+}
+
+// SH rows of one wave from the split dc / rest parameters into LDS rows [dc(3) | rest(45)] (= the torch.cat of
+// gaussian_model.py:144-149): the rest rows of 64 consecutive Gaussians are ONE contiguous, 16-byte aligned run of
+// 64*45 floats, moved with full-width float4 loads.
+__device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const float* dc, const float* rest, int i,
+                                                     bool in_range, int wave_first, int nrow, int lane) {
+    if (in_range) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lds_rows[lane * ROW_LDS + c] = dc[3 * (size_t)i + c];
+    }
+    const float* src = rest + (size_t)wave_first * REST_F;
+    const int nflat = nrow * REST_F;
+    for (int base = 0; base < nflat; base += 256) {
+        const int f0 = base + lane * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (f0 + 3 < nflat) {
+            const float4 t = *reinterpret_cast<const float4*>(src + f0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (f0 + j < nflat) v[j] = src[f0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = f0 + j;
+            if (f < nflat) { const int row = f / REST_F; lds_rows[row * ROW_LDS + 3 + (f - row * REST_F)] = v[j]; }
+        }
+    }
+}
+
+// inverse: gradient rows from LDS to the split dc / rest gradient tensors (zeros for rows not in `live` and for
+// coefficients beyond the active degree)
+__device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, float* d_dc, float* d_rest, int i,
+                                                      bool in_range, int wave_first, int nrow, uint64_t live,
+                                                      int nfloat, int lane) {
+    if (in_range) {
+        const bool on = (live >> lane) & 1ull;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = on ? lds_rows[lane * ROW_LDS + c] : 0.f;
+    }
+    float* dst = d_rest + (size_t)wave_first * REST_F;
+    const int nflat = nrow * REST_F;
+    for (int base = 0; base < nflat; base += 256) {
+        const int f0 = base + lane * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = min(f0 + j, nflat - 1);
+            const int row = f / REST_F, k = f - row * REST_F;
+            v[j] = (((live >> row) & 1ull) && 3 + k < nfloat) ? lds_rows[row * ROW_LDS + 3 + k] : 0.f;
+        }
+        if (f0 + 3 < nflat) {
+            *reinterpret_cast<float4*>(dst + f0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (f0 + j < nflat) dst[f0 + j] = v[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
@@ -265,9 +347,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 #pragma unroll
             for (int k = 0; k < 6; ++k) cov3D[k] = g.cov3D_precomp[6 * i + k];
         } else {
-            const float sc[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
-            const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
-            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            float sc[3], q[4];
+            act_scales(g, i, sc);
+            act_rotation(g, i, q);
             cov3d_from_scale_rot(sc, vp.scale_modifier, q, cov3D);
         }
         Cov2D c2;
@@ -282,7 +364,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
         px = ((ndc_x + 1.0f) * vp.W - 1.0f) * 0.5f;
         py = ((ndc_y + 1.0f) * vp.H - 1.0f) * 0.5f;
-        const float o = g.opacities[i];
+        const float o = act_opacity(g, i);
         out_psize = pixel_size_of(o, conA, conC);                    // SPEC M1 (before any filter)
         minx = min(vp.gx, max(0, (int)((px - my_radius) / TILE)));
         miny = min(vp.gy, max(0, (int)((py - my_radius) / TILE)));
@@ -298,8 +380,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     } while (false);
 
     // ---- phase B: SH rows of the surviving Gaussians, HBM -> LDS, coalesced per row ----
-    const bool staged_sh = g.shs != nullptr && vp.sh_coeffs == 16;   // wave-uniform
-    if (staged_sh) {
+    const bool raw = g.raw_params != 0;
+    const bool staged_sh = raw || (g.shs != nullptr && vp.sh_coeffs == 16);   // wave-uniform
+    if (raw) {
+        const int wave_first = blockIdx.x * blockDim.x + wv * 64;
+        const int nrow = min(64, P - wave_first);
+        if (nrow > 0 && __ballot(alive) != 0)
+            coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane);
+        wave_lds_fence();
+    } else if (staged_sh) {
         const uint64_t need = __ballot(alive);
         if (alive) s_idx[wv][__popcll(need & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         wave_lds_fence();
@@ -312,7 +401,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     // ---- phase C: colour, exact tile-overlap count, record ----
     if (alive) {
         float rgb[3];
-        if (g.colors_precomp) {
+        if (g.colors_precomp && !raw) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c] = g.colors_precomp[3 * i + c];
         } else {
@@ -400,10 +489,16 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     const bool rendered = in_range && radii[i] > 0;
     // SH rows in / dSH rows out through LDS with coalesced wave-cooperative transfers (K == 16 only;
     // other layouts take the direct per-thread path)
-    const bool staged_sh = g.shs != nullptr && grads.dL_dshs != nullptr && K == 16;   // wave-uniform
+    const bool raw = g.raw_params != 0;
+    const bool staged_sh = raw || (g.shs != nullptr && grads.dL_dshs != nullptr && K == 16);   // wave-uniform
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
-    if (staged_sh) {
+    if (raw) {
+        const int nrow = min(64, P - wave_first);
+        if (nrow > 0 && live != 0)
+            coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane);
+        wave_lds_fence();
+    } else if (staged_sh) {
         if (rendered) s_idx[wv][__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         wave_lds_fence();
         coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(live),
@@ -412,6 +507,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     }
     float* dsh = staged_sh ? &s_rows[wv][lane * ROW_LDS]
                            : (grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr);
+    // (raw mode: the LDS row receives the gradient of the concatenated [dc | rest] coefficients)
 
     if (rendered) {
         Cam cm;
@@ -424,23 +520,26 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
         constexpr float LN2 = 0.69314718055994530942f;
         g2x = ga.x * (LN2 * vp.W); g2y = ga.y * (LN2 * vp.H);           // 2 ln2 * 0.5 W  (NDC-ish units)
         const float gA = -0.5f * ga.z, gBh = -0.5f * ga.w, gC = -0.5f * gb.x;
-        const float o_in = g.opacities[i];
+        const float o_in = act_opacity(g, i);
         dopac = o_in > 0.f ? gb.y / o_in : 0.f;                         // (q / (o w)) * w, SPEC M4
+        if (raw) dopac = dopac * (o_in * (1.0f - o_in));                // through the sigmoid
         dcolr[0] = gb.z; dcolr[1] = gb.w; dcolr[2] = gc.x;
         const uint32_t fl = flags[i];
         const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
 
         float cov3D[6];
         float R[3][3], S[3] = {0.f, 0.f, 0.f};
-        float qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        float qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f, qnorm = 1.0f;
+        float sact[3] = {1.f, 1.f, 1.f};
         if (g.cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) cov3D[k] = g.cov3D_precomp[6 * i + k];
         } else {
-            const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
-            const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
-            qr = q4.x; qx = q4.y; qy = q4.z; qz = q4.w;
-            const float q[4] = {qr, qx, qy, qz};
+            float s[3], q[4];
+            act_scales(g, i, s);
+            qnorm = act_rotation(g, i, q);
+            qr = q[0]; qx = q[1]; qy = q[2]; qz = q[3];
+            sact[0] = s[0]; sact[1] = s[1]; sact[2] = s[2];
             cov3d_from_scale_rot(s, vp.scale_modifier, q, cov3D);
             S[0] = vp.scale_modifier * s[0]; S[1] = vp.scale_modifier * s[1]; S[2] = vp.scale_modifier * s[2];
             R[0][0] = 1.f - 2.f * (qy * qy + qz * qz); R[0][1] = 2.f * (qx * qy - qr * qz); R[0][2] = 2.f * (qx * qz + qr * qy);
@@ -586,11 +685,25 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
             dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
             dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
             dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+            if (raw) {
+                // through exp: d/d(log s) = s * d/ds;  through normalize: (g - q (q.g)) / ||raw||
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dscale[j] = dscale[j] * sact[j];
+                const float dotq = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+                dq[0] = (dq[0] - r * dotq) / qnorm; dq[1] = (dq[1] - x * dotq) / qnorm;
+                dq[2] = (dq[2] - y * dotq) / qnorm; dq[3] = (dq[3] - z * dotq) / qnorm;
+            }
         }
     } else if (dsh && !staged_sh) {
         for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
     }
-    if (staged_sh) {
+    if (raw) {
+        wave_lds_fence();
+        const int nrow = min(64, P - wave_first);
+        if (nrow > 0)
+            coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range, wave_first,
+                                  nrow, live, 3 * (deg + 1) * (deg + 1), lane);
+    } else if (staged_sh) {
         wave_lds_fence();
         const int nrow = min(64, P - wave_first);
         if (nrow > 0)

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _backend as _C
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -70,7 +70,7 @@ class _Call:
     """Marshals one (settings, tensors) pair into the C structs; keeps the tensors alive."""
 
     def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                 max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask):
+                 max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raw_features=None):
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("diff_gaussian_rasterization (MI355X build): tensors must live on a HIP device "
@@ -100,6 +100,13 @@ class _Call:
             if t is not None and t.numel() != n:
                 raise ValueError(f"{name} must have {n} elements, got {tuple(t.shape)}")
         self.K = int(self.sh.shape[1]) if self.sh is not None else 0
+        self.fdc = self.frest = None
+        if raw_features is not None:        # raw GaussianModel parameters (msgs_gaussians_t::raw_params = 1)
+            fdc, frest = raw_features
+            self.fdc, self.frest = _f32c(fdc), _f32c(frest)
+            if self.fdc.numel() != 3 * P or self.frest.numel() != 45 * P:
+                raise ValueError("raw mode needs features_dc [P,1,3] and features_rest [P,15,3]")
+            self.K = 16
         self.bg = _f32c(rs.bg.to(dev))
         self.vm = _f32c(rs.viewmatrix.to(dev))
         self.pm = _f32c(rs.projmatrix.to(dev))
@@ -109,9 +116,10 @@ class _Call:
                             float(rs.fade_size), int(rs.sh_degree), self.K,
                             int(bool(rs.filter_small)), int(bool(rs.filter_large)), int(bool(rs.prefiltered)),
                             int(bool(rs.debug)), _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
-        self.g = _C.Gaussians(P, 0, _ptr(self.means3D), _ptr(self.sh), _ptr(self.colors), _ptr(self.opac),
-                              _ptr(self.scales), _ptr(self.rot), _ptr(self.cov), _ptr(self.maxps),
-                              _ptr(self.minps), _ptr(self.occ), _ptr(self.dcd), _ptr(self.base))
+        self.g = _C.Gaussians(P, 1 if raw_features is not None else 0, _ptr(self.means3D), _ptr(self.sh),
+                              _ptr(self.colors), _ptr(self.opac), _ptr(self.scales), _ptr(self.rot), _ptr(self.cov),
+                              _ptr(self.maxps), _ptr(self.minps), _ptr(self.occ), _ptr(self.dcd), _ptr(self.base),
+                              _ptr(self.fdc), _ptr(self.frest))
 
 
 def _forward_impl(call):
@@ -196,7 +204,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_cov = torch.empty(P, 6, dtype=torch.float32, device=dev) if call.cov is not None else None
             scratch = _bytes(lib.msgs_backward_scratch_bytes(P), dev)
             grads = _C.Grads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
-                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov))
+                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, None)
             _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
@@ -206,6 +214,56 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (g_means3D, g_means2D.view(m2_shape) if g_means2D.shape == m2_shape else g_means2D,
                 g_sh, g_col, g_opac.view(op_shape), g_scales, g_rot, g_cov,
                 None, None, None, None, None, None)
+
+
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Opt-in fused entry: takes the RAW GaussianModel parameters
+    (/root/reference/scene/gaussian_model.py:53-58: _xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation);
+    exp / sigmoid / normalize (:39-47) and the dc|rest concatenation (:144-149) run inside the HIP kernels and the
+    backward returns gradients w.r.t. the raw parameters.  Same five outputs as the reference op."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
+        if xyz.shape[0] == 0:
+            raise ValueError("rasterize_gaussians_raw: empty model")
+        call = _Call(raster_settings, xyz, None, None, opacity_raw, scaling_raw, rotation_raw, None,
+                     _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
+                     _opt(base_mask), raw_features=(features_dc, features_rest))
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
+        ctx.call, ctx.state, ctx.radii = call, state, radii
+        ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
+        ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
+        return color, acc_ps, depth, radii, pixel_sizes
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
+        call = ctx.call
+        geom, binning, image, D = ctx.state
+        dev, P = call.device, call.P
+        lib = _C.lib
+        m2_shape, dc_shape, rest_shape, op_shape = ctx.shapes
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            dL = _f32c(grad_color)
+            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            g_xyz, g_m2, g_opac, g_dc, g_rest, g_scal, g_rot = e(P, 3), e(P, 3), e(P), e(P, 3), e(P, 45), e(P, 3), e(P, 4)
+            scratch = _bytes(lib.msgs_backward_scratch_bytes(P), dev)
+            grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, None, _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
+                             _ptr(g_dc), _ptr(g_rest))
+            _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
+                                       geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
+                                       image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
+                                       _C.timer_ptr(), stream), "msgs_backward")
+        return (g_xyz, g_m2.view(m2_shape), g_dc.view(dc_shape), g_rest.view(rest_shape), g_opac.view(op_shape),
+                g_scal, g_rot, None, None, None, None, None, None)
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                            max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                        rotation_raw, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta,
+                                        base_mask, raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -236,6 +294,15 @@ class GaussianRasterizer(nn.Module):
                 _C.check(_C.lib.msgs_mark_visible(int(pos.shape[0]), _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out),
                                                   stream), "msgs_mark_visible")
         return out.bool()
+
+    def forward_raw(self, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                    max_pixel_sizes=None, min_pixel_sizes=None, occ_multiplier=None, dc_delta=None, base_mask=None):
+        """Opt-in fused path on raw GaussianModel parameters (not part of the reference API)."""
+        empty = torch.Tensor([])
+        o = lambda t: t if t is not None else empty
+        return rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                       rotation_raw, o(max_pixel_sizes), o(min_pixel_sizes), o(occ_multiplier),
+                                       o(dc_delta), o(base_mask), self.raster_settings)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, max_pixel_sizes=None, min_pixel_sizes=None, occ_multiplier=None,

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -32,18 +32,20 @@ class View(C.Structure):
 
 
 class Gaussians(C.Structure):
-    _fields_ = [("P", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("P", C.c_int32), ("raw_params", C.c_int32),
                 ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
                 ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
                 ("cov3D_precomp", C.c_void_p), ("max_pixel_sizes", C.c_void_p),
                 ("min_pixel_sizes", C.c_void_p), ("occ_multiplier", C.c_void_p),
-                ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p)]
+                ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p),
+                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p)]
 
 
 class Grads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p)]
 
 
 class Timing(C.Structure):

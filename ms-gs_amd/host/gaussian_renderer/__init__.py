@@ -87,3 +87,26 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # (reference :110-119)
     values = (image, acc_pixel_size, depth, viewspace, radii > 0, radii, pixel_sizes)
     return dict(zip(RESULT_KEYS, values))
+
+
+def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, filter_small=False,
+                 filter_large=False, fade_size=1.0):
+    """Opt-in variant of render(): hands the RAW parameters of the model (pc._xyz,
+    pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation — the attribute names of the reference's
+    GaussianModel, scene/gaussian_model.py:53-58) to the rasterizer, which evaluates the getters' activations
+    (:127-153) and the SH concatenation (:144-149) inside its kernels.  Same result dict as render(); gradients land
+    on the same leaf Parameters.  Not usable with override_color / convert_SHs_python / compute_cov3D_python."""
+    xyz = pc._xyz
+    viewspace = torch.zeros_like(xyz, requires_grad=True) + 0
+    try:
+        viewspace.retain_grad()
+    except Exception:
+        pass
+    rasterizer = GaussianRasterizer(raster_settings=_settings(
+        viewpoint_camera, pc, pipe, bg_color, scaling_modifier, filter_small, filter_large, fade_size))
+    image, acc_pixel_size, depth, radii, pixel_sizes = rasterizer.forward_raw(
+        xyz, viewspace, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation,
+        max_pixel_sizes=pc.get_max_pixel_sizes, min_pixel_sizes=pc.get_min_pixel_sizes,
+        occ_multiplier=pc.get_occ_multiplier, dc_delta=pc.get_dc_delta, base_mask=pc.get_base_mask)
+    values = (image, acc_pixel_size, depth, viewspace, radii > 0, radii, pixel_sizes)
+    return dict(zip(RESULT_KEYS, values))

@@ -27,18 +27,20 @@ class View(C.Structure):
 
 
 class Gaussians(C.Structure):
-    _fields_ = [("P", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("P", C.c_int32), ("raw_params", C.c_int32),
                 ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
                 ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
                 ("cov3D_precomp", C.c_void_p), ("max_pixel_sizes", C.c_void_p),
                 ("min_pixel_sizes", C.c_void_p), ("occ_multiplier", C.c_void_p),
-                ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p)]
+                ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p),
+                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p)]
 
 
 class Grads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p)]
 
 
 def build(force=False):
@@ -162,7 +164,7 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
              0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
     g = Gaussians(P, 0, _ptr(t["means3D"]), _ptr(t["shs"]), _ptr(t["col"]), _ptr(t["opac"]),
                   _ptr(t["scales"]), _ptr(t["rot"]), _ptr(t["cov"]), _ptr(t["maxps"]), _ptr(t["minps"]),
-                  _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]))
+                  _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]), None, None)
     r.color = torch.zeros(3, H, W)
     r.acc_pixel_size = torch.zeros(H, W)
     r.depth = torch.zeros(H, W)
@@ -200,7 +202,7 @@ def backward(r, dL_dcolor, num_threads=0):
         out["cov3D_precomp"] = torch.zeros(P, 6)
     gr = Grads(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out.get("shs")), _ptr(out.get("colors_precomp")),
                _ptr(out["opacities"]), _ptr(out.get("scales")), _ptr(out.get("rotations")),
-               _ptr(out.get("cov3D_precomp")))
+               _ptr(out.get("cov3D_precomp")), None, None)
     rc = L.msgs_oracle_backward(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), int(num_threads))
     if rc != 0:
         raise RuntimeError(f"msgs_oracle_backward failed: {rc}")

@@ -1,0 +1,93 @@
+"""Opt-in fused entry: raw GaussianModel parameters in, activations + SH concatenation inside
+the kernels, gradients w.r.t. the raw parameters out.  Checked against the reference-API path (torch activations
+around the op) and against the CPU oracle."""
+import pytest
+import torch
+
+import scenes
+from parity_utils import PIPE, check_forward, rel_err, small_scene
+
+pytestmark = pytest.mark.gpu
+
+LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def _run(fn, sc, cam, st, bg, dL, **kw):
+    from synthetic_model import SyntheticGaussians
+    pc = SyntheticGaussians(sc, "cuda", requires_grad=True)
+    out = fn(cam.to("cuda"), pc, PIPE, bg.to("cuda"), **st, **kw)
+    out["render"].backward(dL.to("cuda"))
+    torch.cuda.synchronize()
+    return out, pc
+
+
+@pytest.mark.parametrize("P,W,H,seed,deg,ms", [(400, 48, 40, 1, 3, False), (6000, 160, 128, 2, 3, True),
+                                                 (3000, 130, 70, 3, 1, False), (3000, 96, 96, 4, 0, True),
+                                                 (5000, 128, 128, 5, 2, False)])
+def test_fused_matches_reference_api_path(P, W, H, seed, deg, ms):
+    from gaussian_renderer import render, render_fused
+    sc, cam = small_scene(P, W, H, 100 + seed, sh_degree=deg, multiscale=ms,
+                          **({"scale_k": 0.004 * 1920.0 / W * 0.2} if ms else {}))
+    sc.rotations = sc.rotations * (0.5 + torch.rand(P, 1, generator=torch.Generator().manual_seed(seed)))  # un-normalised
+    st = dict(filter_small=ms, filter_large=ms, fade_size=0.0 if ms else 1.0)
+    bg = torch.tensor([0.1, 0.4, 0.8])
+    dL = scenes.grad_seed(W, H, seed)
+    a, pa = _run(render, sc, cam, st, bg, dL)
+    b, pb = _run(render_fused, sc, cam, st, bg, dL)
+    assert torch.equal(a["radii"], b["radii"])
+    assert (a["render"] - b["render"]).abs().max().item() <= 2e-6
+    assert (a["acc_pixel_size"] - b["acc_pixel_size"]).abs().max().item() <= 1e-4
+    assert torch.allclose(a["pixel_sizes"], b["pixel_sizes"], rtol=1e-5, atol=1e-6)
+    for n in LEAVES:
+        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= 1e-4, n      # north_star gradient tolerance
+    assert rel_err(b["viewspace_points"].grad, a["viewspace_points"].grad) <= 1e-4
+    assert pb._features_rest.grad.shape == pb._features_rest.shape and pb._opacity.grad.shape == pb._opacity.shape
+
+
+def test_fused_vs_oracle_forward_backward_and_scale_modifier():
+    import copy
+    from gaussian_renderer import render_fused
+    from oracle import oracle_ctypes as oc
+    from parity_utils import check_backward
+    from synthetic_model import SyntheticGaussians
+    W, H = 120, 80
+    sc, cam = small_scene(3000, W, H, 77)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    dL = scenes.grad_seed(W, H, 7)
+    pc = SyntheticGaussians(sc, "cuda", requires_grad=True)
+    seen = copy.copy(sc)
+    with torch.no_grad():            # the activated values, as torch evaluates them on the GPU (parity_utils.hip_render)
+        seen.scales, seen.rotations = pc.get_scaling.cpu(), pc.get_rotation.cpu()
+        seen.opacities, seen.shs = pc.get_opacity.cpu(), pc.get_features.cpu()
+    out = render_fused(cam.to("cuda"), pc, PIPE, bg.cuda(), scaling_modifier=0.8)
+    out["render"].backward(dL.cuda())
+    torch.cuda.synchronize()
+    orc = oc.rasterize(seen, cam, dict(filter_small=False, filter_large=False, fade_size=1.0), bg, scale_modifier=0.8)
+    check_forward(out, orc, "fused")
+    check_backward(pc, out["viewspace_points"].grad, oc.backward(orc, dL), "fused", flagged=orc.borderline_gaussians)
+
+
+def test_fused_c3_fullsize_matches_reference_api_path():
+    from gaussian_renderer import render, render_fused
+    sc, cam, st = scenes.config("C3")
+    bg = torch.zeros(3)
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 2)
+    a, pa = _run(render, sc, cam, st, bg, dL)
+    b, pb = _run(render_fused, sc, cam, st, bg, dL)
+    assert (a["radii"] != b["radii"]).sum().item() <= 2            # normalize() may differ from torch by 1 ulp
+    frac_bad = ((a["render"] - b["render"]).abs() > 1e-5).float().mean().item()
+    assert frac_bad < 1e-4
+    for n in LEAVES:                                               # float-atomic noise floor at this size
+        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= 1e-3, n
+
+
+def test_fused_argument_errors():
+    from diff_gaussian_rasterization import _backend as _C
+    assert b"exactly one" in _C.lib.msgs_error_string(-1)
+    from gaussian_renderer import render_fused
+    from synthetic_model import SyntheticGaussians
+    sc, cam = small_scene(50, 32, 32, 9)
+    pc = SyntheticGaussians(sc, "cuda", requires_grad=False)
+    pc._features_rest = torch.nn.Parameter(pc._features_rest[:, :8].contiguous())        # wrong SH layout
+    with pytest.raises(ValueError):
+        render_fused(cam.to("cuda"), pc, PIPE, torch.zeros(3).cuda())
