@@ -210,6 +210,52 @@ int msgs_voxel_pool_build(const float* positions, int64_t M, float voxel_size, u
 int msgs_voxel_pool_average(const float* features, int32_t F, const uint32_t* order, const uint32_t* seg_start,
                             int64_t num_voxels, float* out, void* stream);
 
+/* ---- train-step epilogue ------------------------------------------------------------------
+ * msgs_adam_step replaces torch.optim.Adam(l, lr=0.0, eps=1e-15).step() over the model's leaf tensors
+ * (/root/reference/scene/gaussian_model.py:235-248, /root/reference/train.py:416-418) with ONE launch; the state
+ * tensors are the optimizer's own state["exp_avg"], state["exp_avg_sq"] (the reference's densification code slices
+ * and concatenates them: gaussian_model.py:419-476), `step` is the 1-based step count after increment, `lr` the
+ * group's current learning rate.  Semantics: torch Adam with amsgrad=False, weight_decay=0, maximize=False. */
+#define MSGS_ADAM_MAX_TENSORS 8
+typedef struct msgs_adam_tensor {
+    float* param;            /* [n] updated in place */
+    const float* grad;       /* [n] */
+    float* exp_avg;          /* [n] updated in place */
+    float* exp_avg_sq;       /* [n] updated in place */
+    int64_t n;               /* number of floats */
+    double lr;               /* double like the Python float in param_group["lr"]: scalars are rounded to float once */
+} msgs_adam_tensor_t;
+int msgs_adam_step(const msgs_adam_tensor_t* tensors, int32_t n_tensors, int64_t step, double beta1, double beta2,
+                   double eps, void* stream);
+
+/* msgs_densify_stats: every per-Gaussian statistic the reference updates between backward() and optimizer.step(),
+ * in one launch, all masked by visibility_filter = radii > 0 (/root/reference/train.py:239-250):
+ *   MSGS_STATS_BASE_MASK    base_mask |= visible                         (gaussian_model.py:702-704)
+ *   MSGS_STATS_PIXEL_SIZES  update_pixel_sizes(visible, pixel_sizes, reso_lvl)   (gaussian_model.py:663-687)
+ *   MSGS_STATS_DENSIFY      max_radii2D = max(max_radii2D, radii); xyz_gradient_accum[:, reso_lvl] += |grad_xy|;
+ *                           denom[:, reso_lvl] += 1                      (train.py:247-250, gaussian_model.py:698-701)
+ * Pointers of a group that is not selected may be NULL. */
+#define MSGS_STATS_BASE_MASK 1
+#define MSGS_STATS_PIXEL_SIZES 2
+#define MSGS_STATS_DENSIFY 4
+typedef struct msgs_densify_stats {
+    int32_t P;
+    int32_t flags;
+    int32_t reso_lvl;                /* resolution level trained this iteration (train.py reso_idx) */
+    int32_t reso_lvls;               /* number of levels (second dim of xyz_gradient_accum / denom) */
+    const int32_t* radii;            /* [P] output of the forward */
+    const float* pixel_sizes;        /* [P] output of the forward */
+    const float* means2D_grad;       /* [P,3] viewspace_points.grad */
+    const int64_t* target_reso_lvl;  /* [P] torch.long, gaussian_model.py:227 */
+    float* xyz_gradient_accum;       /* [P, reso_lvls, 1] */
+    float* denom;                    /* [P, reso_lvls, 1] */
+    float* max_radii2D;              /* [P] */
+    float* max_pixel_sizes;          /* [P] */
+    float* min_pixel_sizes;          /* [P] */
+    uint8_t* base_mask;              /* [P] torch.bool */
+} msgs_densify_stats_t;
+int msgs_densify_stats(const msgs_densify_stats_t* stats, void* stream);
+
 /* timing helpers: create/destroy the 2*MSGS_K_COUNT events and read elapsed ms per kernel class
  * (ms_host[MSGS_K_COUNT]; a class that was not recorded reads as -1).  The caller synchronises
  * the stream before msgs_timing_read. */

@@ -270,6 +270,32 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
     return MSGS_OK;
 }
 
+int msgs_adam_step(const msgs_adam_tensor_t* tensors, int32_t n_tensors, int64_t step, double beta1, double beta2,
+                   double eps, void* stream) {
+    if (n_tensors < 0 || n_tensors > MSGS_ADAM_MAX_TENSORS || step < 1 || (n_tensors && !tensors))
+        return MSGS_ERR_INVALID_ARG;
+    for (int k = 0; k < n_tensors; ++k) {
+        const msgs_adam_tensor_t& t = tensors[k];
+        if (t.n < 0 || (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq))) return MSGS_ERR_INVALID_ARG;
+        if (t.n > (int64_t)1 << 40) return MSGS_ERR_TOO_MANY;
+    }
+    HIP_TRY(launch_adam(tensors, n_tensors, step, beta1, beta2, eps, (hipStream_t)stream));
+    return MSGS_OK;
+}
+
+int msgs_densify_stats(const msgs_densify_stats_t* d, void* stream) {
+    if (!d || d->P < 0 || d->reso_lvls < 1 || d->reso_lvl < 0 || d->reso_lvl >= d->reso_lvls) return MSGS_ERR_INVALID_ARG;
+    if (d->P == 0 || d->flags == 0) return MSGS_OK;
+    if (!d->radii) return MSGS_ERR_INVALID_ARG;
+    if ((d->flags & MSGS_STATS_BASE_MASK) && !d->base_mask) return MSGS_ERR_INVALID_ARG;
+    if ((d->flags & MSGS_STATS_PIXEL_SIZES) &&
+        (!d->pixel_sizes || !d->target_reso_lvl || !d->max_pixel_sizes || !d->min_pixel_sizes)) return MSGS_ERR_INVALID_ARG;
+    if ((d->flags & MSGS_STATS_DENSIFY) && (!d->means2D_grad || !d->xyz_gradient_accum || !d->denom || !d->max_radii2D))
+        return MSGS_ERR_INVALID_ARG;
+    HIP_TRY(launch_densify_stats(*d, (hipStream_t)stream));
+    return MSGS_OK;
+}
+
 size_t msgs_voxel_pool_scratch_bytes(int64_t M) { return voxel_pool_scratch_bytes(M); }
 
 int msgs_voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,

@@ -300,6 +300,11 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s);
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s);
+// epilogue.hip
+hipError_t launch_adam(const msgs_adam_tensor_t* tensors, int n, int64_t step, double beta1, double beta2, double eps,
+                       hipStream_t s);
+hipError_t launch_densify_stats(const msgs_densify_stats_t& d, hipStream_t s);
+
 // voxel_pool.hip
 size_t voxel_pool_scratch_bytes(int64_t M);
 hipError_t voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,

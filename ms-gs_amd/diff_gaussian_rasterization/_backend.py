@@ -48,6 +48,23 @@ class Grads(C.Structure):
                 ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_double)]
+
+
+ADAM_MAX_TENSORS = 8
+STATS_BASE_MASK, STATS_PIXEL_SIZES, STATS_DENSIFY = 1, 2, 4
+
+
+class DensifyStats(C.Structure):
+    _fields_ = [("P", C.c_int32), ("flags", C.c_int32), ("reso_lvl", C.c_int32), ("reso_lvls", C.c_int32),
+                ("radii", C.c_void_p), ("pixel_sizes", C.c_void_p), ("means2D_grad", C.c_void_p),
+                ("target_reso_lvl", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("max_radii2D", C.c_void_p), ("max_pixel_sizes", C.c_void_p), ("min_pixel_sizes", C.c_void_p),
+                ("base_mask", C.c_void_p)]
+
+
 class Timing(C.Structure):
     _fields_ = [("ev", C.c_void_p * (2 * K_COUNT))]
 
@@ -91,6 +108,10 @@ def _load():
     lib.msgs_voxel_pool_build.argtypes = [vp, C.c_int64, C.c_float, vp, vp, vp, vp, sz, C.POINTER(C.c_int64), vp]
     lib.msgs_voxel_pool_average.restype = C.c_int
     lib.msgs_voxel_pool_average.argtypes = [vp, C.c_int32, vp, vp, C.c_int64, vp, vp]
+    lib.msgs_adam_step.restype = C.c_int
+    lib.msgs_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, vp]
+    lib.msgs_densify_stats.restype = C.c_int
+    lib.msgs_densify_stats.argtypes = [C.POINTER(DensifyStats), vp]
     for name in ("msgs_timing_create", "msgs_timing_destroy"):
         f = getattr(lib, name)
         f.restype = C.c_int
@@ -109,7 +130,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_binning_bytes", "msgs_stage2_scratch_bytes", "msgs_image_bytes", "msgs_backward_scratch_bytes",
            "msgs_forward_stage1", "msgs_forward_stage2", "msgs_backward", "msgs_mark_visible",
            "msgs_binning_stats", "msgs_timing_create", "msgs_timing_destroy", "msgs_timing_read",
-           "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average")
+           "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average", "msgs_adam_step",
+           "msgs_densify_stats")
 
 
 def check(rc, where):
