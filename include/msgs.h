@@ -256,6 +256,20 @@ typedef struct msgs_densify_stats {
 } msgs_densify_stats_t;
 int msgs_densify_stats(const msgs_densify_stats_t* stats, void* stream);
 
+/* ---- fused photometric loss ----------------------------------------------------------------
+ * loss = (1 - lambda_dssim) * l1_loss(img, gt) + lambda_dssim * (1 - ssim(img, gt))   (/root/reference/train.py:209-211)
+ * with l1_loss / ssim of /root/reference/utils/loss_utils.py:17-18,32-63 (window 11, sigma 1.5, zero padding, mean).
+ * img, gt: [C,H,W] float32 device tensors.  msgs_loss_forward writes out3 = {loss, l1 mean, ssim mean} (device) and,
+ * when keep_for_backward != 0, the derivative maps into scratch; msgs_loss_backward then writes
+ * dL_dimg[C,H,W] = upstream * dloss/dimg (upstream: device scalar, NULL = 1) — the layout msgs_backward consumes.
+ * The loss value is summed in a fixed order (run-to-run identical).  msgs_ssim_window returns the 11 window taps. */
+size_t msgs_loss_scratch_bytes(int32_t C, int32_t H, int32_t W);
+int msgs_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                      float* out3, void* scratch, size_t scratch_bytes, int32_t keep_for_backward, void* stream);
+int msgs_loss_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                       const float* upstream, const void* scratch, size_t scratch_bytes, float* dL_dimg, void* stream);
+int msgs_ssim_window(float* taps11_host);
+
 /* timing helpers: create/destroy the 2*MSGS_K_COUNT events and read elapsed ms per kernel class
  * (ms_host[MSGS_K_COUNT]; a class that was not recorded reads as -1).  The caller synchronises
  * the stream before msgs_timing_read. */

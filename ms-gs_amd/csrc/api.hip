@@ -296,6 +296,43 @@ int msgs_densify_stats(const msgs_densify_stats_t* d, void* stream) {
     return MSGS_OK;
 }
 
+static int loss_args_ok(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda) {
+    if (!img || !gt || C < 1 || H < 1 || W < 1 || !(lambda >= 0.f && lambda <= 1.f)) return MSGS_ERR_INVALID_ARG;
+    if ((int64_t)C * H * W > (int64_t)1 << 31 || C > 65535) return MSGS_ERR_TOO_MANY;
+    return MSGS_OK;
+}
+
+size_t msgs_loss_scratch_bytes(int32_t C, int32_t H, int32_t W) {
+    if (C < 1 || H < 1 || W < 1) return 0;
+    return loss_scratch_bytes(C, H, W);
+}
+
+int msgs_loss_forward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                      float* out3, void* scratch, size_t scratch_bytes, int32_t keep_for_backward, void* stream) {
+    if (int rc = loss_args_ok(img, gt, C, H, W, lambda_dssim)) return rc;
+    if (!out3 || !scratch) return MSGS_ERR_INVALID_ARG;
+    if (scratch_bytes < loss_scratch_bytes(C, H, W)) return MSGS_ERR_CAPACITY;
+    HIP_TRY(launch_loss_forward(img, gt, C, H, W, lambda_dssim, out3, (char*)scratch, keep_for_backward != 0,
+                                (hipStream_t)stream));
+    return MSGS_OK;
+}
+
+int msgs_loss_backward(const float* img, const float* gt, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                       const float* upstream, const void* scratch, size_t scratch_bytes, float* dL_dimg, void* stream) {
+    if (int rc = loss_args_ok(img, gt, C, H, W, lambda_dssim)) return rc;
+    if (!dL_dimg || !scratch) return MSGS_ERR_INVALID_ARG;
+    if (scratch_bytes < loss_scratch_bytes(C, H, W)) return MSGS_ERR_CAPACITY;
+    HIP_TRY(launch_loss_backward(img, gt, C, H, W, lambda_dssim, upstream, (const char*)scratch, dL_dimg,
+                                 (hipStream_t)stream));
+    return MSGS_OK;
+}
+
+int msgs_ssim_window(float* taps11_host) {
+    if (!taps11_host) return MSGS_ERR_INVALID_ARG;
+    ssim_window_host(taps11_host);
+    return MSGS_OK;
+}
+
 size_t msgs_voxel_pool_scratch_bytes(int64_t M) { return voxel_pool_scratch_bytes(M); }
 
 int msgs_voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,

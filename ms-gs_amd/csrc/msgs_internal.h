@@ -305,6 +305,14 @@ hipError_t launch_adam(const msgs_adam_tensor_t* tensors, int n, int64_t step, d
                        hipStream_t s);
 hipError_t launch_densify_stats(const msgs_densify_stats_t& d, hipStream_t s);
 
+// loss.hip
+size_t loss_scratch_bytes(int C, int H, int W);
+void ssim_window_host(float w[11]);
+hipError_t launch_loss_forward(const float* img, const float* gt, int C, int H, int W, float lambda, float* out3,
+                               char* scratch, int write_maps, hipStream_t s);
+hipError_t launch_loss_backward(const float* img, const float* gt, int C, int H, int W, float lambda,
+                                const float* upstream, const char* scratch, float* dL_dimg, hipStream_t s);
+
 // voxel_pool.hip
 size_t voxel_pool_scratch_bytes(int64_t M);
 hipError_t voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,

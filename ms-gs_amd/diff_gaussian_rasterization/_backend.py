@@ -112,6 +112,14 @@ def _load():
     lib.msgs_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, vp]
     lib.msgs_densify_stats.restype = C.c_int
     lib.msgs_densify_stats.argtypes = [C.POINTER(DensifyStats), vp]
+    lib.msgs_loss_scratch_bytes.restype = sz
+    lib.msgs_loss_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.msgs_loss_forward.restype = C.c_int
+    lib.msgs_loss_forward.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp, sz, C.c_int32, vp]
+    lib.msgs_loss_backward.restype = C.c_int
+    lib.msgs_loss_backward.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp, sz, vp, vp]
+    lib.msgs_ssim_window.restype = C.c_int
+    lib.msgs_ssim_window.argtypes = [C.POINTER(C.c_float)]
     for name in ("msgs_timing_create", "msgs_timing_destroy"):
         f = getattr(lib, name)
         f.restype = C.c_int
@@ -131,7 +139,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_forward_stage1", "msgs_forward_stage2", "msgs_backward", "msgs_mark_visible",
            "msgs_binning_stats", "msgs_timing_create", "msgs_timing_destroy", "msgs_timing_read",
            "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average", "msgs_adam_step",
-           "msgs_densify_stats")
+           "msgs_densify_stats", "msgs_loss_scratch_bytes", "msgs_loss_forward", "msgs_loss_backward",
+           "msgs_ssim_window")
 
 
 def check(rc, where):
