@@ -75,6 +75,62 @@ def cpu_baseline(scenes, scene, settings, W, H, runs=2):
                       f"C++/OpenMP oracle on all {cores} host cores, best of {runs} runs"}
 
 
+def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup):
+    import torch.nn.functional as F
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    from train_epilogue import FusedAdam
+    from train_step import fused_train_iteration
+    from parity_utils import PIPE
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    out = {}
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t) / steps
+
+    model = SyntheticGaussians(scene, dev)
+    opt = FusedAdam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
+    out["ms_per_iteration"] = round(timed(lambda: fused_train_iteration(model, opt, cam, gt, PIPE, bg, **settings)), 4)
+    del model, opt
+
+    model = SyntheticGaussians(scene, dev)
+    opt = torch.optim.Adam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
+    taps = torch.tensor([math.exp(-(k - 5) ** 2 / (2 * 1.5 ** 2)) for k in range(11)])       # loss_utils.py:23-30
+    taps = (taps / taps.sum()).unsqueeze(1)
+    w = taps.mm(taps.t()).float().to(dev).expand(3, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t, w, padding=5, groups=3)
+
+    def torch_composition():
+        pkg = render(cam, model, PIPE, bg, **settings)
+        x = pkg["render"]
+        m1, m2 = conv(x), conv(gt)
+        m1s, m2s, m12 = m1.pow(2), m2.pow(2), m1 * m2
+        s1, s2, s12 = conv(x * x) - m1s, conv(gt * gt) - m2s, conv(x * gt) - m12
+        S = ((2 * m12 + 0.01 ** 2) * (2 * s12 + 0.03 ** 2)) / ((m1s + m2s + 0.01 ** 2) * (s1 + s2 + 0.03 ** 2))
+        loss = 0.8 * torch.abs(x - gt).mean() + 0.2 * (1.0 - S.mean())
+        loss.backward()
+        with torch.no_grad():
+            vis, radii, ps = pkg["visibility_filter"], pkg["radii"], pkg["pixel_sizes"]
+            mask = vis & (model.target_reso_lvl == 0)
+            mn = torch.clip(model.min_pixel_sizes[mask] * 1.05, -1)
+            model.min_pixel_sizes[mask] = torch.where(ps[mask] > 0, torch.where(mn < 0, ps[mask], torch.min(mn, ps[mask])), mn)
+            model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis])
+            model.xyz_gradient_accum[:, 0][vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
+            model.denom[:, 0][vis] += 1
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    out["ms_per_iteration_torch_composition"] = round(timed(torch_composition), 4)
+    out["note"] = "C3 scene, fixed U(0,1) target, lambda_dssim 0.2, level 0, statistics on; informational"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +309,15 @@ def main():
                                         "unit": "Mpixels/s", "entry": "GaussianRasterizer.forward_raw"}
             except Exception as e:
                 result["fused_path"] = {"error": repr(e)}
+            # informational: one whole training iteration (train.py:202-218,239-250,416-418) on the same workload —
+            # render_fused + fused L1/SSIM loss + backward + statistics + FusedAdam, vs the same iteration with the
+            # reference's torch composition around this rasterizer (torch loss formulation, torch.optim.Adam, masked-
+            # index statistics).  Separate copies of the model; neither is part of `value`.
+            try:
+                result["train_iteration"] = train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev,
+                                                                   args.steps, args.warmup)
+            except Exception as e:
+                result["train_iteration"] = {"error": repr(e)}
         result["binning"] = stats
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -53,6 +53,23 @@ class SyntheticGaussians:
     def parameters(self):
         return [getattr(self, n) for n in self.LEAVES]
 
+    # per-group learning rates of OptimizationParams (/root/reference/arguments/__init__.py:73-79)
+    LRS = dict(xyz=0.00016, f_dc=0.0025, f_rest=0.0025 / 20.0, opacity=0.05, scaling=0.005, rotation=0.001)
+
+    def training_setup(self, reso_lvls=1, target_reso_lvl=None, spatial_lr_scale=1.0):
+        """The state GaussianModel.training_setup / create_from_pcd allocate (gaussian_model.py:222-233) and the
+        optimizer param groups of :235-246 (the two lr-0 groups without gradients are omitted).  Returns the groups."""
+        P, dev = self._xyz.shape[0], self._xyz.device
+        self.reso_lvls = int(reso_lvls)
+        self.xyz_gradient_accum = torch.zeros((P, self.reso_lvls, 1), device=dev)
+        self.denom = torch.zeros((P, self.reso_lvls, 1), device=dev)
+        self.max_radii2D = torch.zeros((P,), device=dev)
+        self.target_reso_lvl = (torch.zeros((P,), dtype=torch.long, device=dev) if target_reso_lvl is None
+                                else target_reso_lvl.to(dev, torch.long).contiguous())
+        names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+        return [{"params": [getattr(self, leaf)], "lr": self.LRS[n] * (spatial_lr_scale if n == "xyz" else 1.0), "name": n}
+                for n, leaf in zip(names, self.LEAVES)]
+
     # --- getters with the reference's activations (gaussian_model.py:127-183) ---
     @property
     def get_xyz(self):

@@ -1,0 +1,34 @@
+"""One MS-GS training iteration composed from the GPU pieces of this package — the body of the reference's loop
+(/root/reference/train.py:202-218 render + loss + backward, :239-250 statistics, :416-418 optimizer step) with every
+per-Gaussian / per-pixel pass inside libmsgs_hip.so:
+
+    render_fused        activations + rasterizer forward            (gaussian_renderer.render_fused)
+    l1_ssim_loss        photometric loss                            (loss_utils.l1_ssim_loss)
+    backward            loss gradient -> rasterizer backward -> raw-parameter gradients
+    update_training_stats, FusedAdam.step                           (train_epilogue)
+
+The densification POLICY (when to clone / split / prune / insert, train.py:252-262) stays with the caller: it is
+control plane, out of scope here.
+"""
+import torch
+
+from gaussian_renderer import render_fused
+from loss_utils import l1_ssim_loss
+from train_epilogue import update_training_stats
+
+
+def fused_train_iteration(model, optimizer, cam, gt_image, pipe, bg, *, lambda_dssim=0.2, loss_multiplier=1.0,
+                          reso_lvl=0, filter_small=False, filter_large=False, fade_size=1.0, base_mask=False,
+                          update_pixel_sizes=True, densify=True):
+    """Returns (loss, Ll1, render_pkg); loss / Ll1 are 0-dim GPU tensors (no host sync is issued here)."""
+    pkg = render_fused(cam, model, pipe, bg, filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)
+    loss, Ll1 = l1_ssim_loss(pkg["render"], gt_image, lambda_dssim)
+    if loss_multiplier != 1.0:                      # train.py:212-215 (0.1 on the coarser levels)
+        loss = loss * loss_multiplier
+    loss.backward()
+    with torch.no_grad():
+        update_training_stats(model, pkg["viewspace_points"], pkg["radii"], pkg["pixel_sizes"], reso_lvl,
+                              base_mask=base_mask, update_pixel_sizes=update_pixel_sizes, densify=densify)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), Ll1, pkg

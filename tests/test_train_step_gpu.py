@@ -1,0 +1,105 @@
+"""The composed GPU training iteration (render_fused -> l1_ssim_loss -> backward -> statistics -> FusedAdam) against
+the same iteration composed the reference's way (render + torch loss formulation + torch.optim.Adam + masked-index
+statistics), and a short optimisation run as the train-step harness of SURVEY §8(d)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import scenes
+from oracle import loss_oracle as lo
+from parity_utils import PIPE, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_loss(x, gt, lam):
+    w = torch.from_numpy(lo.window_2d()).to(x.device).expand(3, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t, w, padding=5, groups=3)
+    m1, m2 = conv(x), conv(gt)
+    s1, s2, s12 = conv(x * x) - m1 * m1, conv(gt * gt) - m2 * m2, conv(x * gt) - m1 * m2
+    S = ((2 * m1 * m2 + 0.01 ** 2) * (2 * s12 + 0.03 ** 2)) / ((m1 * m1 + m2 * m2 + 0.01 ** 2) * (s1 + s2 + 0.03 ** 2))
+    return (1 - lam) * (x - gt).abs().mean() + lam * (1 - S.mean())
+
+
+def _reference_style_iteration(model, opt, cam, gt, bg, lvl, st):
+    from gaussian_renderer import render
+    pkg = render(cam, model, PIPE, bg, **st)
+    loss = _torch_loss(pkg["render"], gt, 0.2)
+    loss.backward()
+    with torch.no_grad():
+        vis, radii, ps = pkg["visibility_filter"], pkg["radii"], pkg["pixel_sizes"]
+        mask = vis & (model.target_reso_lvl == lvl)
+        if lvl > 0:
+            model.max_pixel_sizes[mask] = torch.max(model.max_pixel_sizes[mask] * 0.95, ps[mask])
+        if lvl < model.reso_lvls - 1:
+            mn = torch.clip(model.min_pixel_sizes[mask] * 1.05, -1)
+            model.min_pixel_sizes[mask] = torch.where(ps[mask] > 0, torch.where(mn < 0, ps[mask], torch.min(mn, ps[mask])), mn)
+        model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis])
+        model.xyz_gradient_accum[:, lvl][vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
+        model.denom[:, lvl][vis] += 1
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    return loss.detach(), pkg
+
+
+def test_first_iteration_matches_the_reference_composition():
+    from synthetic_model import SyntheticGaussians
+    from train_epilogue import FusedAdam
+    from train_step import fused_train_iteration
+    W, H = 160, 128
+    sc, cam = small_scene(6000, W, H, 21, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.2)
+    st = dict(filter_small=True, filter_large=True, fade_size=0.0)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)).cuda()
+    bg = torch.zeros(3).cuda()
+    camd = cam.to("cuda")
+    a, b = SyntheticGaussians(sc, "cuda"), SyntheticGaussians(sc, "cuda")
+    ga = a.training_setup(7, sc.target_reso_lvl)
+    gb = b.training_setup(7, sc.target_reso_lvl)
+    oa, ob = FusedAdam(ga, lr=0.0, eps=1e-15), torch.optim.Adam(gb, lr=0.0, eps=1e-15)
+    before = {n: getattr(a, n).detach().clone() for n in a.LEAVES}
+    la, _, pa = fused_train_iteration(a, oa, camd, gt, PIPE, bg, **st)
+    lb, pb = _reference_style_iteration(b, ob, camd, gt, bg, 0, st)
+    assert abs(la.item() - lb.item()) <= 1e-5
+    assert torch.equal(pa["radii"], pb["radii"])
+    for k in ("denom", "max_radii2D"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    for k in ("max_pixel_sizes", "min_pixel_sizes"):       # pixel sizes: in-kernel expf vs torch.exp, 1 ulp apart
+        assert torch.allclose(getattr(a, k), getattr(b, k), rtol=1e-5, atol=0), k
+    ref = b.xyz_gradient_accum
+    assert (a.xyz_gradient_accum - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # first Adam step = -lr * g / (|g| + eps): +-lr wherever the gradient is not ~0.  Compare the moments (linear in
+    # the gradient) for every Gaussian, and the parameters where the gradient is well above the float-atomic noise.
+    for (n, ga_, gb_) in zip(a.LEAVES, ga, gb):
+        p, q = ga_["params"][0], gb_["params"][0]
+        ma, mb = oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]
+        assert (ma - mb).abs().max().item() <= 1e-4 * mb.abs().max().item(), n
+        sure = mb.abs() > 1e-3 * mb.abs().max()
+        assert sure.any()
+        step_a, step_b = (p - before[n])[sure], (q - before[n])[sure]
+        assert (step_a - step_b).abs().max().item() <= 1e-3 * step_b.abs().max().item(), n
+
+
+def test_short_run_reduces_the_loss():
+    """Fit a fixed target (a render of a perturbed copy of the scene) for 30 iterations."""
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    from train_epilogue import FusedAdam
+    from train_step import fused_train_iteration
+    W, H = 192, 128
+    sc, cam = small_scene(8000, W, H, 33)
+    bg = torch.zeros(3).cuda()
+    camd = cam.to("cuda")
+    with torch.no_grad():
+        target = render(camd, SyntheticGaussians(sc, "cuda", requires_grad=False), PIPE, bg)["render"].clone()
+    g = torch.Generator().manual_seed(4)
+    sc.shs = sc.shs + 0.3 * torch.randn(sc.shs.shape, generator=g)
+    sc.means3D = sc.means3D + 0.01 * torch.randn(sc.means3D.shape, generator=g)
+    model = SyntheticGaussians(sc, "cuda")
+    opt = FusedAdam(model.training_setup(1), lr=0.0, eps=1e-15)
+    losses = []
+    for it in range(30):
+        loss, l1, pkg = fused_train_iteration(model, opt, camd, target, PIPE, bg)
+        losses.append(loss.item())
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert losses[-1] < 0.6 * losses[0], losses
+    assert model.denom.sum().item() > 0 and model.max_radii2D.max().item() > 0
