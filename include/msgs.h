@@ -194,6 +194,13 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
+/* msgs_preprocess_only: the per-Gaussian stage alone (frustum cull, multi-scale filters, projection) — radii and
+ * pixel_sizes exactly as msgs_forward_stage1 writes them, without sorting, binning or blending.  For the camera
+ * sweeps of the reference that render a view only to read visibility_filter / pixel_sizes
+ * (/root/reference/train.py:283-300 before insert_large_gaussians, :334-338 after it).  No host synchronisation. */
+int msgs_preprocess_only(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int32_t* radii,
+                         float* pixel_sizes, void* geom, size_t geom_bytes, void* stream);
+
 /* ---- voxel-average pooling (large-Gaussian insertion) ------------------------------------------------------
  * GPU replacement for the eleven CPU calls of open3d.ml.torch.layers.VoxelPooling(position_fn='center',
  * feature_fn='average') in /root/reference/scene/gaussian_model.py:802-816 (third-party, un-vendored; restated

@@ -153,6 +153,19 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     return MSGS_OK;
 }
 
+int msgs_preprocess_only(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+                         void* geom_v, size_t geom_bytes, void* stream) {
+    int rc = check_inputs(view, g);
+    if (rc) return rc;
+    const int P = g->P;
+    if (P == 0) return MSGS_OK;
+    if (!radii || !pixel_sizes || !geom_v) return MSGS_ERR_INVALID_ARG;
+    if (geom_bytes < msgs_geom_bytes(P)) return MSGS_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_preprocess(make_view_params(view), *g, radii, pixel_sizes, (char*)geom_v, s));
+    return debug_sync(view, s);
+}
+
 int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes,
                         int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
                         void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,

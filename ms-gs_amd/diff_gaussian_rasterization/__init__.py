@@ -295,6 +295,32 @@ class GaussianRasterizer(nn.Module):
                                                   stream), "msgs_mark_visible")
         return out.bool()
 
+    def preprocess_only(self, means3D, opacities, scales=None, rotations=None, cov3D_precomp=None,
+                        max_pixel_sizes=None, min_pixel_sizes=None, base_mask=None):
+        """(radii, pixel_sizes) of this view exactly as forward() returns them, from the per-Gaussian kernel alone —
+        no sort / binning / blend, no colour.  For camera sweeps that only read visibility_filter and pixel_sizes
+        (/root/reference/train.py:283-300,334-338).  Same argument meaning as forward(); no gradients."""
+        rs = self.raster_settings
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        with torch.no_grad():
+            P = int(means3D.shape[0])
+            dev = means3D.device
+            call = _Call(rs, means3D, None, torch.zeros(P, 3, device=dev), opacities, scales, rotations,
+                         cov3D_precomp, max_pixel_sizes, min_pixel_sizes, None, None, base_mask)
+            radii = torch.zeros(P, dtype=torch.int32, device=dev)
+            pixel_sizes = torch.zeros(P, dtype=torch.float32, device=dev)
+            if P == 0:
+                return radii, pixel_sizes
+            lib = _C.lib
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                geom = torch.empty(int(lib.msgs_geom_bytes(P)), dtype=torch.uint8, device=dev)
+                _C.check(lib.msgs_preprocess_only(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(pixel_sizes),
+                                                  _ptr(geom), geom.numel(), stream), "msgs_preprocess_only")
+        return radii, pixel_sizes
+
     def forward_raw(self, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
                     max_pixel_sizes=None, min_pixel_sizes=None, occ_multiplier=None, dc_delta=None, base_mask=None):
         """Opt-in fused path on raw GaussianModel parameters (not part of the reference API)."""
