@@ -277,6 +277,14 @@ int msgs_loss_backward(const float* img, const float* gt, int32_t C, int32_t H, 
                        const float* upstream, const void* scratch, size_t scratch_bytes, float* dL_dimg, void* stream);
 int msgs_ssim_window(float* taps11_host);
 
+/* ---- distCUDA2 --------------------------------------------------------------------------------
+ * mean_dist2[i] = mean of the squared distances from points[i] to its 3 nearest OTHER points (exact, float32) —
+ * `distCUDA2(points)` of the un-vendored simple-knn submodule, used once at initialisation
+ * (/root/reference/scene/gaussian_model.py:26,199).  points: [P,3] device, P >= 4. */
+size_t msgs_knn_scratch_bytes(int64_t P);
+int msgs_dist2_knn3(const float* points, int64_t P, float* mean_dist2, void* scratch, size_t scratch_bytes,
+                    void* stream);
+
 /* timing helpers: create/destroy the 2*MSGS_K_COUNT events and read elapsed ms per kernel class
  * (ms_host[MSGS_K_COUNT]; a class that was not recorded reads as -1).  The caller synchronises
  * the stream before msgs_timing_read. */

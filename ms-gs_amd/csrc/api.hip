@@ -346,6 +346,17 @@ int msgs_ssim_window(float* taps11_host) {
     return MSGS_OK;
 }
 
+size_t msgs_knn_scratch_bytes(int64_t P) { return knn_scratch_bytes(P); }
+
+int msgs_dist2_knn3(const float* points, int64_t P, float* mean_dist2, void* scratch, size_t scratch_bytes,
+                    void* stream) {
+    if (P < 4 || !points || !mean_dist2 || !scratch) return MSGS_ERR_INVALID_ARG;
+    if (P > 0x7FFFFFFFll) return MSGS_ERR_TOO_MANY;
+    if (scratch_bytes < knn_scratch_bytes(P)) return MSGS_ERR_CAPACITY;
+    HIP_TRY(knn_mean_dist2(points, P, mean_dist2, (char*)scratch, (hipStream_t)stream));
+    return MSGS_OK;
+}
+
 size_t msgs_voxel_pool_scratch_bytes(int64_t M) { return voxel_pool_scratch_bytes(M); }
 
 int msgs_voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,

@@ -313,6 +313,10 @@ hipError_t launch_loss_forward(const float* img, const float* gt, int C, int H, 
 hipError_t launch_loss_backward(const float* img, const float* gt, int C, int H, int W, float lambda,
                                 const float* upstream, const char* scratch, float* dL_dimg, hipStream_t s);
 
+// knn.hip
+size_t knn_scratch_bytes(int64_t P);
+hipError_t knn_mean_dist2(const float* points, int64_t P, float* mean_dist2, char* scratch, hipStream_t s);
+
 // voxel_pool.hip
 size_t voxel_pool_scratch_bytes(int64_t M);
 hipError_t voxel_pool_build(const float* positions, int64_t M, float voxel_size, uint32_t* order, uint32_t* seg_start,

@@ -120,6 +120,10 @@ def _load():
     lib.msgs_loss_forward.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp, sz, C.c_int32, vp]
     lib.msgs_loss_backward.restype = C.c_int
     lib.msgs_loss_backward.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, vp, sz, vp, vp]
+    lib.msgs_knn_scratch_bytes.restype = sz
+    lib.msgs_knn_scratch_bytes.argtypes = [C.c_int64]
+    lib.msgs_dist2_knn3.restype = C.c_int
+    lib.msgs_dist2_knn3.argtypes = [vp, C.c_int64, vp, vp, sz, vp]
     lib.msgs_ssim_window.restype = C.c_int
     lib.msgs_ssim_window.argtypes = [C.POINTER(C.c_float)]
     for name in ("msgs_timing_create", "msgs_timing_destroy"):
@@ -142,7 +146,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_binning_stats", "msgs_timing_create", "msgs_timing_destroy", "msgs_timing_read",
            "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average", "msgs_adam_step",
            "msgs_densify_stats", "msgs_loss_scratch_bytes", "msgs_loss_forward", "msgs_loss_backward",
-           "msgs_ssim_window", "msgs_preprocess_only")
+           "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
+           "msgs_dist2_knn3")
 
 
 def check(rc, where):
