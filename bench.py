@@ -219,6 +219,28 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * (W * H / 1e6) / (elapsed / args.steps)
 
+    # N > 1, informational ("with and without the all-reduce"): the same K steps without the gradient
+    # exchange, i.e. pure view-sharded rendering fwd+bwd.  `value` above INCLUDES the all-reduce.
+    no_allreduce = None
+    if world > 1:
+        def step_local():
+            bucket.zero()
+            render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+        step_local()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_local()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tl = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        tl = float(tl.item()) / args.steps
+        no_allreduce = {"ms_per_step": round(1e3 * tl, 4), "value": round(world * (W * H / 1e6) / tl, 3),
+                        "unit": "Mpixels/s", "allreduce_bytes_per_step": 4 * sum(p_.numel() for p_ in pc.parameters())}
+
     result = {
         "metric": "Mpixels/s fwd+bwd @1080p, 1M Gaussians; fraction of HBM roofline",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
@@ -287,6 +309,8 @@ def main():
                                            "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
         result["roofline"] = roof
         result["kernel_ms"] = kernels
+        if no_allreduce is not None:
+            result["without_allreduce"] = no_allreduce
         # informational: the opt-in raw-parameter entry (render_fused: activations + SH concat inside K1/K9,
         # SURVEY §8(f) rank 1) on the same workload.  `value` above stays on the reference-API drop-in path.
         if world == 1:

@@ -55,6 +55,7 @@ __global__ void knn_bbox_init_kernel(uint32_t* bbox) {
 }
 
 __global__ __launch_bounds__(256) void knn_bbox_kernel(const float* __restrict__ p, int64_t P, uint32_t* bbox) {
+    __shared__ float s_lo[4][3], s_hi[4][3];
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
         for (int k = 0; k < 3; ++k) {
@@ -67,10 +68,13 @@ __global__ __launch_bounds__(256) void knn_bbox_kernel(const float* __restrict__
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&bbox[k], f2ord(lo[k]));
-            atomicMax(&bbox[3 + k], f2ord(hi[k]));
-        }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][k] = lo[k]; s_hi[threadIdx.x >> 6][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {                                   // 6 atomics per workgroup on 6 addresses
+        const int k = threadIdx.x;
+        atomicMin(&bbox[k], f2ord(fminf(fminf(s_lo[0][k], s_lo[1][k]), fminf(s_lo[2][k], s_lo[3][k]))));
+        atomicMax(&bbox[3 + k], f2ord(fmaxf(fmaxf(s_hi[0][k], s_hi[1][k]), fmaxf(s_hi[2][k], s_hi[3][k]))));
     }
 }
 
@@ -218,7 +222,7 @@ hipError_t knn_mean_dist2(const float* points, int64_t P, float* mean_dist2, cha
     float4 *slo = (float4*)(scratch + L.sup_lo), *shi = (float4*)(scratch + L.sup_hi);
     const unsigned g256 = (unsigned)((P + 255) / 256);
     hipLaunchKernelGGL(knn_bbox_init_kernel, dim3(1), dim3(64), 0, s, bbox);
-    hipLaunchKernelGGL(knn_bbox_kernel, dim3(g256 < 1024u ? g256 : 1024u), dim3(256), 0, s, points, P, bbox);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(g256 < 512u ? g256 : 512u), dim3(256), 0, s, points, P, bbox);
     hipLaunchKernelGGL(knn_morton_kernel, dim3(g256), dim3(256), 0, s, points, P, bbox, keys);
     hipError_t e = radix_sort_pairs(keys, nullptr, keys_s, ids, P, 0, 32, scratch + L.sort, s);
     if (e != hipSuccess) return e;
