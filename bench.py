@@ -11,8 +11,13 @@ Workload (config.workload):
           filter_small + filter_large, fade_size 0 (train.py:124-125), the seeded synthetic scene of
           scenes.config("C3"), all inputs resident in HBM before the timed region.
   N > 1 : the same 1M-Gaussian scene replicated on every GPU, ONE view per GPU per step (camera yawed
-          per rank so the views differ), followed by ONE flat fp32 all-reduce (RCCL) of the 59 floats /
+          per rank so the views differ), each followed by ONE flat fp32 all-reduce (RCCL) of the 59 floats /
           Gaussian gradient bucket -> weak scaling (per-GPU work fixed), BASELINE.json configs[3] pattern.
+          The all-reduce of view k is issued asynchronously and overlaps the rendering of view k+1 (two buckets,
+          view_parallel.PipelinedGradExchange: the gradient-accumulation pipeline of a trainer whose optimizer
+          step covers >= 2 views per GPU); all K exchanges complete inside the timed region.  The JSON line also
+          carries `exchange.serial_allreduce` (exchange serialised after every view) and
+          `exchange.without_allreduce` (no exchange at all) measured the same way.
 
 Output: ONE JSON line on rank 0 (see the driver contract in the task statement) carrying `roofline`
 (dominant blend kernel: algorithmic bytes / HIP-event time / 8 TB/s) and `cpu_baseline` (the CPU oracle
@@ -167,7 +172,7 @@ def main():
     import diff_gaussian_rasterization as dgr
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
-    from view_parallel import FlatGradBucket
+    from view_parallel import PipelinedGradExchange
     from parity_utils import PIPE
 
     W, H, P = args.width, args.height, args.gaussians
@@ -175,9 +180,11 @@ def main():
     scene = scenes.frustum_scene(P, W, H, seed=2, sh_degree=3, multiscale=True)
     cam = yawed_front_camera(scenes, W, H, rank, world).to(dev)
     pc = SyntheticGaussians(scene, dev, requires_grad=True)
-    # N > 1: parameter .grad tensors are views into ONE flat bucket that is all-reduced once per step.
+    # N > 1: parameter .grad tensors are views into a flat fp32 bucket (two buckets, used alternately): the all-reduce
+    #        of view k runs on RCCL's stream while view k+1 is rendered (PipelinedGradExchange); every exchange
+    #        completes inside the timed region (drain before the closing synchronize).
     # N = 1: nothing to reduce -> grads are left to autograd (set-to-None each step, like optimizer.zero_grad).
-    bucket = FlatGradBucket(pc.parameters()) if world > 1 else None
+    exchange = PipelinedGradExchange(pc.parameters(), world) if world > 1 else None
     bg = torch.zeros(3, device=dev)
     dL = scenes.grad_seed(W, H, 2).to(dev)
     torch.cuda.synchronize()
@@ -186,60 +193,71 @@ def main():
 
     def step(timer=None):
         dgr._C.set_timer(timer)
-        if bucket is not None:
-            bucket.zero()
+        if exchange is not None:
+            exchange.begin_view()
         else:
             for p_ in pc.parameters():
                 p_.grad = None
         out = render(cam, pc, PIPE, bg, **settings)
         out["render"].backward(dL)               # fixed dL/dimage (SURVEY §8(d) 'backward seed')
-        if bucket is not None:
-            bucket.all_reduce(average_over=world)
+        if exchange is not None:
+            exchange.end_view()
         return out
+
+    def timed_region(fn, n):
+        """barrier + synchronize on both sides, MAX over ranks (the driver's contract)"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for k in range(n):
+            fn(k)
+        if exchange is not None:
+            exchange.drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        out = step(timers[k] if timers else None)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if exchange is not None:
+        exchange.drain()
+    elapsed = timed_region(lambda k: step(timers[k] if timers else None), args.steps)
     dgr._C.set_timer(None)
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * (W * H / 1e6) / (elapsed / args.steps)
 
-    # N > 1, informational ("with and without the all-reduce"): the same K steps without the gradient
-    # exchange, i.e. pure view-sharded rendering fwd+bwd.  `value` above INCLUDES the all-reduce.
-    no_allreduce = None
+    # N > 1, informational (SURVEY 8(e): "with and without the all-reduce"): the same K steps (a) with the exchange
+    # serialised after each view (one optimizer step per view: nothing to overlap with) and (b) without any exchange,
+    # i.e. pure view-sharded rendering fwd+bwd.  `value` above INCLUDES every all-reduce (overlapped).
+    extra = None
     if world > 1:
-        def step_local():
+        bucket = exchange.buckets[0]
+
+        def step_serial(k):
             bucket.zero()
             render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
-        step_local()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_local()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        tl = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-        tl = float(tl.item()) / args.steps
-        no_allreduce = {"ms_per_step": round(1e3 * tl, 4), "value": round(world * (W * H / 1e6) / tl, 3),
-                        "unit": "Mpixels/s", "allreduce_bytes_per_step": 4 * sum(p_.numel() for p_ in pc.parameters())}
+            bucket.all_reduce(average_over=world)
+
+        def step_local(k):
+            bucket.zero()
+            render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+        step_serial(0)
+        ts = timed_region(step_serial, args.steps) / args.steps
+        step_local(0)
+        tl = timed_region(step_local, args.steps) / args.steps
+        mp = world * (W * H / 1e6)
+        extra = {"serial_allreduce": {"ms_per_step": round(1e3 * ts, 4), "value": round(mp / ts, 3)},
+                 "without_allreduce": {"ms_per_step": round(1e3 * tl, 4), "value": round(mp / tl, 3)},
+                 "unit": "Mpixels/s", "allreduce_bytes_per_step": 4 * sum(p_.numel() for p_ in pc.parameters())}
 
     result = {
         "metric": "Mpixels/s fwd+bwd @1080p, 1M Gaussians; fraction of HBM roofline",
@@ -249,7 +267,8 @@ def main():
         "config": {"workload": ("C3: 1M Gaussians, 1920x1080, SH3, multi-scale filter_small+filter_large, fade 0"
                                 if (P, W, H) == (1_000_000, 1920, 1080) else f"custom: {P} Gaussians {W}x{H}"),
                    "gaussians": P, "width": W, "height": H, "views_per_gpu_per_step": 1,
-                   "parallelism": f"view-parallel x{world}" + (", flat fp32 grad all-reduce (RCCL)" if world > 1 else "")},
+                   "parallelism": f"view-parallel x{world}" + (", flat fp32 grad all-reduce (RCCL) of view k overlapped with "
+                                                                "the rendering of view k+1 (2 buckets)" if world > 1 else "")},
     }
 
     if rank == 0:
@@ -309,8 +328,8 @@ def main():
                                            "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
         result["roofline"] = roof
         result["kernel_ms"] = kernels
-        if no_allreduce is not None:
-            result["without_allreduce"] = no_allreduce
+        if extra is not None:
+            result["exchange"] = extra
         # informational: the opt-in raw-parameter entry (render_fused: activations + SH concat inside K1/K9,
         # SURVEY §8(f) rank 1) on the same workload.  `value` above stays on the reference-API drop-in path.
         if world == 1:

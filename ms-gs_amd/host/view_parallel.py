@@ -45,6 +45,71 @@ class FlatGradBucket:
         return None
 
 
+class PipelinedGradExchange:
+    """Gradient exchange overlapped with rendering ("on a dedicated stream, overlappable"): two flat
+    buckets used alternately — while the all-reduce of view k runs on the communicator's stream, view k+1 is rendered
+    into the other bucket.  This is the gradient-accumulation pipeline of a trainer whose optimizer step covers >= 2
+    views per GPU (SURVEY's partitioning: GPU g renders views {g, g+N, ...} of the iteration's batch); with one view
+    per optimizer step use FlatGradBucket.all_reduce directly.
+
+        ex = PipelinedGradExchange(params, world)
+        for each view:  ex.begin_view(); loss.backward(); ex.end_view()
+        ex.drain()                      # every exchange finished (stream-level), buckets hold the averaged grads
+
+    xGMI is per-link bound, so the exchange of a 236 MB bucket costs about as much as a whole view at 8 GPUs; hiding
+    it behind the next view is what keeps view-parallel scaling near-linear."""
+
+    def __init__(self, params, world=None, group=None):
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = world if world is not None else (dist.get_world_size(group) if self.active else 1)
+        self.buckets = [FlatGradBucket(params), FlatGradBucket(params)]
+        self.pending = [None, None]
+        self.k = 0
+        # ncclAvg folds the 1/world into the collective; gloo (CPU tests) has no AVG -> SUM and divide after the wait
+        self.avg_op = None
+        if self.active and dist.get_backend(group) == "nccl":
+            try:
+                probe = torch.ones(1, device=self.buckets[0].flat.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+                self.avg_op = dist.ReduceOp.AVG
+            except Exception:
+                self.avg_op = None
+
+    @property
+    def current(self):
+        return self.buckets[self.k % 2]
+
+    def _finish(self, i):
+        w = self.pending[i]
+        if w is None:
+            return
+        w.wait()                                   # NCCL: the current stream waits; the host does not
+        if self.avg_op is None and self.world > 1:
+            self.buckets[i].flat.div_(self.world)
+        self.pending[i] = None
+
+    def begin_view(self):
+        i = self.k % 2
+        self._finish(i)                            # the exchange issued two views ago used this bucket
+        self.buckets[i].zero()                     # also points every p.grad at this bucket
+
+    def end_view(self):
+        i = self.k % 2
+        b = self.buckets[i]
+        if self.active:
+            op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
+            self.pending[i] = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+        elif self.world > 1:
+            b.flat.div_(self.world)
+        self.k += 1
+        return b
+
+    def drain(self):
+        for i in (0, 1):
+            self._finish(i)
+
+
 def all_reduce_densification_stats(grad_norm_sum, vis_count, max_radii, group=None):
     """Training statistics that must stay equivalent between 1 and N GPUs:
     sum of per-view ||viewspace_points.grad[:, :2]|| and visibility counts (SUM; the norm is taken per

@@ -52,6 +52,23 @@ def _worker(rank, world, port, ret):
     (params[0].sum()).backward()
     bucket.all_reduce()
     ok = ok and bucket.flat.data_ptr() == ptr and bool(torch.allclose(params[0].grad, torch.full_like(params[0], float(world))))
+    # pipelined exchange: alternate buckets, exchange of view k in flight while view k+1 accumulates
+    from view_parallel import PipelinedGradExchange
+    ex = PipelinedGradExchange(params, world)
+    seen = []
+    for k in range(5):
+        ex.begin_view()
+        assert all(p.grad.data_ptr() == w.data_ptr() for p, w in zip(params, ex.current.views))
+        (float(10 * k + rank + 1) * params[0].sum() + params[5].sum()).backward()
+        seen.append(ex.end_view())
+    ex.drain()
+    # after the drain the two buckets hold the AVERAGED gradients of the last two views (k = 3 -> bucket 1, k = 4 -> 0)
+    for k, b in ((4, ex.buckets[0]), (3, ex.buckets[1])):
+        want0 = sum(10 * k + r + 1 for r in range(world)) / world
+        ok = ok and bool(torch.allclose(b.views[0], torch.full_like(params[0], want0)))
+        ok = ok and bool(torch.allclose(b.views[5], torch.ones_like(params[5])))
+        ok = ok and bool((b.views[2] == 0).all())
+    ok = ok and seen[0] is ex.buckets[0] and seen[1] is ex.buckets[1] and seen[2] is ex.buckets[0]
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
@@ -74,3 +91,11 @@ def test_single_process_paths():
     b.all_reduce(average_over=4)
     assert torch.allclose(p[0].grad, torch.full((5, 3), 0.5))
     assert views_for_rank(8, 1, 4) == [1, 5] and sum(len(views_for_rank(8, r, 8)) for r in range(8)) == 8
+    from view_parallel import PipelinedGradExchange
+    ex = PipelinedGradExchange(p, world=2)                      # no process group: local average only
+    for k in range(3):
+        ex.begin_view()
+        (p[0] * (k + 1)).sum().backward()
+        b = ex.end_view()
+        assert torch.allclose(b.views[0], torch.full((5, 3), (k + 1) / 2.0))
+    ex.drain()
