@@ -51,6 +51,7 @@ struct GeomLayout {
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 8;
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;
+constexpr int64_t SORT_BIG_N = 2'000'000;   // from here on radix passes use 16 keys per thread (2 x SORT_CHUNK per block)
 constexpr int SORT_MAX_GROUPS = 128;   // group sums per digit (grouped radix path)
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;

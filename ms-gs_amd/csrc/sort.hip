@@ -129,13 +129,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 // ---------------------------------------------------------------------------------------------
 // Element layout inside a block's chunk: wave w owns [w*64*ITEMS, (w+1)*64*ITEMS); in round r lane l
 // handles element w*64*ITEMS + r*64 + l.  Waves, rounds and lanes are therefore all in key order.
+template <int ITEMS = SORT_ITEMS>
 __device__ __forceinline__ int64_t elem_index(int64_t chunk_base, int w, int r, int lane) {
-    return chunk_base + (int64_t)w * (64 * SORT_ITEMS) + r * 64 + lane;
+    return chunk_base + (int64_t)w * (64 * ITEMS) + r * 64 + lane;
 }
 
 // With `gsum` (grouped path) the block histograms are stored block-major (hist[block][digit]) and the
 // per-(group of `gsize` blocks, digit) sums gsum[group][digit] are accumulated with atomics: with those every
 // scatter block derives its own output bases (no scan kernels at all).
+template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
                                                                   int shift, uint32_t mask, int64_t nblocks,
                                                                   uint32_t* __restrict__ hist,
@@ -144,10 +146,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t chunk_base = (int64_t)blockIdx.x * SORT_CHUNK;
+    const int64_t chunk_base = (int64_t)blockIdx.x * (SORT_THREADS * ITEMS);
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = elem_index(chunk_base, w, r, lane);
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
         if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     }
 }
 
+template <bool STAGED, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
@@ -171,16 +174,16 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, later per-wave global bases
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t chunk_base = (int64_t)blockIdx.x * SORT_CHUNK;
+    const int64_t chunk_base = (int64_t)blockIdx.x * (SORT_THREADS * ITEMS);
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = elem_index(chunk_base, w, r, lane);
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
         const bool valid = i < n;
         key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
@@ -199,9 +202,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         if (valid && before == 0) s_cnt[w][d] = prev + (uint32_t)__popcll(peers);
     }
     __syncthreads();
-    {   // digit d = threadIdx.x: turn per-wave counts into per-wave global bases
+    uint32_t gbase;
+    {   // digit d = threadIdx.x: global base of this block's run of digit d
         const uint32_t d = threadIdx.x;
-        uint32_t base;
         if (gsum) {
             // base = (keys with a smaller digit) + (same digit in earlier groups) + (same digit in earlier blocks of
             // this group); hist_scanned holds the RAW block histograms here
@@ -218,26 +221,67 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 #pragma unroll 8
             for (int k = 0; k < nin; ++k) before += hrow[(int64_t)k * 256];
             uint32_t dummy;
-            base = block_exclusive_scan(tot, s_wave, &dummy) + before;
+            gbase = block_exclusive_scan(tot, s_wave, &dummy) + before;
         } else {
-            base = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
+            gbase = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
         }
+    }
+    if (!STAGED) {
+        uint32_t base = gbase;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t c = s_cnt[k][d];
-            s_cnt[k][d] = base;
+            const uint32_t c = s_cnt[k][threadIdx.x];
+            s_cnt[k][threadIdx.x] = base;
             base += c;
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
+            if (i < n) {
+                const uint32_t d = (key[r] >> shift) & mask;
+                const uint32_t pos = s_cnt[w][d] + rank[r];
+                keys_out[pos] = key[r];
+                vals_out[pos] = val[r];
+            }
+        }
+        return;
+    }
+    // STAGED: reorder the chunk by digit in LDS first, then write it out in local order — consecutive lanes write
+    // consecutive addresses inside each digit run (a wave store touches a few runs instead of 64 scattered words)
+    __shared__ uint32_t s_key[STAGED ? SORT_THREADS * ITEMS : 1], s_val[STAGED ? SORT_THREADS * ITEMS : 1], s_delta[256];
+    {
+        const uint32_t d = threadIdx.x;
+        uint32_t c[4], ltot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = s_cnt[k][d]; ltot += c[k]; }
+        uint32_t dummy;
+        const uint32_t lbase = block_exclusive_scan(ltot, s_wave, &dummy);   // position of digit d's run in the chunk
+        uint32_t run = lbase;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_cnt[k][d] = run; run += c[k]; }
+        s_delta[d] = gbase - lbase;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = elem_index(chunk_base, w, r, lane);
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
         if (i < n) {
-            const uint32_t d = (key[r] >> shift) & mask;
-            const uint32_t pos = s_cnt[w][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
+            const uint32_t lp = s_cnt[w][(key[r] >> shift) & mask] + rank[r];
+            s_key[lp] = key[r];
+            s_val[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const int nvalid = (int)min((int64_t)(SORT_THREADS * ITEMS), n - chunk_base);
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int j = r * SORT_THREADS + threadIdx.x;
+        if (j < nvalid) {
+            const uint32_t k = s_key[j];
+            const uint32_t pos = (uint32_t)j + s_delta[(k >> shift) & mask];
+            keys_out[pos] = k;
+            vals_out[pos] = s_val[j];
         }
     }
 }
@@ -494,13 +538,17 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     uint32_t* vals_alt = reinterpret_cast<uint32_t*>(scratch + L.vals_alt);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + L.hist);
     uint64_t* partials = reinterpret_cast<uint64_t*>(scratch + L.partials);
-    const int64_t nb = sort_blocks(n);
     int passes = (end_bit - begin_bit + 7) / 8;
     if (passes < 1) passes = 1;
     const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
     // grouped variant of the spin-free path (default): group sums live behind the block-histogram table
     static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
     const bool grouped = !onesweep && !scan_table && passes <= 4;
+    static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
+    // 16 keys per thread for big inputs (longer digit runs per block -> better write coalescing; measured on the
+    // tile sort: 94 -> 81 us at 4.1M pairs, 1.6 -> 1.2 ms at 55M); 8 below that, where 16 would leave CUs idle
+    const bool big = grouped && staged && n >= SORT_BIG_N;
+    const int64_t nb = big ? (n + 2 * SORT_CHUNK - 1) / (2 * SORT_CHUNK) : sort_blocks(n);
     // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
     int gsize = 8;
     while ((int64_t)gsize * gsize < nb) gsize += 8;
@@ -540,17 +588,28 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
         } else if (grouped) {
             // two kernels per pass: block histograms + group sums, then a scatter that derives its own bases
             uint32_t* gs = gsum_all + (size_t)p * 256 * ngroups;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist,
-                               gs, gsize, ngroups);
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k,
-                               dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups);
+            const dim3 grid((unsigned)nb), block(SORT_THREADS);
+            if (big) {
+                hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
+                hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
+                                   mask, nb, hist, gs, gsize, ngroups);
+            } else {
+                hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
+                                   ngroups);
+                if (staged)
+                    hipLaunchKernelGGL((radix_scatter_kernel<true, SORT_ITEMS>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
+                                       shift, mask, nb, hist, gs, gsize, ngroups);
+                else
+                    hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
+                                       shift, mask, nb, hist, gs, gsize, ngroups);
+            }
         } else {
-            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask, nb, hist,
-                               (uint32_t*)nullptr, 1, 1);
+            hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask,
+                               nb, hist, (uint32_t*)nullptr, 1, 1);
             hipError_t e = exclusive_scan_u32(hist, nullptr, hist, 256 * nb, partials, nullptr, s);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k,
-                               dst_v, n, shift, mask, nb, hist, (const uint32_t*)nullptr, 1, 1);
+            hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v,
+                               dst_k, dst_v, n, shift, mask, nb, hist, (const uint32_t*)nullptr, 1, 1);
         }
         src_k = dst_k;
         src_v = dst_v;
