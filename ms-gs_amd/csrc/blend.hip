@@ -521,6 +521,8 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
     const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
     const int vbase = 4 * (int)p0 + 2 * (int)p1;
+    const bool alane = lane < 5 || (lane >= 32 && lane < 36);          // lanes that issue the per-entry atomics
+    const int aoff = lane == 4 ? 8 : (lane < 4 ? vbase : vbase + 1);
 
     const int nb = ((int)tile_last + WB - 1) / WB;
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
@@ -572,11 +574,20 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             r2s += dpp_mov<0x4E>(r2s);
             r0s += dpp_mov<0x124>(r0s); r1s += dpp_mov<0x124>(r1s); r2s += dpp_mov<0x124>(r2s);
             r0s += dpp_mov<0x128>(r0s); r1s += dpp_mov<0x128>(r1s); r2s += dpp_mov<0x128>(r2s);
-            r0s = cross_row_allreduce(r0s); r1s = cross_row_allreduce(r1s); r2s = cross_row_allreduce(r2s);
-            // lanes 0..3 hold components (vbase, vbase+1) = (0,1 | 4,5 | 2,3 | 6,7); lane 4 adds #8
-            float* gdst = grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS;
-            if (lane < 4) unsafeAtomicAdd(gdst + vbase, r0s);
-            if (lane < 5) unsafeAtomicAdd(gdst + (lane == 4 ? 8 : vbase + 1), lane == 4 ? r2s : r1s);
+            // across the four rows: r0s and r1s share ONE exchange per level (v_permlane32_swap hands the upper half of
+            // its first operand to the lower half of the second: the sum of the two results is r0s over both halves in
+            // lanes 0..31 and r1s over both halves in lanes 32..63; v_permlane16_swap then folds the row pairs)
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const u2 h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0s), __float_as_uint(r1s), false, false);
+            const float hs = __uint_as_float(h.x) + __uint_as_float(h.y);
+            const u2 g = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
+            const float r01 = __uint_as_float(g.x) + __uint_as_float(g.y);
+            r2s = cross_row_allreduce(r2s);
+            // lanes 0..3: components vbase = (0 | 4 | 2 | 6) from r0s; lanes 32..35: vbase + 1 from r1s; lane 4: #8.
+            // The record id is wave-uniform: scalar address arithmetic, one atomic instruction.
+            const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+            float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+            if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r2s : r01);
         }
     }
 }
