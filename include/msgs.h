@@ -194,6 +194,18 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
+/* msgs_forward: both stages in ONE call.  Runs stage 1, synchronises once to learn the instance count D, and — when
+ * the caller's `binning` and `scratch2` buffers are large enough for D (msgs_binning_bytes(D, W, H),
+ * msgs_stage2_scratch_bytes(D, W, H)) — launches stage 2 immediately, with no allocation and no second library call
+ * inside the bubble the synchronisation opens on the GPU (*stage2_done = 1).  Buffers sized from the previous frame's
+ * D plus a margin make that the normal case.  Otherwise *stage2_done = 0 and *num_instances_host = D: grow the
+ * buffers and call msgs_forward_stage2.  The binning buffer's internal layout depends on D only, not on its capacity. */
+int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int32_t* radii, float* pixel_sizes,
+                 void* geom, size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning,
+                 size_t binning_bytes, void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes,
+                 float* out_color, float* out_acc_pixel_size, float* out_depth, int64_t* num_instances_host,
+                 int32_t* stage2_done, const msgs_timing_t* timing, void* stream);
+
 /* msgs_preprocess_only: the per-Gaussian stage alone (frustum cull, multi-scale filters, projection) — radii and
  * pixel_sizes exactly as msgs_forward_stage1 writes them, without sorting, binning or blending.  For the camera
  * sweeps of the reference that render a view only to read visibility_filter / pixel_sizes

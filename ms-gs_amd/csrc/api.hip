@@ -153,6 +153,27 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     return MSGS_OK;
 }
 
+int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes, void* geom,
+                 size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
+                 void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
+                 float* out_acc_ps, float* out_depth, int64_t* num_instances_host, int32_t* stage2_done,
+                 const msgs_timing_t* timing, void* stream) {
+    if (!stage2_done) return MSGS_ERR_INVALID_ARG;
+    *stage2_done = 0;
+    int rc = msgs_forward_stage1(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes,
+                                 num_instances_host, timing, stream);
+    if (rc) return rc;
+    const int64_t D = *num_instances_host;
+    const int W = view->image_width, H = view->image_height;
+    if (!binning || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_OK;
+    if (D > 0 && (!scratch2 || scratch2_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_OK;
+    rc = msgs_forward_stage2(view, g, geom, geom_bytes, D, binning, binning_bytes, scratch2, scratch2_bytes, image,
+                             image_bytes, out_color, out_acc_ps, out_depth, timing, stream);
+    if (rc) return rc;
+    *stage2_done = 1;
+    return MSGS_OK;
+}
+
 int msgs_preprocess_only(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
                          void* geom_v, size_t geom_bytes, void* stream) {
     int rc = check_inputs(view, g);

@@ -122,31 +122,48 @@ class _Call:
                               _ptr(self.fdc), _ptr(self.frest))
 
 
+# instance count of the previous forward per (device, P, W, H): the next call sizes its binning buffers from it, so
+# that msgs_forward can run both stages in one library call (no allocation in the bubble behind the one host sync)
+_last_instances = {}
+
+
 def _forward_impl(call):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
+    key = (dev.index, P, W, H)
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         pixel_sizes = torch.empty(P, dtype=torch.float32, device=dev)
         geom = _bytes(lib.msgs_geom_bytes(P), dev)
         scratch1 = _bytes(lib.msgs_stage1_scratch_bytes(P), dev)
-        D = C.c_int64(0)
-        _C.check(lib.msgs_forward_stage1(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(pixel_sizes),
-                                         _ptr(geom), geom.numel(), _ptr(scratch1), scratch1.numel(),
-                                         C.byref(D), _C.timer_ptr(), stream), "msgs_forward_stage1")
-        D = int(D.value)
-        del scratch1
-        binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
-        scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
         image = _bytes(lib.msgs_image_bytes(W, H), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         acc_ps = torch.empty(H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(H, W, dtype=torch.float32, device=dev)
-        _C.check(lib.msgs_forward_stage2(C.byref(call.view), C.byref(call.g), _ptr(geom), geom.numel(), D,
-                                         _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
-                                         _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
-                                         _C.timer_ptr(), stream), "msgs_forward_stage2")
+        guess = _last_instances.get(key)
+        binning = scratch2 = None
+        if guess is not None:
+            cap = guess + (guess >> 3) + 4096
+            binning = _bytes(lib.msgs_binning_bytes(cap, W, H), dev)
+            scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(cap, W, H), dev)
+        D, done = C.c_int64(0), C.c_int32(0)
+        _C.check(lib.msgs_forward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(pixel_sizes),
+                                  _ptr(geom), geom.numel(), _ptr(scratch1), scratch1.numel(),
+                                  _ptr(binning), binning.numel() if binning is not None else 0,
+                                  _ptr(scratch2), scratch2.numel() if scratch2 is not None else 0,
+                                  _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                  C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
+        D = int(D.value)
+        _last_instances[key] = D
+        del scratch1
+        if not done.value:                              # first frame of this shape, or the scene grew past the margin
+            binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
+            scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
+            _C.check(lib.msgs_forward_stage2(C.byref(call.view), C.byref(call.g), _ptr(geom), geom.numel(), D,
+                                             _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
+                                             _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                             _C.timer_ptr(), stream), "msgs_forward_stage2")
     return color, acc_ps, depth, radii, pixel_sizes, (geom, binning, image, D)
 
 

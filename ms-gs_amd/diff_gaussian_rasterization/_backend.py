@@ -91,6 +91,9 @@ def _load():
     lib.msgs_forward_stage1.restype = C.c_int
     lib.msgs_forward_stage1.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz,
                                         C.POINTER(C.c_int64), C.POINTER(Timing), vp]
+    lib.msgs_forward.restype = C.c_int
+    lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
+                                 vp, vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
     lib.msgs_preprocess_only.restype = C.c_int
     lib.msgs_preprocess_only.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp]
     lib.msgs_forward_stage2.restype = C.c_int
@@ -147,7 +150,7 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average", "msgs_adam_step",
            "msgs_densify_stats", "msgs_loss_scratch_bytes", "msgs_loss_forward", "msgs_loss_backward",
            "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
-           "msgs_dist2_knn3")
+           "msgs_dist2_knn3", "msgs_forward")
 
 
 def check(rc, where):
