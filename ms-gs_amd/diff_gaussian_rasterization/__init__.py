@@ -155,7 +155,8 @@ def _forward_impl(call):
                                   _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
-        _last_instances[key] = D
+        # views of one scene differ in D: remember a slowly decaying maximum rather than the last value
+        _last_instances[key] = max(D, int(0.97 * guess)) if guess is not None else D
         del scratch1
         if not done.value:                              # first frame of this shape, or the scene grew past the margin
             binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
