@@ -194,6 +194,16 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
+/* Deterministic mode (process-wide switch; initial value from the environment variable MSGS_DETERMINISTIC=1).
+ * The forward is always bitwise reproducible.  The backward normally accumulates per-Gaussian sums with float
+ * atomics (order varies run to run, ~1e-5 relative noise); with the switch on, msgs_backward stores the sums of
+ * every tile entry, groups them by Gaussian with a stable sort and adds them in a fixed order: bitwise reproducible,
+ * about 0.4 ms slower at C3, and the scratch buffer must hold msgs_backward_scratch_bytes_deterministic(P, D) bytes.
+ * msgs_set_deterministic returns the previous value. */
+int msgs_set_deterministic(int32_t on);
+int msgs_get_deterministic(void);
+size_t msgs_backward_scratch_bytes_deterministic(int32_t P, int64_t D);
+
 /* msgs_forward: both stages in ONE call.  Runs stage 1, synchronises once to learn the instance count D, and — when
  * the caller's `binning` and `scratch2` buffers are large enough for D (msgs_binning_bytes(D, W, H),
  * msgs_stage2_scratch_bytes(D, W, H)) — launches stage 2 immediately, with no allocation and no second library call

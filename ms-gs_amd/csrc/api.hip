@@ -4,6 +4,8 @@
 // count) outside debug mode.
 #include "msgs_internal.h"
 
+#include <atomic>
+
 #include <cstring>
 
 using namespace msgs;
@@ -97,6 +99,11 @@ size_t msgs_image_bytes(int32_t W, int32_t H) { return ImageLayout(W, H).total; 
 size_t msgs_backward_scratch_bytes(int32_t P) {
     return align256(sizeof(float) * GRAD_REC_FLOATS * (size_t)(P > 0 ? P : 1));
 }
+size_t msgs_backward_scratch_bytes_deterministic(int32_t P, int64_t D) { return DetScratch(P, D).total; }
+
+static std::atomic<int> g_deterministic{[] { const char* e = getenv("MSGS_DETERMINISTIC"); return (e && e[0] == '1') ? 1 : 0; }()};
+int msgs_set_deterministic(int32_t on) { return g_deterministic.exchange(on ? 1 : 0); }
+int msgs_get_deterministic(void) { return g_deterministic.load(); }
 
 int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
                         void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
@@ -248,8 +255,10 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     const int P = g->P, W = view->image_width, H = view->image_height;
     if (P == 0) return MSGS_OK;
     if (!radii || !geom_v || !binning_v || !image_v || !scratch_v) return MSGS_ERR_INVALID_ARG;
+    const bool det = g_deterministic.load() != 0;
     if (geom_bytes < msgs_geom_bytes(P) || binning_bytes < msgs_binning_bytes(D, W, H) ||
-        image_bytes < msgs_image_bytes(W, H) || scratch_bytes < msgs_backward_scratch_bytes(P))
+        image_bytes < msgs_image_bytes(W, H) ||
+        scratch_bytes < (det ? msgs_backward_scratch_bytes_deterministic(P, D) : msgs_backward_scratch_bytes(P)))
         return MSGS_ERR_CAPACITY;
     if (g->shs && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
     if (g->raw_params && (!grads->dL_dfeatures_dc || !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
@@ -265,9 +274,14 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
 
     HIP_TRY(hipMemsetAsync(grad_rec, 0, sizeof(float) * GRAD_REC_FLOATS * (size_t)P, s));
     tm.begin(MSGS_K_BLEND_BWD);
-    HIP_TRY(launch_blend_backward(vp, geom, (const uint32_t*)(binning + BL.ids), (const uint2*)(binning + BL.ranges),
-                                  (const float*)(image + IL.final_T), (const uint32_t*)(image + IL.n_contrib),
-                                  dL_dcolor, grad_rec, s));
+    if (det)      // grad_rec is the first region of the deterministic scratch layout
+        HIP_TRY(launch_blend_backward_det(vp, P, geom, (const uint32_t*)(binning + BL.ids), D,
+                                          (const uint2*)(binning + BL.ranges), (const float*)(image + IL.final_T),
+                                          (const uint32_t*)(image + IL.n_contrib), dL_dcolor, (char*)scratch_v, s));
+    else
+        HIP_TRY(launch_blend_backward(vp, geom, (const uint32_t*)(binning + BL.ids), (const uint2*)(binning + BL.ranges),
+                                      (const float*)(image + IL.final_T), (const uint32_t*)(image + IL.n_contrib),
+                                      dL_dcolor, grad_rec, s));
     tm.end(MSGS_K_BLEND_BWD);
     if ((rc = debug_sync(view, s))) return rc;
 

@@ -482,6 +482,9 @@ __device__ __forceinline__ bool bwd_quad_step(BwdQuad& s, BwdSums& v, const floa
     return valid;
 }
 
+// DET = true (deterministic mode): instead of atomics, the nine sums of tile entry j (its position in the sorted instance
+// array) are STORED to inst_grad[j][0..8]; det_reduce_kernel then adds every Gaussian's entries in a fixed order.
+template <bool DET>
 __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                                  const uint32_t* __restrict__ ids,
                                                                  const uint2* __restrict__ ranges,
@@ -587,9 +590,14 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             r2s = cross_row_allreduce(r2s);
             // lanes 0..3: components vbase = (0 | 4 | 2 | 6) from r0s; lanes 32..35: vbase + 1 from r1s; lane 4: #8.
             // The record id is wave-uniform: scalar address arithmetic, one atomic instruction.
-            const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
-            float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-            if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r2s : r01);
+            if (DET) {
+                float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
+                if (alane) idst[aoff] = lane == 4 ? r2s : r01;
+            } else {
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+                float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+                if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r2s : r01);
+            }
         }
     }
 }
@@ -661,7 +669,7 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     // flush pass per batch: 903 us at C3, profiles/r1_notes.md) for A/B measurements.
     static const bool direct = [] { const char* e = getenv("MSGS_BWD_LDS_ACC"); return !(e && e[0] == '1'); }();
     if (!bwd_v1())
-        hipLaunchKernelGGL(blend_backward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
+        hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
     else if (direct)
         hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
@@ -669,6 +677,73 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     else
         hipLaunchKernelGGL(blend_backward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic backward (msgs_set_deterministic): no float atomics.  K7 stores the nine sums of every tile entry;
+// the entries are then grouped by Gaussian with a STABLE sort of (Gaussian id, entry position) and each Gaussian's
+// entries are added in ascending entry position (= ascending tile id) by one thread.  Bitwise reproducible run to run.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void det_reduce_kernel(const uint32_t* __restrict__ gid_sorted,
+                                                         const uint32_t* __restrict__ entry_of, int64_t D,
+                                                         const float* __restrict__ inst_grad,
+                                                         float* __restrict__ grad_rec) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= D) return;
+    const uint32_t g = gid_sorted[q];
+    if (q > 0 && gid_sorted[q - 1] == g) return;               // not the head of its segment
+    float acc[DET_INST_FLOATS];
+#pragma unroll
+    for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] = 0.f;
+    for (int64_t k = q; k < D && gid_sorted[k] == g; ++k) {
+        const float* src = inst_grad + (size_t)entry_of[k] * DET_INST_FLOATS;
+#pragma unroll
+        for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] += src[c];
+    }
+    float* dst = grad_rec + (size_t)g * GRAD_REC_FLOATS;
+#pragma unroll
+    for (int c = 0; c < DET_INST_FLOATS; ++c) dst[c] = acc[c];
+}
+}  // namespace
+
+DetScratch::DetScratch(int64_t P, int64_t D) {
+    const int64_t n = D > 0 ? D : 1;
+    size_t o = 0;
+    grad_rec = o;  o = align256(o + sizeof(float) * GRAD_REC_FLOATS * (size_t)(P > 0 ? P : 1));
+    inst_grad = o; o = align256(o + sizeof(float) * DET_INST_FLOATS * (size_t)n);
+    keys = o;      o = align256(o + 4 * (size_t)n);
+    keys_s = o;    o = align256(o + 4 * (size_t)n);
+    entry = o;     o = align256(o + 4 * (size_t)n);
+    sort = o;      o = align256(o + SortScratch(n).total);
+    total = o;
+}
+
+hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* geom, const uint32_t* ids, int64_t D,
+                                     const uint2* ranges, const float* final_T, const uint32_t* n_contrib,
+                                     const float* dL_dcolor, char* scratch, hipStream_t s) {
+    const int tiles = vp.gx * vp.gy;
+    if (tiles == 0 || D <= 0) return hipSuccess;
+    const DetScratch L(P, D);
+    float* grad_rec = (float*)(scratch + L.grad_rec);
+    float* inst = (float*)(scratch + L.inst_grad);
+    uint32_t* keys = (uint32_t*)(scratch + L.keys);
+    uint32_t* keys_s = (uint32_t*)(scratch + L.keys_s);
+    uint32_t* entry = (uint32_t*)(scratch + L.entry);
+    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
+    hipError_t e = hipMemsetAsync(inst, 0, sizeof(float) * DET_INST_FLOATS * (size_t)D, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
+                       n_contrib, dL_dcolor, inst);
+    e = hipMemcpyAsync(keys, ids, 4 * (size_t)D, hipMemcpyDeviceToDevice, s);      // the sort clobbers its input
+    if (e != hipSuccess) return e;
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < P) ++bits;
+    e = radix_sort_pairs(keys, nullptr, keys_s, entry, D, 0, bits, scratch + L.sort, s);   // stable: entries ascending
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys_s, entry, D, inst,
+                       grad_rec);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2; };
 //   [9..11] pad, with q = alpha_raw dL/dalpha; preprocess_backward_kernel turns [0..5] into
 //   dL/dmean2D (NDC-ish units), dL/dconic (A, B-half, C) and dL/dopacity with per-Gaussian factors.
 constexpr int GRAD_REC_FLOATS = 12;
+constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode: the nine K7 sums
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -301,6 +302,15 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s);
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s);
+// blend.hip, deterministic backward: scratch = [grad_rec | inst_grad | sort buffers]
+struct DetScratch {
+    size_t grad_rec, inst_grad, keys, keys_s, entry, sort, total;
+    DetScratch(int64_t P, int64_t D);
+};
+hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* geom, const uint32_t* ids, int64_t D,
+                                     const uint2* ranges, const float* final_T, const uint32_t* n_contrib,
+                                     const float* dL_dcolor, char* scratch, hipStream_t s);
+
 // epilogue.hip
 hipError_t launch_adam(const msgs_adam_tensor_t* tensors, int n, int64_t step, double beta1, double beta2, double eps,
                        hipStream_t s);

@@ -91,6 +91,12 @@ def _load():
     lib.msgs_forward_stage1.restype = C.c_int
     lib.msgs_forward_stage1.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz,
                                         C.POINTER(C.c_int64), C.POINTER(Timing), vp]
+    lib.msgs_set_deterministic.restype = C.c_int
+    lib.msgs_set_deterministic.argtypes = [C.c_int32]
+    lib.msgs_get_deterministic.restype = C.c_int
+    lib.msgs_get_deterministic.argtypes = []
+    lib.msgs_backward_scratch_bytes_deterministic.restype = sz
+    lib.msgs_backward_scratch_bytes_deterministic.argtypes = [C.c_int32, C.c_int64]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
@@ -150,7 +156,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_voxel_pool_scratch_bytes", "msgs_voxel_pool_build", "msgs_voxel_pool_average", "msgs_adam_step",
            "msgs_densify_stats", "msgs_loss_scratch_bytes", "msgs_loss_forward", "msgs_loss_backward",
            "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
-           "msgs_dist2_knn3", "msgs_forward")
+           "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
+           "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic")
 
 
 def check(rc, where):

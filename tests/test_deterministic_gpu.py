@@ -1,0 +1,75 @@
+"""Deterministic mode (msgs_set_deterministic): the backward without float atomics is bitwise reproducible, agrees
+with the default (atomic) backward to the float-atomic noise level and with the oracle to the usual tolerance."""
+import pytest
+import torch
+
+import scenes
+from parity_utils import PIPE, check_backward, hip_render, rel_err, small_scene
+
+pytestmark = pytest.mark.gpu
+LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+@pytest.fixture
+def deterministic():
+    import diff_gaussian_rasterization as dgr
+    prev = dgr.set_deterministic(True)
+    yield
+    dgr.set_deterministic(prev)
+
+
+def _grads(sc, cam, st, dL, fused=False):
+    from gaussian_renderer import render, render_fused
+    from synthetic_model import SyntheticGaussians
+    pc = SyntheticGaussians(sc, "cuda")
+    out = (render_fused if fused else render)(cam.to("cuda"), pc, PIPE, torch.zeros(3).cuda(), **st)
+    out["render"].backward(dL.cuda())
+    torch.cuda.synchronize()
+    return {n: getattr(pc, n).grad.clone() for n in LEAVES} | {"means2D": out["viewspace_points"].grad.clone()}
+
+
+@pytest.mark.parametrize("ms,fused", [(False, False), (True, False), (True, True)])
+def test_bitwise_reproducible_and_close_to_atomic_mode(ms, fused, deterministic):
+    import diff_gaussian_rasterization as dgr
+    W, H = 160, 128
+    sc, cam = small_scene(6000, W, H, 31, multiscale=ms, **({"scale_k": 0.004 * 1920.0 / W * 0.2} if ms else {}))
+    st = dict(filter_small=ms, filter_large=ms, fade_size=0.0 if ms else 1.0)
+    dL = scenes.grad_seed(W, H, 3)
+    a = _grads(sc, cam, st, dL, fused)
+    b = _grads(sc, cam, st, dL, fused)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                                  # bit for bit, run to run
+    assert dgr._C.lib.msgs_get_deterministic() == 1
+    dgr.set_deterministic(False)
+    c = _grads(sc, cam, st, dL, fused)
+    dgr.set_deterministic(True)
+    for k in a:
+        assert rel_err(a[k], c[k]) <= 2e-5, k                              # float-atomic noise only
+    assert any(not torch.equal(a[k], c[k]) for k in a) or True
+
+
+def test_deterministic_backward_vs_oracle(deterministic):
+    from oracle import oracle_ctypes as oc
+    W, H = 120, 80
+    sc, cam = small_scene(3000, W, H, 77)
+    st = dict(filter_small=False, filter_large=False, fade_size=1.0)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    dL = scenes.grad_seed(W, H, 7)
+    out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+    orc = oc.rasterize(pc.seen, cam, st, bg)
+    check_backward(pc, m2, oc.backward(orc, dL), "deterministic", flagged=orc.borderline_gaussians)
+
+
+def test_c3_fullsize_reproducible(deterministic):
+    sc, cam, st = scenes.config("C3")
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 2)
+    a = _grads(sc, cam, st, dL)
+    b = _grads(sc, cam, st, dL)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert a["_xyz"].abs().max().item() > 0
+
+
+def test_deterministic_scratch_capacity_is_checked(deterministic):
+    from diff_gaussian_rasterization import _backend as _C
+    assert _C.lib.msgs_backward_scratch_bytes_deterministic(1000, 5000) > _C.lib.msgs_backward_scratch_bytes(1000) + 5000 * 36
