@@ -204,6 +204,11 @@ int msgs_set_deterministic(int32_t on);
 int msgs_get_deterministic(void);
 size_t msgs_backward_scratch_bytes_deterministic(int32_t P, int64_t D);
 
+/* Which of the two blend-backward kernels msgs_backward launches: 0 (default) = by tile count (one wave per tile from
+ * 4096 tiles up, four waves per tile below), 1 | 2 = force one — for the parity tests and A/B measurements.  Initial
+ * value from MSGS_BWD_GEN.  Returns the previous value. */
+int msgs_set_backward_generation(int32_t gen);
+
 /* msgs_forward: both stages in ONE call.  Runs stage 1, synchronises once to learn the instance count D, and — when
  * the caller's `binning` and `scratch2` buffers are large enough for D (msgs_binning_bytes(D, W, H),
  * msgs_stage2_scratch_bytes(D, W, H)) — launches stage 2 immediately, with no allocation and no second library call

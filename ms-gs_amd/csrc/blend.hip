@@ -31,6 +31,8 @@
 // K7 = 48*D_trav + 20*N + 36*V.
 #include "msgs_internal.h"
 
+#include <atomic>
+
 #include <algorithm>
 
 namespace msgs {
@@ -652,8 +654,10 @@ static int env_gen(const char* name, int dflt) {
 // >= ~4000 tiles to occupy 1024 SIMDs, below that four waves per tile (gen 1) win (C3 scene, profiles/r1_notes.md:
 // 8160 tiles 437 vs 667 us; 2040 tiles 334 vs 297; 510 tiles 481 vs 205; 135 tiles 834 vs 303; 2 tiles 1378 vs 431)
 constexpr int BWD_GEN2_MIN_TILES = 4096;
+static std::atomic<int> g_bwd_gen{[] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
+int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen == 2 ? gen : 0); }
 static bool bwd_v1(int tiles) {
-    static const int forced = [] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+    const int forced = g_bwd_gen.load();
     return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
 }
 

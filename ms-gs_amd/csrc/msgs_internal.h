@@ -302,6 +302,7 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s);
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s);
+int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value
 // blend.hip, deterministic backward: scratch = [grad_rec | inst_grad | sort buffers]
 struct DetScratch {
     size_t grad_rec, inst_grad, keys, keys_s, entry, sort, total;

@@ -97,6 +97,8 @@ def _load():
     lib.msgs_get_deterministic.argtypes = []
     lib.msgs_backward_scratch_bytes_deterministic.restype = sz
     lib.msgs_backward_scratch_bytes_deterministic.argtypes = [C.c_int32, C.c_int64]
+    lib.msgs_set_backward_generation.restype = C.c_int
+    lib.msgs_set_backward_generation.argtypes = [C.c_int32]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
@@ -157,7 +159,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_densify_stats", "msgs_loss_scratch_bytes", "msgs_loss_forward", "msgs_loss_backward",
            "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
-           "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic")
+           "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
+           "msgs_set_backward_generation")
 
 
 def check(rc, where):

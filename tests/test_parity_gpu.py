@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 ST0 = dict(filter_small=False, filter_large=False, fade_size=1.0)
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["bwd-4waves-per-tile", "bwd-1wave-per-tile"])
+def backward_generation(request):
+    """Both blend-backward kernels against the oracle at every size (by default the library picks by tile count, which
+    would leave the one-wave-per-tile kernel to the full-size tests only)."""
+    import diff_gaussian_rasterization as dgr
+    prev = dgr._C.lib.msgs_set_backward_generation(request.param)
+    yield request.param
+    dgr._C.lib.msgs_set_backward_generation(prev)
+
+
 def _oracle(scene, cam, st, bg, dL=None, **kw):
     from oracle import oracle_ctypes as oc
     r = oc.rasterize(scene, cam, st, bg, **kw)
