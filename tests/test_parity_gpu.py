@@ -236,3 +236,28 @@ def test_determinism_of_forward():
     b, _, _ = hip_render(sc, cam, ST0, bg)
     for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_forward_capacity_guess_paths_give_identical_results():
+    """msgs_forward with buffers sized from a previous frame: too small a guess must fall back to the exact two-call
+    path, a generous one must take the one-call path, both bit-identical to a first call without history."""
+    import diff_gaussian_rasterization as dgr
+    W, H = 144, 96
+    sc, cam = small_scene(4000, W, H, 23)
+    bg = torch.tensor([0.0, 0.1, 0.2])
+    dL = scenes.grad_seed(W, H, 23)
+
+    def run(seed_guess):
+        dgr._last_instances.clear()
+        if seed_guess is not None:
+            dgr._last_instances[(torch.cuda.current_device(), 4000, W, H)] = seed_guess
+        out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
+        return out, pc, m2, dgr._last_instances[(torch.cuda.current_device(), 4000, W, H)]
+    ref, pref, mref, D = run(None)
+    assert D > 0
+    for guess in (1, max(D // 2, 1), D, 10 * D):
+        out, pc, m2, D2 = run(guess)
+        assert D2 >= D
+        for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
+            assert torch.equal(out[k], ref[k]), (k, guess)
+        assert rel_err(pc._xyz.grad, pref._xyz.grad) <= 1e-4 and rel_err(m2, mref) <= 1e-4
