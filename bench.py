@@ -267,6 +267,9 @@ def main():
         "config": {"workload": ("C3: 1M Gaussians, 1920x1080, SH3, multi-scale filter_small+filter_large, fade 0"
                                 if (P, W, H) == (1_000_000, 1920, 1080) else f"custom: {P} Gaussians {W}x{H}"),
                    "gaussians": P, "width": W, "height": H, "views_per_gpu_per_step": 1,
+                   "api": "reference API: gaussian_renderer.render() -> GaussianRasterizer.forward(13 kwargs); the op "
+                          "recognises the reference's getters in the autograd graph and chains their backward inside "
+                          "msgs_backward (chain_reference_getters=" + str(bool(dgr.chain_reference_getters)) + ")",
                    "parallelism": f"view-parallel x{world}" + (", flat fp32 grad all-reduce (RCCL) of view k overlapped with "
                                                                 "the rendering of view k+1 (2 buckets)" if world > 1 else "")},
     }

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 2
+#define MSGS_ABI_VERSION 3
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -82,7 +82,15 @@ typedef struct msgs_gaussians {
                                     * (shs / colors_precomp / cov3D_precomp must be NULL, sh_coeffs = 16); the
                                     * activations of scene/gaussian_model.py:39-47,127-153 (exp, sigmoid, normalize)
                                     * and the torch.cat of :144-149 are evaluated inside the kernels and msgs_backward
-                                    * returns gradients w.r.t. the raw parameters */
+                                    * returns gradients w.r.t. the raw parameters.
+                                    * 2: CHAINED gradients: opacities / scales / rotations are the ACTIVATED values
+                                    * exactly as in mode 0 (the forward is bit-identical to mode 0), the SH
+                                    * coefficients are read from features_dc + features_rest (whose concatenation the
+                                    * reference passes as `shs`), rotations_raw holds the un-normalised quaternions, and
+                                    * msgs_backward applies the chain rule of sigmoid / exp / normalize / cat itself:
+                                    * dL_dopacities, dL_dscales, dL_drotations, dL_dfeatures_dc/_rest are gradients
+                                    * w.r.t. the RAW parameters — what autograd would produce by running the backward
+                                    * of the reference's getters after the op */
     const float* means3D;          /* [P,3]                                                          */
     const float* shs;              /* [P,K,3]  xor colors_precomp                                    */
     const float* colors_precomp;   /* [P,3]                                                          */
@@ -95,8 +103,9 @@ typedef struct msgs_gaussians {
     const float* occ_multiplier;   /* [P,4]    accepted; identity semantics (DESIGN.md SPEC M5)      */
     const float* dc_delta;         /* [P,12]   accepted; identity semantics (DESIGN.md SPEC M5)      */
     const uint8_t* base_mask;      /* [P]      bool                                                  */
-    const float* features_dc;      /* [P,1,3]  raw mode only (gaussian_model.py:55)                          */
-    const float* features_rest;    /* [P,15,3] raw mode only (gaussian_model.py:56)                          */
+    const float* features_dc;      /* [P,1,3]  modes 1, 2    (gaussian_model.py:55)                          */
+    const float* features_rest;    /* [P,15,3] modes 1, 2    (gaussian_model.py:56)                          */
+    const float* rotations_raw;    /* [P,4]    mode 2 only: the un-normalised quaternions (gaussian_model.py:58)  */
 } msgs_gaussians_t;
 
 /* Gradient outputs of msgs_backward.  Every non-NULL buffer is fully written (zeros for

@@ -24,8 +24,10 @@ inline int check_inputs(const msgs_view_t* v, const msgs_gaussians_t* g) {
     if (g->P < 0 || v->image_width <= 0 || v->image_height <= 0) return MSGS_ERR_INVALID_ARG;
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) return MSGS_ERR_INVALID_ARG;
     if (g->P > 0 && (!g->means3D || !g->opacities)) return MSGS_ERR_INVALID_ARG;
-    if (g->raw_params) {      // raw GaussianModel parameters: dc + rest SH, log-scales + raw quaternions, nothing precomputed
+    if (g->raw_params) {      // 1: raw GaussianModel parameters; 2: activated inputs + chained gradients (msgs.h)
+        if (g->raw_params != 1 && g->raw_params != 2) return MSGS_ERR_INVALID_ARG;
         if (!g->features_dc || !g->features_rest || !g->scales || !g->rotations) return MSGS_ERR_INVALID_ARG;
+        if (g->raw_params == 2 && !g->rotations_raw) return MSGS_ERR_INVALID_ARG;
         if (g->shs || g->colors_precomp || g->cov3D_precomp) return MSGS_ERR_INVALID_ARG;
         if (v->sh_degree < 0 || v->sh_degree > 3 || v->sh_coeffs != 16) return MSGS_ERR_SH_DEGREE;
         if ((v->image_width + TILE - 1) / TILE > 65535 || (v->image_height + TILE - 1) / TILE > 65535)

@@ -221,17 +221,21 @@ constexpr int REST_F = 45;         // floats per features_rest row (15 coefficie
 
 __device__ __forceinline__ float act_opacity(const msgs_gaussians_t& g, int i) {
     const float x = g.opacities[i];
-    return g.raw_params ? 1.0f / (1.0f + expf(-x)) : x;               // torch.sigmoid
+    return g.raw_params == 1 ? 1.0f / (1.0f + expf(-x)) : x;          // torch.sigmoid
 }
 __device__ __forceinline__ void act_scales(const msgs_gaussians_t& g, int i, float* s) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const float x = g.scales[3 * i + k]; s[k] = g.raw_params ? expf(x) : x; }   // torch.exp
+    for (int k = 0; k < 3; ++k) { const float x = g.scales[3 * i + k]; s[k] = g.raw_params == 1 ? expf(x) : x; }   // torch.exp
 }
 // q = raw / max(||raw||, 1e-12) (torch.nn.functional.normalize); returns the norm used
 __device__ __forceinline__ float act_rotation(const msgs_gaussians_t& g, int i, float* q) {
     const float4 q4 = reinterpret_cast<const float4*>(g.rotations)[i];
     q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
-    if (!g.raw_params) return 1.0f;
+    if (g.raw_params == 0) return 1.0f;
+    if (g.raw_params == 2) {         // chained mode: q is already normalised; the norm comes from the raw quaternion
+        const float4 r4 = reinterpret_cast<const float4*>(g.rotations_raw)[i];
+        return fmaxf(sqrtf(r4.x * r4.x + r4.y * r4.y + r4.z * r4.z + r4.w * r4.w), 1e-12f);
+    }
     const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = q[k] / n;

@@ -17,6 +17,7 @@ device memory (caching allocator), streams and autograd plumbing.  There is NO f
 this package without lib/libmsgs_hip.so raises ImportError, and calling it with CPU tensors raises.
 """
 import ctypes as C
+import os
 from typing import NamedTuple
 
 import torch
@@ -70,7 +71,8 @@ class _Call:
     """Marshals one (settings, tensors) pair into the C structs; keeps the tensors alive."""
 
     def __init__(self, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                 max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raw_features=None):
+                 max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raw_features=None,
+                 rotations_raw=None):
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("diff_gaussian_rasterization (MI355X build): tensors must live on a HIP device "
@@ -116,10 +118,14 @@ class _Call:
                             float(rs.fade_size), int(rs.sh_degree), self.K,
                             int(bool(rs.filter_small)), int(bool(rs.filter_large)), int(bool(rs.prefiltered)),
                             int(bool(rs.debug)), _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
-        self.g = _C.Gaussians(P, 1 if raw_features is not None else 0, _ptr(self.means3D), _ptr(self.sh),
+        # mode 1: raw parameters everywhere; mode 2: activated inputs + raw quaternions, gradients chained to the raw
+        # parameters inside msgs_backward (include/msgs.h, msgs_gaussians_t::raw_params)
+        self.rot_raw = _f32c(rotations_raw) if rotations_raw is not None else None
+        mode = 0 if raw_features is None else (2 if rotations_raw is not None else 1)
+        self.g = _C.Gaussians(P, mode, _ptr(self.means3D), _ptr(self.sh),
                               _ptr(self.colors), _ptr(self.opac), _ptr(self.scales), _ptr(self.rot), _ptr(self.cov),
                               _ptr(self.maxps), _ptr(self.minps), _ptr(self.occ), _ptr(self.dcd), _ptr(self.base),
-                              _ptr(self.fdc), _ptr(self.frest))
+                              _ptr(self.fdc), _ptr(self.frest), _ptr(self.rot_raw))
 
 
 def _backward_scratch(P, D, dev):
@@ -290,6 +296,87 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 g_scal, g_rot, None, None, None, None, None, None)
 
 
+class _RasterizeGaussiansChained(torch.autograd.Function):
+    """The reference-API call whose inputs are recognised as the reference's own getters applied to leaf parameters
+    (see _match_reference_getters).  Forward: exactly the reference-API forward on the activated tensors (bit-identical
+    outputs).  Backward: msgs_backward applies the chain rule of sigmoid / exp / normalize / cat itself and the gradients
+    go straight to the leaf parameters, instead of autograd running the getters' backward kernels afterwards (at 1 M
+    Gaussians: two strided 190 MB copies for the cat and ~15 small kernels)."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                opacities, scales, rotations, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask,
+                raster_settings):
+        call = _Call(raster_settings, xyz, None, None, opacities, scales, rotations, None,
+                     _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
+                     _opt(base_mask), raw_features=(features_dc, features_rest), rotations_raw=rotation_raw)
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
+        ctx.call, ctx.state, ctx.radii = call, state, radii
+        ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
+        ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
+        return color, acc_ps, depth, radii, pixel_sizes
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
+        return _RasterizeGaussiansRaw.backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii,
+                                               grad_pixel_sizes)[:7] + (None,) * 9
+
+
+# Recognition of the reference's getters (scene/gaussian_model.py:127-153) in the autograd graph of the arguments of
+# GaussianRasterizer.forward.  Module-level switch; MSGS_NO_GETTER_CHAIN=1 in the environment turns it off.
+chain_reference_getters = os.environ.get("MSGS_NO_GETTER_CHAIN", "0") != "1"
+
+
+def _leaf(fn):
+    return fn.variable if fn is not None and type(fn).__name__ == "AccumulateGrad" else None
+
+
+def _match_reference_getters(means3D, sh, opacities, scales, rotations):
+    """(features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw) when the four tensors are, provably from
+    their grad_fn chains,  cat((dc, rest), dim=1), sigmoid(leaf), exp(leaf) and F.normalize(leaf)  of float32 CUDA leaf
+    tensors with the reference's shapes; None otherwise (then autograd handles everything as usual)."""
+    try:
+        P = means3D.shape[0]
+        f = sh.grad_fn
+        if type(f).__name__ != "CatBackward0" or f._saved_dim != 1 or len(f.next_functions) != 2:
+            return None
+        dc, rest = _leaf(f.next_functions[0][0]), _leaf(f.next_functions[1][0])
+        f = opacities.grad_fn
+        if type(f).__name__ != "SigmoidBackward0":
+            return None
+        op = _leaf(f.next_functions[0][0])
+        f = scales.grad_fn
+        if type(f).__name__ != "ExpBackward0":
+            return None
+        sc = _leaf(f.next_functions[0][0])
+        # F.normalize: x / x.norm(2, 1, keepdim=True).clamp_min(1e-12).expand_as(x)
+        f = rotations.grad_fn
+        if type(f).__name__ != "DivBackward0":
+            return None
+        rot = _leaf(f.next_functions[0][0])
+        e = f.next_functions[1][0]
+        if type(e).__name__ != "ExpandBackward0":
+            return None
+        c = e.next_functions[0][0]
+        if type(c).__name__ != "ClampMinBackward0" or float(c._saved_min) != 1e-12:
+            return None
+        n = c.next_functions[0][0]
+        if type(n).__name__ != "LinalgVectorNormBackward0" or float(n._saved_ord) != 2.0 or \
+                tuple(n._saved_dim) != (1,) or not n._saved_keepdim or _leaf(n.next_functions[0][0]) is not rot:
+            return None
+        leaves = (dc, rest, op, sc, rot)
+        want = ((P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4))
+        for t, shape in zip(leaves, want):
+            if t is None or tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() \
+                    or t.device != means3D.device or not t.requires_grad:
+                return None
+        if tuple(sh.shape) != (P, 16, 3) or tuple(opacities.shape) != (P, 1):
+            return None
+        return leaves
+    except (AttributeError, IndexError, TypeError):
+        return None
+
+
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
                             max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
@@ -371,6 +458,14 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         empty = torch.Tensor([])
+        if chain_reference_getters and torch.is_grad_enabled() and shs is not None and cov3D_precomp is None \
+                and means3D.shape[0] > 0 and means3D.device.type == "cuda":
+            leaves = _match_reference_getters(means3D, shs, opacities, scales, rotations)
+            if leaves is not None:
+                o = lambda t: t if t is not None else empty
+                return _RasterizeGaussiansChained.apply(
+                    means3D, means2D, *leaves, opacities.detach(), scales.detach(), rotations.detach(),
+                    o(max_pixel_sizes), o(min_pixel_sizes), o(occ_multiplier), o(dc_delta), o(base_mask), rs)
         return rasterize_gaussians(
             means3D, means2D,
             shs if shs is not None else empty,

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -38,7 +38,8 @@ class Gaussians(C.Structure):
                 ("cov3D_precomp", C.c_void_p), ("max_pixel_sizes", C.c_void_p),
                 ("min_pixel_sizes", C.c_void_p), ("occ_multiplier", C.c_void_p),
                 ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p),
-                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p)]
+                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p),
+                ("rotations_raw", C.c_void_p)]
 
 
 class Grads(C.Structure):

@@ -33,7 +33,8 @@ class Gaussians(C.Structure):
                 ("cov3D_precomp", C.c_void_p), ("max_pixel_sizes", C.c_void_p),
                 ("min_pixel_sizes", C.c_void_p), ("occ_multiplier", C.c_void_p),
                 ("dc_delta", C.c_void_p), ("base_mask", C.c_void_p),
-                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p)]
+                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p),
+                ("rotations_raw", C.c_void_p)]
 
 
 class Grads(C.Structure):
@@ -164,7 +165,7 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
              0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
     g = Gaussians(P, 0, _ptr(t["means3D"]), _ptr(t["shs"]), _ptr(t["col"]), _ptr(t["opac"]),
                   _ptr(t["scales"]), _ptr(t["rot"]), _ptr(t["cov"]), _ptr(t["maxps"]), _ptr(t["minps"]),
-                  _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]), None, None)
+                  _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]), None, None, None)
     r.color = torch.zeros(3, H, W)
     r.acc_pixel_size = torch.zeros(H, W)
     r.depth = torch.zeros(H, W)

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/msgs.h but not exported"
     assert set(dgr._C.EXPORTS) == set(names)
-    assert lib.msgs_abi_version() == 2
+    assert lib.msgs_abi_version() == 3
     assert b"exactly one" in lib.msgs_error_string(-1)
 
 
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     import diff_gaussian_rasterization as dgr
     from oracle import oracle_ctypes as oc
     assert C.sizeof(dgr._C.View) == 12 * 4 + 4 * 8 == C.sizeof(oc.View)
-    assert C.sizeof(dgr._C.Gaussians) == 8 + 14 * 8 == C.sizeof(oc.Gaussians)
+    assert C.sizeof(dgr._C.Gaussians) == 8 + 15 * 8 == C.sizeof(oc.Gaussians)
     assert C.sizeof(dgr._C.Grads) == 10 * 8 == C.sizeof(oc.Grads)
     assert dgr._C.View.bg.offset == 48 and dgr._C.Gaussians.means3D.offset == 8
     assert [f[0] for f in dgr._C.View._fields_] == [f[0] for f in oc.View._fields_]
@@ -112,3 +112,27 @@ def test_render_mirror_signature_and_keys():
     assert sig.parameters["fade_size"].default == 1.0 and sig.parameters["filter_small"].default is False
     assert gaussian_renderer.RESULT_KEYS == ("render", "acc_pixel_size", "depth", "viewspace_points",
                                              "visibility_filter", "radii", "pixel_sizes")
+
+
+def test_reference_getter_recognition_on_cpu_graphs():
+    """_match_reference_getters only accepts the exact autograd patterns of the reference's getters."""
+    import torch.nn.functional as F
+    import diff_gaussian_rasterization as dgr
+    P = 10
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s))
+    xyz, dc, rest, op, sc, rot = mk(P, 3), mk(P, 1, 3), mk(P, 15, 3), mk(P, 1), mk(P, 3), mk(P, 4)
+    cat = lambda: torch.cat((dc, rest), dim=1)
+    m = dgr._match_reference_getters(xyz, cat(), torch.sigmoid(op), torch.exp(sc), F.normalize(rot))
+    assert m is not None and all(x is y for x, y in zip(m, (dc, rest, op, sc, rot)))
+    M = dgr._match_reference_getters
+    assert M(xyz, cat(), torch.sigmoid(op), torch.exp(sc) * 1.0, F.normalize(rot)) is None          # not a bare exp
+    assert M(xyz, cat().clone(), torch.sigmoid(op), torch.exp(sc), F.normalize(rot)) is None          # not a bare cat
+    assert M(xyz, torch.cat((rest[:, :1], rest), dim=1), torch.sigmoid(op), torch.exp(sc), F.normalize(rot)) is None
+    assert M(xyz, cat(), torch.sigmoid(op.detach()), torch.exp(sc), F.normalize(rot)) is None         # no graph
+    assert M(xyz, cat(), torch.sigmoid(op), torch.exp(sc), F.normalize(rot, eps=1e-6)) is None        # other eps
+    assert M(xyz, cat(), torch.sigmoid(op), torch.exp(sc), F.normalize(rot, dim=0)) is None
+    assert M(xyz, cat(), torch.tanh(op), torch.exp(sc), F.normalize(rot)) is None
+    half = torch.nn.Parameter(torch.randn(P, 3).double())
+    assert M(xyz, cat(), torch.sigmoid(op), torch.exp(half), F.normalize(rot)) is None                # dtype
+    with torch.no_grad():
+        assert M(xyz, cat(), torch.sigmoid(op), torch.exp(sc), F.normalize(rot)) is None

@@ -1,0 +1,88 @@
+"""Recognition of the reference's getters (GaussianRasterizer.forward -> _RasterizeGaussiansChained): same forward bit
+for bit, gradients of the leaf parameters equal to what autograd produces through the getters' own backward."""
+import pytest
+import torch
+
+import scenes
+from parity_utils import PIPE, rel_err, small_scene
+
+pytestmark = pytest.mark.gpu
+LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+HIP_VS_HIP_RTOL = 3e-4          # two runs with float atomics (tests/test_fused_gpu.py)
+
+
+def _run(sc, cam, st, bg, dL, chain, pipe=PIPE):
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    prev = dgr.chain_reference_getters
+    dgr.chain_reference_getters = chain
+    try:
+        pc = SyntheticGaussians(sc, "cuda")
+        out = render(cam.to("cuda"), pc, pipe, bg.cuda(), **st)
+        used = type(out["render"].grad_fn).__name__
+        out["render"].backward(dL.cuda())
+        torch.cuda.synchronize()
+    finally:
+        dgr.chain_reference_getters = prev
+    return out, pc, used
+
+
+@pytest.mark.parametrize("P,W,H,seed,deg,ms", [(500, 64, 48, 1, 3, False), (6000, 160, 128, 2, 3, True),
+                                                 (4000, 130, 70, 3, 1, False), (3000, 96, 96, 4, 0, True)])
+def test_chained_equals_autograd_through_the_getters(P, W, H, seed, deg, ms):
+    sc, cam = small_scene(P, W, H, 300 + seed, sh_degree=deg, multiscale=ms,
+                          **({"scale_k": 0.004 * 1920.0 / W * 0.2} if ms else {}))
+    sc.rotations = sc.rotations * (0.5 + torch.rand(P, 1, generator=torch.Generator().manual_seed(seed)))   # un-normalised
+    st = dict(filter_small=ms, filter_large=ms, fade_size=0.0 if ms else 1.0)
+    bg = torch.tensor([0.2, 0.1, 0.6])
+    dL = scenes.grad_seed(W, H, seed)
+    a, pa, ua = _run(sc, cam, st, bg, dL, chain=False)
+    b, pb, ub = _run(sc, cam, st, bg, dL, chain=True)
+    assert ua == "_RasterizeGaussiansBackward" and ub == "_RasterizeGaussiansChainedBackward"
+    for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
+        assert torch.equal(a[k], b[k]), k                     # the forward is the same kernel on the same inputs
+    for n in LEAVES:
+        ga, gb = getattr(pa, n).grad, getattr(pb, n).grad
+        assert gb.shape == ga.shape and gb.is_contiguous()
+        assert rel_err(gb, ga) <= HIP_VS_HIP_RTOL, n
+    assert rel_err(b["viewspace_points"].grad, a["viewspace_points"].grad) <= HIP_VS_HIP_RTOL
+
+
+def test_patterns_that_must_not_be_chained_take_the_plain_path():
+    import types
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    sc, cam = small_scene(300, 48, 40, 9)
+    bg = torch.zeros(3).cuda()
+    camd = cam.to("cuda")
+    pc = SyntheticGaussians(sc, "cuda")
+    for pipe in (types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False),
+                 types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=True, debug=False)):
+        assert type(render(camd, pc, pipe, bg)["render"].grad_fn).__name__ == "_RasterizeGaussiansBackward"
+    out = render(camd, pc, PIPE, bg, override_color=torch.rand(300, 3).cuda())
+    assert type(out["render"].grad_fn).__name__ == "_RasterizeGaussiansBackward"
+    with torch.no_grad():
+        assert render(camd, pc, PIPE, bg)["render"].grad_fn is None
+    # a getter that is not the reference's (scaled exp): plain path, and its own backward still runs
+    class Scaled(SyntheticGaussians):
+        @property
+        def get_scaling(self):
+            return torch.exp(self._scaling) * 1.0
+    pc2 = Scaled(sc, "cuda")
+    out = render(camd, pc2, PIPE, bg)
+    assert type(out["render"].grad_fn).__name__ == "_RasterizeGaussiansBackward"
+    out["render"].sum().backward()
+    assert pc2._scaling.grad is not None
+
+
+def test_c3_fullsize_chained_vs_plain():
+    sc, cam, st = scenes.config("C3")
+    bg = torch.zeros(3)
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 2)
+    a, pa, _ = _run(sc, cam, st, bg, dL, chain=False)
+    b, pb, ub = _run(sc, cam, st, bg, dL, chain=True)
+    assert ub == "_RasterizeGaussiansChainedBackward"
+    assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+    for n in LEAVES:
+        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= 1e-3, n      # float-atomic noise floor at this size

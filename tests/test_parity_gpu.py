@@ -13,14 +13,20 @@ pytestmark = pytest.mark.gpu
 ST0 = dict(filter_small=False, filter_large=False, fade_size=1.0)
 
 
-@pytest.fixture(autouse=True, params=[1, 2], ids=["bwd-4waves-per-tile", "bwd-1wave-per-tile"])
-def backward_generation(request):
-    """Both blend-backward kernels against the oracle at every size (by default the library picks by tile count, which
-    would leave the one-wave-per-tile kernel to the full-size tests only)."""
+@pytest.fixture(autouse=True, params=[(1, True), (2, True), (1, False), (2, False)],
+                ids=["bwd4-chained", "bwd1-chained", "bwd4-plain", "bwd1-plain"])
+def backward_variants(request):
+    """Every test runs with both blend-backward kernels (by default the library picks by tile count, which would leave
+    the one-wave-per-tile kernel to the full-size tests only) and with the recognition of the reference's getters on
+    (gradients chained to the leaf parameters inside msgs_backward) and off (autograd runs the getters' backward)."""
     import diff_gaussian_rasterization as dgr
-    prev = dgr._C.lib.msgs_set_backward_generation(request.param)
+    gen, chain = request.param
+    prev_gen = dgr._C.lib.msgs_set_backward_generation(gen)
+    prev_chain = dgr.chain_reference_getters
+    dgr.chain_reference_getters = chain
     yield request.param
-    dgr._C.lib.msgs_set_backward_generation(prev)
+    dgr._C.lib.msgs_set_backward_generation(prev_gen)
+    dgr.chain_reference_getters = prev_chain
 
 
 def _oracle(scene, cam, st, bg, dL=None, **kw):
@@ -33,7 +39,7 @@ def _oracle(scene, cam, st, bg, dL=None, **kw):
 def test_library_is_the_hip_one():
     import diff_gaussian_rasterization as dgr
     assert dgr._C._LIB_PATH.endswith("libmsgs_hip.so")
-    assert dgr._C.lib.msgs_abi_version() == 2
+    assert dgr._C.lib.msgs_abi_version() == 3
 
 
 @pytest.mark.parametrize("P,W,H,seed,deg,bgv", [
