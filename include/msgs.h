@@ -86,7 +86,8 @@ typedef struct msgs_gaussians {
                                     * 2: CHAINED gradients: opacities / scales / rotations are the ACTIVATED values
                                     * exactly as in mode 0 (the forward is bit-identical to mode 0), the SH
                                     * coefficients are read from features_dc + features_rest (whose concatenation the
-                                    * reference passes as `shs`), rotations_raw holds the un-normalised quaternions, and
+                                    * reference passes as `shs`; `shs` may be given as well and is then the one read:
+                                    * aligned rows, only the visible ones), rotations_raw holds the raw quaternions, and
                                     * msgs_backward applies the chain rule of sigmoid / exp / normalize / cat itself:
                                     * dL_dopacities, dL_dscales, dL_drotations, dL_dfeatures_dc/_rest are gradients
                                     * w.r.t. the RAW parameters — what autograd would produce by running the backward

@@ -28,7 +28,7 @@ inline int check_inputs(const msgs_view_t* v, const msgs_gaussians_t* g) {
         if (g->raw_params != 1 && g->raw_params != 2) return MSGS_ERR_INVALID_ARG;
         if (!g->features_dc || !g->features_rest || !g->scales || !g->rotations) return MSGS_ERR_INVALID_ARG;
         if (g->raw_params == 2 && !g->rotations_raw) return MSGS_ERR_INVALID_ARG;
-        if (g->shs || g->colors_precomp || g->cov3D_precomp) return MSGS_ERR_INVALID_ARG;
+        if ((g->shs && g->raw_params != 2) || g->colors_precomp || g->cov3D_precomp) return MSGS_ERR_INVALID_ARG;
         if (v->sh_degree < 0 || v->sh_degree > 3 || v->sh_coeffs != 16) return MSGS_ERR_SH_DEGREE;
         if ((v->image_width + TILE - 1) / TILE > 65535 || (v->image_height + TILE - 1) / TILE > 65535)
             return MSGS_ERR_INVALID_ARG;
@@ -263,7 +263,7 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
         image_bytes < msgs_image_bytes(W, H) ||
         scratch_bytes < (det ? msgs_backward_scratch_bytes_deterministic(P, D) : msgs_backward_scratch_bytes(P)))
         return MSGS_ERR_CAPACITY;
-    if (g->shs && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
+    if (g->shs && !g->raw_params && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
     if (g->raw_params && (!grads->dL_dfeatures_dc || !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const char* geom = (const char*)geom_v;

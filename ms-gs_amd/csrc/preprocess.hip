@@ -385,8 +385,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 
     // ---- phase B: SH rows of the surviving Gaussians, HBM -> LDS, coalesced per row ----
     const bool raw = g.raw_params != 0;
+    // chained mode may also hand over the concatenated `shs` the reference built: 16-byte aligned 192-byte rows, of
+    // which only the surviving Gaussians' are fetched (the split leaves are read as one run per wave, all 64 rows)
+    const bool split_in = raw && g.shs == nullptr;
     const bool staged_sh = raw || (g.shs != nullptr && vp.sh_coeffs == 16);   // wave-uniform
-    if (raw) {
+    if (split_in) {
         const int wave_first = blockIdx.x * blockDim.x + wv * 64;
         const int nrow = min(64, P - wave_first);
         if (nrow > 0 && __ballot(alive) != 0)
@@ -494,10 +497,11 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     // SH rows in / dSH rows out through LDS with coalesced wave-cooperative transfers (K == 16 only;
     // other layouts take the direct per-thread path)
     const bool raw = g.raw_params != 0;
+    const bool split_in = raw && g.shs == nullptr;
     const bool staged_sh = raw || (g.shs != nullptr && grads.dL_dshs != nullptr && K == 16);   // wave-uniform
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
-    if (raw) {
+    if (split_in) {
         const int nrow = min(64, P - wave_first);
         if (nrow > 0 && live != 0)
             coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane);

@@ -305,9 +305,9 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
-                opacities, scales, rotations, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask,
+                shs, opacities, scales, rotations, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask,
                 raster_settings):
-        call = _Call(raster_settings, xyz, None, None, opacities, scales, rotations, None,
+        call = _Call(raster_settings, xyz, _opt(shs), None, opacities, scales, rotations, None,
                      _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
                      _opt(base_mask), raw_features=(features_dc, features_rest), rotations_raw=rotation_raw)
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
@@ -319,12 +319,15 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
         return _RasterizeGaussiansRaw.backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii,
-                                               grad_pixel_sizes)[:7] + (None,) * 9
+                                               grad_pixel_sizes)[:7] + (None,) * 10
 
 
 # Recognition of the reference's getters (scene/gaussian_model.py:127-153) in the autograd graph of the arguments of
 # GaussianRasterizer.forward.  Module-level switch; MSGS_NO_GETTER_CHAIN=1 in the environment turns it off.
 chain_reference_getters = os.environ.get("MSGS_NO_GETTER_CHAIN", "0") != "1"
+# the chained kernels read the SH rows from the concatenated tensor the reference built (aligned rows, visible ones
+# only: K1 111 -> 89 us, K9 141 -> 126 us at C3) at the price of keeping that [P,16,3] tensor alive until backward
+_chain_reads_cat = os.environ.get("MSGS_CHAIN_SPLIT_READS", "0") != "1"
 
 
 def _leaf(fn):
@@ -464,7 +467,8 @@ class GaussianRasterizer(nn.Module):
             if leaves is not None:
                 o = lambda t: t if t is not None else empty
                 return _RasterizeGaussiansChained.apply(
-                    means3D, means2D, *leaves, opacities.detach(), scales.detach(), rotations.detach(),
+                    means3D, means2D, *leaves, shs.detach() if _chain_reads_cat else empty, opacities.detach(), scales.detach(),
+                    rotations.detach(),
                     o(max_pixel_sizes), o(min_pixel_sizes), o(occ_multiplier), o(dc_delta), o(base_mask), rs)
         return rasterize_gaussians(
             means3D, means2D,
