@@ -150,12 +150,55 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     uint64_t* status_dev = total_dev + 2;
     const SortScratch SSL(P);
     const bool classic = use_classic_sort();
+    // The instance count comes back through three pinned, device-mapped host words per host thread that the status
+    // kernel writes itself and this thread polls: no copy command, no interrupt-driven wait (a blocking
+    // hipStreamSynchronize wakes up tens of microseconds after the data landed, and until stage 2 is launched the GPU
+    // idles).  MSGS_BLOCKING_SYNC=1, or a failed pinned allocation, falls back to copy + hipStreamSynchronize.
+    static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
+    static thread_local uint64_t* t_host = nullptr;
+    static thread_local uint64_t* t_host_dev = nullptr;
+    static thread_local uint64_t t_ticket = 0;
+    static thread_local bool t_tried = false;
+    if (!blocking && !t_tried) {
+        t_tried = true;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                t_host = (uint64_t*)h;
+                t_host_dev = (uint64_t*)d;
+                t_host[2] = 0;
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    const bool polled = !blocking && t_host != nullptr;
+    const uint64_t ticket = ++t_ticket;
     HIP_TRY(launch_collect_status(total_dev,
                                   classic ? nullptr : (const uint32_t*)(scratch + SL.sort + SSL.hist) + 4 * 256 + 4,
                                   classic ? nullptr : (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
-                                  status_dev, s));
-    HIP_TRY(hipMemcpyAsync(host_status, status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+                                  status_dev, polled ? t_host_dev : nullptr, ticket, s));
+    if (polled) {
+        volatile uint64_t* hv = t_host;
+        uint64_t spins = 0;
+        while (hv[2] != ticket) {
+            if ((++spins & 0xFFFF) == 0) {                 // every 65536 polls: has the stream failed or finished?
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipErrorNotReady && q != hipSuccess) return (int)q;
+                if (q == hipSuccess && hv[2] != ticket) {  // finished without the flag: fall back to the device copy
+                    HIP_TRY(hipMemcpyAsync(host_status, status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    break;
+                }
+            }
+        }
+        if (hv[2] == ticket) { host_status[0] = hv[0]; host_status[1] = hv[1]; }
+    } else {
+        HIP_TRY(hipMemcpyAsync(host_status, status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     const uint64_t total = host_status[0];
     if (host_status[1] != 0) return MSGS_ERR_INTERNAL;
     if (total > 0xFFFFFFFFull) return MSGS_ERR_TOO_MANY;
@@ -275,7 +318,7 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     const Timer tm{timing, s};
     float* grad_rec = (float*)scratch_v;
 
-    HIP_TRY(hipMemsetAsync(grad_rec, 0, sizeof(float) * GRAD_REC_FLOATS * (size_t)P, s));
+    HIP_TRY(launch_zero(grad_rec, sizeof(float) * GRAD_REC_FLOATS * (size_t)P, s));
     tm.begin(MSGS_K_BLEND_BWD);
     if (det)      // grad_rec is the first region of the deterministic scratch layout
         HIP_TRY(launch_blend_backward_det(vp, P, geom, (const uint32_t*)(binning + BL.ids), D,

@@ -101,7 +101,7 @@ hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* 
 }
 
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, s);
+    hipError_t e = launch_zero(ranges, sizeof(uint2) * (size_t)num_tiles, s);
     if (e != hipSuccess) return e;
     if (D == 0) return hipSuccess;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys, D, ranges, num_tiles);

@@ -751,7 +751,7 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
     uint32_t* keys_s = (uint32_t*)(scratch + L.keys_s);
     uint32_t* entry = (uint32_t*)(scratch + L.entry);
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    hipError_t e = hipMemsetAsync(inst, 0, sizeof(float) * DET_INST_FLOATS * (size_t)D, s);
+    hipError_t e = launch_zero(inst, sizeof(float) * DET_INST_FLOATS * (size_t)D, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                        n_contrib, dL_dcolor, inst);

@@ -297,7 +297,10 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s);
 bool use_classic_sort();
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
-                                 uint64_t* out, hipStream_t s);
+                                 uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);
+// device-side fill with zeros (sort.hip): an ordinary kernel launch — hipMemsetAsync costs ~10 us of queue latency per
+// call on this runtime (barrier packets around the fill), four of them per step were 3 % of the C3 step
+hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and bytes multiples of 4
 // binning.hip
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s);

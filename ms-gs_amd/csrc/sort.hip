@@ -497,14 +497,24 @@ bool use_classic_sort() {
 
 // stage-1 status block {u64 total, u32 sort watchdog, u32 scan watchdog, ...}: one D2H copy for the host
 __global__ void collect_status_kernel(const uint64_t* __restrict__ total, const uint32_t* __restrict__ sort_err,
-                                      const uint32_t* __restrict__ scan_err, uint64_t* __restrict__ out) {
-    out[0] = *total;
-    out[1] = (uint64_t)(sort_err ? *sort_err : 0u) | ((uint64_t)(scan_err ? *scan_err : 0u) << 32);
+                                      const uint32_t* __restrict__ scan_err, uint64_t* __restrict__ out,
+                                      volatile uint64_t* host, uint64_t ticket) {
+    const uint64_t t = *total;
+    const uint64_t e = (uint64_t)(sort_err ? *sort_err : 0u) | ((uint64_t)(scan_err ? *scan_err : 0u) << 32);
+    out[0] = t;
+    out[1] = e;
+    if (host) {                     // pinned, device-mapped host words {total, flags, ticket}: the host polls `ticket`
+        host[0] = t;
+        host[1] = e;
+        __threadfence_system();
+        host[2] = ticket;
+    }
 }
 
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
-                                 uint64_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(collect_status_kernel, dim3(1), dim3(1), 0, s, total, sort_err, scan_err, out);
+                                 uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s) {
+    hipLaunchKernelGGL(collect_status_kernel, dim3(1), dim3(1), 0, s, total, sort_err, scan_err, out,
+                       (volatile uint64_t*)host_mapped, ticket);
     return hipGetLastError();
 }
 
@@ -527,6 +537,27 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n, partials);
+    return hipGetLastError();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, size_t n_words) {
+    const size_t n4 = n_words >> 2;
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[(n4 << 2) + threadIdx.x] = 0u;
+}
+}  // namespace
+
+hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(ptr) & 15) || (bytes & 3)) return hipMemsetAsync(ptr, 0, bytes, s);
+    const size_t words = bytes >> 2;
+    size_t blocks = (words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)ptr, words);
     return hipGetLastError();
 }
 
@@ -556,7 +587,7 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     const int ngroups = (int)((nb + gsize - 1) / gsize);
     uint32_t* gsum_all = hist + (size_t)256 * nb;
     if (grouped) {
-        hipError_t e = hipMemsetAsync(gsum_all, 0, sizeof(uint32_t) * (size_t)passes * 256 * ngroups, s);
+        hipError_t e = launch_zero(gsum_all, sizeof(uint32_t) * (size_t)passes * 256 * ngroups, s);
         if (e != hipSuccess) return e;
     }
     // onesweep carve-up of the `hist` region: [4][256] digit histograms, [4] tickets, [1] error flag,
