@@ -127,33 +127,27 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     const ViewParams vp = make_view_params(view);
     const Timer tm{timing, s};
 
+    // K1 also clears the depth sort's group-sum table (saves a fill launch)
+    ZeroJob zj1{nullptr, 0, nullptr, 0};
+    const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
     tm.begin(MSGS_K_PREPROCESS);
-    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s));
+    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1));
     tm.end(MSGS_K_PREPROCESS);
     if ((rc = debug_sync(view, s))) return rc;
 
     // depth order of the Gaussians (not rendered -> key 0xFFFFFFFF -> sorted last, zero tiles)
     tm.begin(MSGS_K_DEPTH_SORT);
     HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(scratch + SL.keys_a),
-                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s));
+                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed));
     tm.end(MSGS_K_DEPTH_SORT);
     if ((rc = debug_sync(view, s))) return rc;
 
-    tm.begin(MSGS_K_SCAN);
-    uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
-    HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
-                               (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s));
-    tm.end(MSGS_K_SCAN);
-
-    // one synchronisation, one D2H copy: {instance count, look-back watchdog flags} (sort.hip)
-    uint64_t host_status[2] = {0, 0};
-    uint64_t* status_dev = total_dev + 2;
-    const SortScratch SSL(P);
-    const bool classic = use_classic_sort();
-    // The instance count comes back through three pinned, device-mapped host words per host thread that the status
-    // kernel writes itself and this thread polls: no copy command, no interrupt-driven wait (a blocking
+    // The instance count D comes back through three pinned, device-mapped host words per host thread {D, flags,
+    // ticket} that a kernel writes itself and this thread polls: no copy command, no interrupt-driven wait (a blocking
     // hipStreamSynchronize wakes up tens of microseconds after the data landed, and until stage 2 is launched the GPU
-    // idles).  MSGS_BLOCKING_SYNC=1, or a failed pinned allocation, falls back to copy + hipStreamSynchronize.
+    // idles).  In the default sort/scan configuration the scan's middle kernel — where the grand total is final —
+    // writes them, so the host learns D while the last stage-1 kernel still runs.  MSGS_BLOCKING_SYNC=1, or a failed
+    // pinned allocation, falls back to a 16-byte copy + hipStreamSynchronize.
     static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
     static thread_local uint64_t* t_host = nullptr;
     static thread_local uint64_t* t_host_dev = nullptr;
@@ -176,10 +170,22 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     }
     const bool polled = !blocking && t_host != nullptr;
     const uint64_t ticket = ++t_ticket;
-    HIP_TRY(launch_collect_status(total_dev,
-                                  classic ? nullptr : (const uint32_t*)(scratch + SL.sort + SSL.hist) + 4 * 256 + 4,
-                                  classic ? nullptr : (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
-                                  status_dev, polled ? t_host_dev : nullptr, ticket, s));
+    const bool classic = use_classic_sort();
+    uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
+    uint64_t* status_dev = total_dev + 2;
+    uint64_t host_status[2] = {0, 0};
+
+    tm.begin(MSGS_K_SCAN);
+    HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
+                               (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
+                               classic ? status_dev : nullptr, classic && polled ? t_host_dev : nullptr, ticket));
+    tm.end(MSGS_K_SCAN);
+    if (!classic) {        // look-back sort / scan variants: watchdog flags join the status in a final tiny kernel
+        const SortScratch SSL(P);
+        HIP_TRY(launch_collect_status(total_dev, (const uint32_t*)(scratch + SL.sort + SSL.hist) + 4 * 256 + 4,
+                                      (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
+                                      status_dev, polled ? t_host_dev : nullptr, ticket, s));
+    }
     if (polled) {
         volatile uint64_t* hv = t_host;
         uint64_t spins = 0;
@@ -267,20 +273,26 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
     uint2* ranges = (uint2*)(binning + BL.ranges);
     uint32_t* keys_sorted = D > 0 ? (uint32_t*)(scratch + SL.total) : nullptr;
 
+    bool ranges_prezeroed = false;
     if (D > 0) {
         uint32_t* keys_a = (uint32_t*)(scratch + SL.keys_a);
         uint32_t* ids_a = (uint32_t*)(scratch + SL.ids_a);
+        // emit also clears the tile sort's group-sum table and the tile-range array (two fill launches less)
+        ZeroJob zj2{nullptr, 0, (uint32_t*)ranges, 2 * (size_t)num_tiles};
+        const bool sort2_prezeroed = radix_sort_zero_region(D, 0, tile_bits(num_tiles), scratch + SL.sort, &zj2.p0, &zj2.n0);
+        ranges_prezeroed = true;
         tm.begin(MSGS_K_EMIT);
-        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s));
+        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2));
         tm.end(MSGS_K_EMIT);
         if ((rc = debug_sync(view, s))) return rc;
         tm.begin(MSGS_K_TILE_SORT);
-        HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, D, 0, tile_bits(num_tiles), scratch + SL.sort, s));
+        HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, D, 0, tile_bits(num_tiles), scratch + SL.sort, s,
+                                 sort2_prezeroed));
         tm.end(MSGS_K_TILE_SORT);
         if ((rc = debug_sync(view, s))) return rc;
     }
     tm.begin(MSGS_K_RANGES);
-    HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s));
+    HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s, ranges_prezeroed));
     tm.end(MSGS_K_RANGES);
     if ((rc = debug_sync(view, s))) return rc;
 

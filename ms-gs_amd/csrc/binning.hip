@@ -22,7 +22,12 @@ constexpr int EMIT_STAGE = 3072;   // pairs: 24 KB of LDS
 
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids,
-                                                   int64_t D) {
+                                                   int64_t D, ZeroJob zj) {
+    {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
+        const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+        for (size_t t = t0; t < zj.n0; t += nt) zj.p0[t] = 0u;
+        for (size_t t = t0; t < zj.n1; t += nt) zj.p1[t] = 0u;
+    }
     __shared__ uint32_t s_keys[EMIT_STAGE];
     __shared__ uint32_t s_ids[EMIT_STAGE];
     __shared__ int64_t s_range[2];
@@ -94,15 +99,18 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
 }  // namespace
 
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids, int64_t D,
-                       hipStream_t s) {
-    if (P == 0 || D == 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D);
+                       hipStream_t s, ZeroJob zj) {
+    if (P == 0 || D == 0) return hipSuccess;     // (callers fold a ZeroJob in only when D > 0)
+    hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj);
     return hipGetLastError();
 }
 
-hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s) {
-    hipError_t e = launch_zero(ranges, sizeof(uint2) * (size_t)num_tiles, s);
-    if (e != hipSuccess) return e;
+hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
+                         bool pre_zeroed) {
+    if (!pre_zeroed) {
+        hipError_t e = launch_zero(ranges, sizeof(uint2) * (size_t)num_tiles, s);
+        if (e != hipSuccess) return e;
+    }
     if (D == 0) return hipSuccess;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys, D, ranges, num_tiles);
     return hipGetLastError();

@@ -277,9 +277,13 @@ inline ViewParams make_view_params(const msgs_view_t* v) {
     return p;
 }
 
+// up to two word ranges a kernel clears on behalf of later launches (thread t clears word t of each range): saves the
+// separate fill launches in front of the radix sorts and the tile-range pass
+struct ZeroJob { uint32_t* p0; size_t n0; uint32_t* p1; size_t n1; };
+
 // preprocess.hip
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s);
+                             char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const float* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s);
@@ -291,10 +295,13 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // inputs are clobbered when more than one pass is needed.
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch /* SortScratch(n) */,
-                            hipStream_t s);
+                            hipStream_t s, bool pre_zeroed = false);
+bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words);
+
 // out[r] = exclusive sum of in[gather ? gather[r] : r]; *total (device, u64) = grand total
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
-                              uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s);
+                              uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s,
+                              uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0);
 bool use_classic_sort();
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
                                  uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);
@@ -303,8 +310,9 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and bytes multiples of 4
 // binning.hip
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
-                       int64_t D, hipStream_t s);
-hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s);
+                       int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
+hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
+                         bool pre_zeroed = false);
 int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value
 // blend.hip, deterministic backward: scratch = [grad_rec | inst_grad | sort buffers]
 struct DetScratch {

@@ -307,10 +307,15 @@ __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, flo
 __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gaussians_t g,
                                                          int32_t* __restrict__ radii,
                                                          float* __restrict__ pixel_sizes,
-                                                         char* __restrict__ geom) {
+                                                         char* __restrict__ geom, ZeroJob zj) {
     __shared__ float s_rows[4][64 * ROW_LDS];
     __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
+    {   // housekeeping for the depth sort that follows: clear its group-sum table (one word per thread)
+        const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+        for (size_t t = t0; t < zj.n0; t += nt) zj.p0[t] = 0u;
+        for (size_t t = t0; t < zj.n1; t += nt) zj.p1[t] = 0u;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool in_range = i < P;
@@ -748,9 +753,9 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s) {
+                             char* geom, hipStream_t s, ZeroJob zj) {
     if (g.P == 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom);
+    hipLaunchKernelGGL(preprocess_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
     return hipGetLastError();
 }
 

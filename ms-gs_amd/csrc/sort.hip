@@ -68,8 +68,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 }
 
 // single block: exclusive scan of the per-block totals (u64), grand total to partials[nb]
+// (status / host: optional stage-1 status block {total, 0} on the device and {total, 0, ticket} in pinned host words —
+//  the grand total is final HERE, one kernel before the offsets are, so the host learns D while scan_apply still runs)
 __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict__ partials, int64_t nb,
-                                                            uint64_t* __restrict__ total_out) {
+                                                            uint64_t* __restrict__ total_out,
+                                                            uint64_t* __restrict__ status = nullptr,
+                                                            volatile uint64_t* host = nullptr, uint64_t ticket = 0) {
     __shared__ uint64_t s_w[4];
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -97,6 +101,13 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
     if (threadIdx.x == 0) {
         partials[nb] = s_carry;
         if (total_out) *total_out = s_carry;
+        if (status) { status[0] = s_carry; status[1] = 0; }
+        if (host) {
+            host[0] = s_carry;
+            host[1] = 0;
+            __threadfence_system();
+            host[2] = ticket;
+        }
     }
 }
 
@@ -519,10 +530,12 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 }
 
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
-                              uint64_t* partials, uint64_t* total, hipStream_t s) {
+                              uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
+                              uint64_t* host_mapped, uint64_t ticket) {
     const int64_t nb = scan_blocks(n > 0 ? n : 1);
     if (n <= 0) {
-        hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total);
+        hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total, status,
+                           (volatile uint64_t*)host_mapped, ticket);
         return hipGetLastError();
     }
     if (!use_classic_sort()) {
@@ -535,7 +548,8 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
         return hipGetLastError();
     }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials);
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
+                       (volatile uint64_t*)host_mapped, ticket);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n, partials);
     return hipGetLastError();
 }
@@ -561,8 +575,31 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+// The words radix_sort_pairs(n, bits) needs zeroed beforehand in its default (grouped) configuration — an upper bound on
+// the group-sum table, so that a kernel running earlier on the stream can clear them and the sort can be called with
+// pre_zeroed = true (one launch less).  Returns false when the sort will not take the grouped path.
+bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {
+    if (n <= 0) return false;
+    int passes = (end_bit - begin_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
+    static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
+    const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
+    if (onesweep || scan_table || passes > 4) return false;
+    const bool big = staged && n >= SORT_BIG_N;
+    const int64_t nb = big ? (n + 2 * SORT_CHUNK - 1) / (2 * SORT_CHUNK) : sort_blocks(n);
+    int gsize = 8;
+    while ((int64_t)gsize * gsize < nb) gsize += 8;
+    gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
+    const int ngroups = (int)((nb + gsize - 1) / gsize);
+    const SortScratch L(n);
+    *ptr = reinterpret_cast<uint32_t*>(scratch + L.hist) + (size_t)256 * nb;
+    *words = (size_t)passes * 256 * ngroups;
+    return true;
+}
+
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                            int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s) {
+                            int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s, bool pre_zeroed) {
     if (n <= 0) return hipSuccess;
     const SortScratch L(n);
     uint32_t* keys_alt = reinterpret_cast<uint32_t*>(scratch + L.keys_alt);
@@ -586,7 +623,7 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
     const int ngroups = (int)((nb + gsize - 1) / gsize);
     uint32_t* gsum_all = hist + (size_t)256 * nb;
-    if (grouped) {
+    if (grouped && !pre_zeroed) {
         hipError_t e = launch_zero(gsum_all, sizeof(uint32_t) * (size_t)passes * 256 * ngroups, s);
         if (e != hipSuccess) return e;
     }
