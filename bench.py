@@ -184,7 +184,10 @@ def main():
     #        of view k runs on RCCL's stream while view k+1 is rendered (PipelinedGradExchange); every exchange
     #        completes inside the timed region (drain before the closing synchronize).
     # N = 1: nothing to reduce -> grads are left to autograd (set-to-None each step, like optimizer.zero_grad).
-    exchange = PipelinedGradExchange(pc.parameters(), world) if world > 1 else None
+    # (direct: the backward writes each view's gradients straight into the bucket — no zero-fill, no accumulation pass;
+    #  available because the op chains the reference's getters itself)
+    direct = bool(dgr.chain_reference_getters)
+    exchange = PipelinedGradExchange(pc.parameters(), world, direct=direct) if world > 1 else None
     bg = torch.zeros(3, device=dev)
     dL = scenes.grad_seed(W, H, 2).to(dev)
     torch.cuda.synchronize()
@@ -245,18 +248,26 @@ def main():
     if world > 1:
         bucket = exchange.buckets[0]
 
+        def prepare(bk):
+            if direct:
+                bk.detach_grads()
+                dgr.set_grad_sinks(bk.sinks())
+            else:
+                bk.zero()
+
         def step_serial(k):
-            bucket.zero()
+            prepare(bucket)
             render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
             bucket.all_reduce(average_over=world)
 
         def step_local(k):
-            bucket.zero()
+            prepare(bucket)
             render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
         step_serial(0)
         ts = timed_region(step_serial, args.steps) / args.steps
         step_local(0)
         tl = timed_region(step_local, args.steps) / args.steps
+        dgr.set_grad_sinks(None)
         mp = world * (W * H / 1e6)
         extra = {"serial_allreduce": {"ms_per_step": round(1e3 * ts, 4), "value": round(mp / ts, 3)},
                  "without_allreduce": {"ms_per_step": round(1e3 * tl, 4), "value": round(mp / tl, 3)},
@@ -274,7 +285,8 @@ def main():
                           "recognises the reference's getters in the autograd graph and chains their backward inside "
                           "msgs_backward (chain_reference_getters=" + str(bool(dgr.chain_reference_getters)) + ")",
                    "parallelism": f"view-parallel x{world}" + (", flat fp32 grad all-reduce (RCCL) of view k overlapped with "
-                                                                "the rendering of view k+1 (2 buckets)" if world > 1 else "")},
+                                                                "the rendering of view k+1 (2 buckets" + (", gradients written straight into the "
+                                                                "bucket" if world > 1 and direct else "") + ")" if world > 1 else "")},
     }
 
     if rank == 0:

@@ -253,6 +253,30 @@ class _RasterizeGaussians(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
+# Gradient sinks (view-parallel training): a trainer that exchanges gradients through one flat bucket registers, per leaf
+# parameter, the slice of the bucket its gradient belongs in.  The backward of the raw / chained entries then writes the
+# gradient THERE and returns a fresh alias of that slice; with param.grad = None autograd adopts the alias as .grad (no
+# copy), so neither a zero-fill of the bucket nor an accumulation pass over it is needed.  Keys: leaf.data_ptr().
+_grad_sinks = {}
+
+
+def set_grad_sinks(mapping):
+    """mapping: {leaf parameter: destination tensor (float32, contiguous, same numel)} or None to clear."""
+    _grad_sinks.clear()
+    if mapping:
+        for leaf, dest in mapping.items():
+            if dest.dtype != torch.float32 or not dest.is_contiguous() or dest.numel() != leaf.numel():
+                raise ValueError("grad sink must be a contiguous float32 tensor with the parameter's numel")
+            _grad_sinks[leaf.data_ptr()] = dest
+
+
+def _grad_out(key, shape, dev):
+    dest = _grad_sinks.get(key)
+    if dest is not None and dest.device == dev:
+        return dest.view(shape)                     # a NEW alias: autograd may adopt it as param.grad
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
 class _RasterizeGaussiansRaw(torch.autograd.Function):
     """Opt-in fused entry: takes the RAW GaussianModel parameters
     (/root/reference/scene/gaussian_model.py:53-58: _xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation);
@@ -270,6 +294,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
+        ctx.leaf_keys = tuple(t.data_ptr() for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
+                                                      rotation_raw))
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
         return color, acc_ps, depth, radii, pixel_sizes
 
@@ -283,8 +309,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dL = _f32c(grad_color)
-            e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-            g_xyz, g_m2, g_opac, g_dc, g_rest, g_scal, g_rot = e(P, 3), e(P, 3), e(P), e(P, 3), e(P, 45), e(P, 3), e(P, 4)
+            kx, kdc, krest, kop, ksc, krot = ctx.leaf_keys
+            g_m2 = torch.empty(P, 3, dtype=torch.float32, device=dev)
+            g_xyz, g_dc, g_rest = _grad_out(kx, (P, 3), dev), _grad_out(kdc, dc_shape, dev), _grad_out(krest, rest_shape, dev)
+            g_opac, g_scal, g_rot = _grad_out(kop, op_shape, dev), _grad_out(ksc, (P, 3), dev), _grad_out(krot, (P, 4), dev)
             scratch = _backward_scratch(P, D, dev)
             grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, None, _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
                              _ptr(g_dc), _ptr(g_rest))
@@ -292,8 +320,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
                                        _C.timer_ptr(), stream), "msgs_backward")
-        return (g_xyz, g_m2.view(m2_shape), g_dc.view(dc_shape), g_rest.view(rest_shape), g_opac.view(op_shape),
-                g_scal, g_rot, None, None, None, None, None, None)
+        return (g_xyz, g_m2.view(m2_shape), g_dc, g_rest, g_opac, g_scal, g_rot, None, None, None, None, None, None)
 
 
 class _RasterizeGaussiansChained(torch.autograd.Function):
@@ -313,6 +340,8 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
+        ctx.leaf_keys = tuple(t.data_ptr() for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
+                                                      rotation_raw))
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
         return color, acc_ps, depth, radii, pixel_sizes
 

@@ -25,6 +25,16 @@ class FlatGradBucket:
             self.views.append(v)
             off += p.numel()
 
+    def sinks(self):
+        """{parameter: its slice of the bucket} for diff_gaussian_rasterization.set_grad_sinks (direct mode)."""
+        return dict(zip(self.params, self.views))
+
+    def detach_grads(self):
+        """Direct mode: param.grad = None, so that autograd ADOPTS the alias of the bucket slice the rasterizer's
+        backward wrote the gradient into (no zero-fill of the bucket, no accumulation pass)."""
+        for p in self.params:
+            p.grad = None
+
     def zero(self):
         self.flat.zero_()
         for p, v in zip(self.params, self.views):   # re-attach in case an optimiser set grads to None
@@ -59,7 +69,11 @@ class PipelinedGradExchange:
     xGMI is per-link bound, so the exchange of a 236 MB bucket costs about as much as a whole view at 8 GPUs; hiding
     it behind the next view is what keeps view-parallel scaling near-linear."""
 
-    def __init__(self, params, world=None, group=None):
+    def __init__(self, params, world=None, group=None, direct=False):
+        """direct=True: the rasterizer's backward writes each view's gradients straight into the current bucket
+        (diff_gaussian_rasterization.set_grad_sinks; needs the raw / chained entry, i.e. the reference's getters or
+        render_fused) — ONE view per bucket use, no zero-fill and no accumulation pass over the 59*P floats."""
+        self.direct = direct
         self.group = group
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = world if world is not None else (dist.get_world_size(group) if self.active else 1)
@@ -92,11 +106,23 @@ class PipelinedGradExchange:
     def begin_view(self):
         i = self.k % 2
         self._finish(i)                            # the exchange issued two views ago used this bucket
-        self.buckets[i].zero()                     # also points every p.grad at this bucket
+        if self.direct:
+            import diff_gaussian_rasterization as dgr
+            self.buckets[i].detach_grads()
+            dgr.set_grad_sinks(self.buckets[i].sinks())
+        else:
+            self.buckets[i].zero()                 # also points every p.grad at this bucket
 
     def end_view(self):
         i = self.k % 2
         b = self.buckets[i]
+        if self.direct:
+            import diff_gaussian_rasterization as dgr
+            dgr.set_grad_sinks(None)
+            for p, v in zip(b.params, b.views):    # the backward must have delivered every gradient into the bucket
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    raise RuntimeError("PipelinedGradExchange(direct=True): a gradient did not land in the bucket "
+                                       "(the rasterizer was not called through its raw / chained entry)")
         if self.active:
             op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
             self.pending[i] = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)

@@ -86,3 +86,46 @@ def test_c3_fullsize_chained_vs_plain():
     assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
     for n in LEAVES:
         assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= 1e-3, n      # float-atomic noise floor at this size
+
+
+def test_gradient_sinks_deliver_into_the_exchange_bucket():
+    """PipelinedGradExchange(direct=True): the backward writes the leaf gradients straight into the flat bucket and
+    autograd adopts those aliases as .grad — same values as the ordinary path, no zero-fill / accumulation pass."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render, render_fused
+    from synthetic_model import SyntheticGaussians
+    from view_parallel import PipelinedGradExchange
+    W, H = 128, 96
+    sc, cam = small_scene(3000, W, H, 41)
+    bg = torch.zeros(3).cuda()
+    camd = cam.to("cuda")
+    dL = scenes.grad_seed(W, H, 41).cuda()
+    ref = SyntheticGaussians(sc, "cuda")
+    render(camd, ref, PIPE, bg)["render"].backward(dL)
+    for fn in (render, render_fused):
+        pc = SyntheticGaussians(sc, "cuda")
+        ex = PipelinedGradExchange(pc.parameters(), world=2, direct=True)      # no process group: local average only
+        for k in range(3):                                                    # both buckets, and reuse of the first
+            ex.begin_view()
+            assert all(p.grad is None for p in pc.parameters())
+            fn(camd, pc, PIPE, bg)["render"].backward(dL)
+            b = ex.end_view()
+            for p, v in zip(pc.parameters(), b.views):
+                assert p.grad.data_ptr() == v.data_ptr()                      # adopted, not copied
+        ex.drain()
+        assert not dgr._grad_sinks
+        for n in LEAVES:
+            got, want = getattr(pc, n).grad, getattr(ref, n).grad / 2
+            assert rel_err(got, want) <= HIP_VS_HIP_RTOL, (fn.__name__, n)
+    # the plain path cannot deliver into the bucket: loud failure instead of silently missing gradients
+    pc = SyntheticGaussians(sc, "cuda")
+    ex = PipelinedGradExchange(pc.parameters(), world=2, direct=True)
+    dgr.chain_reference_getters = False
+    try:
+        ex.begin_view()
+        render(camd, pc, PIPE, bg)["render"].backward(dL)
+        with pytest.raises(RuntimeError, match="did not land in the bucket"):
+            ex.end_view()
+    finally:
+        dgr.chain_reference_getters = True
+        dgr.set_grad_sinks(None)
