@@ -51,17 +51,52 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return base + inc - v;
 }
 
+// SCAN_ITEMS consecutive values of one thread: 16-byte accesses when the run is complete and aligned
+__device__ __forceinline__ void scan_load_items(const uint32_t* in, int64_t base, int64_t n, uint32_t v[SCAN_ITEMS]) {
+    static_assert(SCAN_ITEMS % 4 == 0, "uint4 runs");
+    if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS / 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(in + base + 4 * q);
+            v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < n ? in[base + k] : 0u;
+    }
+}
+__device__ __forceinline__ void scan_store_items(uint32_t* out, int64_t base, int64_t n, const uint32_t v[SCAN_ITEMS]) {
+    if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(out + base) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < SCAN_ITEMS / 4; ++q)
+            *reinterpret_cast<uint4*>(out + base + 4 * q) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) out[base + k] = v[k];
+    }
+}
+
+// with `gather`, the gathered values are also STORED to staged[] (the caller passes the output array): the second pass
+// then scans that array in place and the random gather happens once instead of twice
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in,
                                                                    const uint32_t* __restrict__ gather,
-                                                                   int64_t n, uint64_t* __restrict__ partials) {
+                                                                   int64_t n, uint64_t* __restrict__ partials,
+                                                                   uint32_t* __restrict__ staged) {
     __shared__ uint32_t s_wave[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    if (gather) {
+        uint32_t g[SCAN_ITEMS];
+        scan_load_items(gather, base, n, g);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < n ? in[g[k]] : 0u;
+        if (staged) scan_store_items(staged, base, n, v);
+    } else {
+        scan_load_items(in, base, n, v);
+    }
     uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int64_t i = base + k;
-        if (i < n) sum += gather ? in[gather[i]] : in[i];
-    }
+    for (int k = 0; k < SCAN_ITEMS; ++k) sum += v[k];
     uint32_t total;
     block_exclusive_scan(sum, s_wave, &total);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
@@ -111,28 +146,33 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ in,
-                                                                  const uint32_t* __restrict__ gather,
-                                                                  uint32_t* __restrict__ out, int64_t n,
+// `in` may alias `out` (in-place: every thread reads its SCAN_ITEMS values before it writes them)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather,
+                                                                  uint32_t* out, int64_t n,
                                                                   const uint64_t* __restrict__ partials) {
     __shared__ uint32_t s_wave[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
+    if (gather) {
+        uint32_t g[SCAN_ITEMS];
+        scan_load_items(gather, base, n, g);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < n ? in[g[k]] : 0u;
+    } else {
+        scan_load_items(in, base, n, v);
+    }
     uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int64_t i = base + k;
-        v[k] = i < n ? (gather ? in[gather[i]] : in[i]) : 0u;
-        sum += v[k];
-    }
+    for (int k = 0; k < SCAN_ITEMS; ++k) sum += v[k];
     uint32_t total;
     uint32_t run = block_exclusive_scan(sum, s_wave, &total) + (uint32_t)partials[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int64_t i = base + k;
-        if (i < n) out[i] = run;
-        run += v[k];
+        const uint32_t x = v[k];
+        v[k] = run;
+        run += x;
     }
+    scan_store_items(out, base, n, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -547,10 +587,14 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
                            reinterpret_cast<unsigned long long*>(partials), tk, total, tk + 1);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials);
+    // with a gather the first pass leaves the gathered values in `out` and the last pass scans `out` in place
+    const bool stage = gather != nullptr && out != in;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
+                       stage ? out : (uint32_t*)nullptr);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
                        (volatile uint64_t*)host_mapped, ticket);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n, partials);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
+                       stage ? (const uint32_t*)nullptr : gather, out, n, partials);
     return hipGetLastError();
 }
 
