@@ -136,3 +136,15 @@ def test_reference_getter_recognition_on_cpu_graphs():
     assert M(xyz, cat(), torch.sigmoid(op), torch.exp(half), F.normalize(rot)) is None                # dtype
     with torch.no_grad():
         assert M(xyz, cat(), torch.sigmoid(op), torch.exp(sc), F.normalize(rot)) is None
+
+
+def test_header_is_plain_c():
+    """include/msgs.h must be consumable from C (cgo / JNI / any FFI generator): C99, no C++isms, no torch types."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "msgs.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = open(hdr).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S).lower()
