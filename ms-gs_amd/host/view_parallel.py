@@ -7,6 +7,8 @@ message is one fp32 bucket of 59 floats per Gaussian at SH degree 3 (3 xyz + 3 d
 1 opacity + 3 scale + 4 rotation = 236 B): parameter .grad tensors are VIEWS into that bucket, so
 autograd accumulates straight into it and no flatten/unflatten copy is needed around the collective.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -75,7 +77,9 @@ class PipelinedGradExchange:
         render_fused) — ONE view per bucket use, no zero-fill and no accumulation pass over the 59*P floats."""
         self.direct = direct
         self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (MSGS_EXCHANGE_FORCE=1: issue the collectives even with a single rank — lets one GPU exercise the RCCL path)
+        self.active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("MSGS_EXCHANGE_FORCE") == "1")
         self.world = world if world is not None else (dist.get_world_size(group) if self.active else 1)
         self.buckets = [FlatGradBucket(params), FlatGradBucket(params)]
         self.pending = [None, None]
