@@ -157,6 +157,30 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, int c, flo
 }
 
 
+// The same polynomial as sh_channel, factored as colour_c = sum_k basis[k] * sh[k][c] with the terms accumulated in
+// the same order k = 0..15 (and the same products: (C * poly) * coefficient), so that the coefficients can arrive in
+// two halves without changing a single bit of the result.
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = 0.f;
+    b[0] = SH_C0;
+    if (deg > 0) {
+        b[1] = -(SH_C1 * y); b[2] = SH_C1 * z; b[3] = -(SH_C1 * x);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.0f * zz - xx - yy);
+            b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = SH_C3[0] * y * (3.0f * xx - yy); b[10] = SH_C3[1] * xy * z;
+                b[11] = SH_C3[2] * y * (4.0f * zz - xx - yy);
+                b[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                b[13] = SH_C3[4] * x * (4.0f * zz - xx - yy); b[14] = SH_C3[5] * z * (xx - yy);
+                b[15] = SH_C3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-cooperative movement of 192-byte SH rows (K = 16 coefficients x 3 channels) between HBM and
 // LDS.  A thread-per-Gaussian float4 access at a 192-B stride touches 64 different cache lines per
@@ -188,6 +212,26 @@ __device__ __forceinline__ void coop_load_rows(float* lds_rows, const float* g_r
             const int sl = idx[slot];
             const float4 v = *reinterpret_cast<const float4*>(g_rows + (size_t)sl * ROW_F + 4 * c);
             float* d = lds_rows + sl * ROW_LDS + 4 * c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+}
+
+// half rows: float4s [f4_first, f4_first + n4) of every listed row into LDS rows of HALF_LDS floats.  K1 keeps only
+// 24 coefficients-floats per Gaussian in LDS at a time: 25.6 KB per workgroup instead of 50 KB, i.e. six workgroups per CU
+// instead of three — the kernel is latency-bound and its time follows 1/occupancy (measured 87 -> 115 us with two)
+constexpr int HALF_F4 = 6;             // float4s per half row
+constexpr int HALF_LDS = 25;           // floats per half row in LDS (odd: conflict-free one-thread-per-row reads)
+__device__ __forceinline__ void coop_load_rows_part(float* lds_rows, const float* g_rows, const uint8_t* idx, int nrow,
+                                                    int f4_first, int n4, int lane) {
+    const int rpi = 64 / n4;
+    const int sub = lane / n4, c = lane - sub * n4;
+    for (int it = 0; it * rpi < nrow; ++it) {
+        const int slot = it * rpi + sub;
+        if (sub < rpi && slot < nrow) {
+            const int sl = idx[slot];
+            const float4 v = *reinterpret_cast<const float4*>(g_rows + (size_t)sl * ROW_F + 4 * (f4_first + c));
+            float* d = lds_rows + sl * HALF_LDS + 4 * c;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     }
@@ -304,11 +348,15 @@ __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, flo
 // ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
+// SPLIT_ROWS = true: SH from the split dc / rest leaves without a concatenated tensor (raw mode 1, or mode 2 without
+// `shs`): whole 48-float rows in LDS.  false: every other input form; a concatenated K = 16 `shs` goes through LDS in
+// two 24-float halves.
+template <bool SPLIT_ROWS>
 __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gaussians_t g,
                                                          int32_t* __restrict__ radii,
                                                          float* __restrict__ pixel_sizes,
                                                          char* __restrict__ geom, ZeroJob zj) {
-    __shared__ float s_rows[4][64 * ROW_LDS];
+    __shared__ float s_rows[4][64 * (SPLIT_ROWS ? ROW_LDS : HALF_LDS)];
     __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
     {   // housekeeping for the depth sort that follows: clear its group-sum table (one word per thread)
@@ -388,43 +436,70 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         alive = true;
     } while (false);
 
-    // ---- phase B: SH rows of the surviving Gaussians, HBM -> LDS, coalesced per row ----
+    // ---- phase B + colour: SH rows of the surviving Gaussians, HBM -> LDS (coalesced per row) -> SH->RGB ----
     const bool raw = g.raw_params != 0;
     // chained mode may also hand over the concatenated `shs` the reference built: 16-byte aligned 192-byte rows, of
     // which only the surviving Gaussians' are fetched (the split leaves are read as one run per wave, all 64 rows)
-    const bool split_in = raw && g.shs == nullptr;
+    const bool split_in = SPLIT_ROWS && raw && g.shs == nullptr;
     const bool staged_sh = raw || (g.shs != nullptr && vp.sh_coeffs == 16);   // wave-uniform
+    float rgb[3] = {0.f, 0.f, 0.f};
+    float dirx = 0.f, diry = 0.f, dirz = 0.f;
+    if (alive) {
+        const float dx = p[0] - cm.cam[0], dy = p[1] - cm.cam[1], dz = p[2] - cm.cam[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dirx = dx / len; diry = dy / len; dirz = dz / len;
+    }
     if (split_in) {
         const int wave_first = blockIdx.x * blockDim.x + wv * 64;
         const int nrow = min(64, P - wave_first);
         if (nrow > 0 && __ballot(alive) != 0)
             coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane);
         wave_lds_fence();
+        if (alive) {
+            const float* sh = (const float*)&s_rows[wv][lane * ROW_LDS];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = sh_channel(vp.sh_degree, sh, c, dirx, diry, dirz);
+        }
     } else if (staged_sh) {
         const uint64_t need = __ballot(alive);
         if (alive) s_idx[wv][__popcll(need & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        wave_lds_fence();
         const int wave_first = blockIdx.x * blockDim.x + wv * 64;
-        coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(need),
-                       sh_row_float4s(vp.sh_degree), lane);
-        wave_lds_fence();
+        const int ncoef = (vp.sh_degree + 1) * (vp.sh_degree + 1);
+        float basis[16];
+        sh_basis(vp.sh_degree, dirx, diry, dirz, basis);
+        const int n4_total = sh_row_float4s(vp.sh_degree);
+        for (int half = 0; half * HALF_F4 < n4_total; ++half) {
+            wave_lds_fence();                              // s_idx visible / previous half consumed
+            coop_load_rows_part(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(need),
+                                half * HALF_F4, min(HALF_F4, n4_total - half * HALF_F4), lane);
+            wave_lds_fence();
+            if (alive) {
+                const float* row = (const float*)&s_rows[wv][lane * HALF_LDS];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int kk = 8 * half + k;
+                    if (kk < ncoef) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] + basis[kk] * row[3 * k + c];
+                    }
+                }
+            }
+        }
+    } else if (alive && !(g.colors_precomp && !raw)) {
+        const float* sh = g.shs + (size_t)3 * vp.sh_coeffs * i;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = sh_channel(vp.sh_degree, sh, c, dirx, diry, dirz);
     }
 
-    // ---- phase C: colour, exact tile-overlap count, record ----
+    // ---- phase C: clamp, exact tile-overlap count, record ----
     if (alive) {
-        float rgb[3];
         if (g.colors_precomp && !raw) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c] = g.colors_precomp[3 * i + c];
         } else {
-            const float dx = p[0] - cm.cam[0], dy = p[1] - cm.cam[1], dz = p[2] - cm.cam[2];
-            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-            const float x = dx / len, y = dy / len, z = dz / len;
-            const float* sh = staged_sh ? (const float*)&s_rows[wv][lane * ROW_LDS]
-                                        : g.shs + (size_t)3 * vp.sh_coeffs * i;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float r = sh_channel(vp.sh_degree, sh, c, x, y, z) + 0.5f;
+                float r = rgb[c] + 0.5f;
                 if (r < 0.0f) { out_flags |= (1u << c); r = 0.0f; }
                 rgb[c] = r;
             }
@@ -755,7 +830,10 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
                              char* geom, hipStream_t s, ZeroJob zj) {
     if (g.P == 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
+    if (g.raw_params != 0 && g.shs == nullptr)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
     return hipGetLastError();
 }
 
