@@ -50,9 +50,11 @@ struct GeomLayout {
 
 // radix sort geometry: 256 threads x SORT_ITEMS keys per block
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 8;
+constexpr int SORT_ITEMS = 4;
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;
-constexpr int64_t SORT_BIG_N = 2'000'000;   // from here on radix passes use 16 keys per thread (2 x SORT_CHUNK per block)
+constexpr int64_t SORT_BIG_N = 2'000'000;   // from here on radix passes use 16 keys per thread
+constexpr int64_t SORT_MID_N = 400'000;     // from here on 8 keys per thread; below, SORT_ITEMS = 4 (more, smaller blocks:
+                                            // 100k keys 59 -> 50 us; at 1M keys 8 per thread is faster, 76 vs 88 us)
 constexpr int SORT_MAX_GROUPS = 128;   // group sums per digit (grouped radix path)
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;

@@ -631,7 +631,9 @@ bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch
     const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
     if (onesweep || scan_table || passes > 4) return false;
     const bool big = staged && n >= SORT_BIG_N;
-    const int64_t nb = big ? (n + 2 * SORT_CHUNK - 1) / (2 * SORT_CHUNK) : sort_blocks(n);
+    const bool mid = !big && staged && n >= SORT_MID_N;
+    const int items = big ? 16 : (mid ? 8 : SORT_ITEMS);
+    const int64_t nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
     int gsize = 8;
     while ((int64_t)gsize * gsize < nb) gsize += 8;
     gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
@@ -660,7 +662,9 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     // 16 keys per thread for big inputs (longer digit runs per block -> better write coalescing; measured on the
     // tile sort: 94 -> 81 us at 4.1M pairs, 1.6 -> 1.2 ms at 55M); 8 below that, where 16 would leave CUs idle
     const bool big = grouped && staged && n >= SORT_BIG_N;
-    const int64_t nb = big ? (n + 2 * SORT_CHUNK - 1) / (2 * SORT_CHUNK) : sort_blocks(n);
+    const bool mid = !big && grouped && staged && n >= SORT_MID_N;
+    const int items = big ? 16 : (mid ? 8 : SORT_ITEMS);
+    const int64_t nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
     // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
     int gsize = 8;
     while ((int64_t)gsize * gsize < nb) gsize += 8;
@@ -704,6 +708,10 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
             if (big) {
                 hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
                 hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
+                                   mask, nb, hist, gs, gsize, ngroups);
+            } else if (mid) {
+                hipLaunchKernelGGL((radix_hist_kernel<8>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
+                hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
                                    mask, nb, hist, gs, gsize, ngroups);
             } else {
                 hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
