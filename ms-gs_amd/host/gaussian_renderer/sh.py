@@ -1,40 +1,45 @@
-"""SH evaluation for the convert_SHs_python path of render() — the polynomial of
-/root/reference/utils/sh_utils.py:57-112 (degrees 0-3), pinned against the reference's own
-eval_sh by tests/golden/sh_*.npz."""
+"""Real spherical harmonics up to degree 3 for the convert_SHs_python path of render(): colour = sum_k Y_k(dir) * sh_k,
+with the basis functions Y_k in the sign / ordering convention of the reference (/root/reference/utils/sh_utils.py:57-112),
+evaluated here as one basis tensor contracted with the coefficients.  Pinned against the reference's own eval_sh by
+tests/golden/sh_colors.npz."""
+import torch
 
-C0 = 0.28209479177387814
-C1 = 0.4886025119029199
-C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
-C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
-      -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
+Y00 = 0.28209479177387814                      # 1 / (2 sqrt(pi))
+Y1 = 0.4886025119029199                        # sqrt(3 / (4 pi))
+Y2 = (1.0925484305920792, 0.31539156525252005, 0.5462742152960396)
+Y3 = (0.5900435899266435, 2.890611442640554, 0.4570457994644658, 0.3731763325901154, 1.445305721320277)
+
+
+def sh_basis(deg, dirs):
+    """dirs [..., 3] unit vectors -> [..., (deg+1)^2] basis values."""
+    if not 0 <= deg <= 3:
+        raise ValueError(f"SH degree {deg} not in 0..3")
+    x, y, z = dirs.unbind(-1)
+    cols = [torch.full_like(x, Y00)]
+    if deg >= 1:
+        cols += [-Y1 * y, Y1 * z, -Y1 * x]
+    if deg >= 2:
+        x2, y2, z2 = x * x, y * y, z * z
+        cols += [Y2[0] * x * y, -Y2[0] * y * z, Y2[1] * (2.0 * z2 - x2 - y2), -Y2[0] * x * z, Y2[2] * (x2 - y2)]
+    if deg >= 3:
+        r = 4.0 * z2 - x2 - y2
+        cols += [-Y3[0] * y * (3.0 * x2 - y2), Y3[1] * x * y * z, -Y3[2] * y * r,
+                 Y3[3] * z * (2.0 * z2 - 3.0 * x2 - 3.0 * y2), -Y3[2] * x * r, Y3[4] * z * (x2 - y2),
+                 -Y3[0] * x * (x2 - 3.0 * y2)]
+    return torch.stack(cols, dim=-1)
 
 
 def eval_sh(deg, sh, dirs):
-    """sh [..., C, (deg+1)^2 or more], dirs [..., 3] unit -> [..., C]."""
-    assert 0 <= deg <= 3
-    assert sh.shape[-1] >= (deg + 1) ** 2
-    result = C0 * sh[..., 0]
-    if deg > 0:
-        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
-        result = result - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
-        if deg > 1:
-            xx, yy, zz = x * x, y * y, z * z
-            xy, yz, xz = x * y, y * z, x * z
-            result = (result + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5]
-                      + C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] + C2[3] * xz * sh[..., 7]
-                      + C2[4] * (xx - yy) * sh[..., 8])
-            if deg > 2:
-                result = (result + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10]
-                          + C3[2] * y * (4 * zz - xx - yy) * sh[..., 11]
-                          + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
-                          + C3[4] * x * (4 * zz - xx - yy) * sh[..., 13]
-                          + C3[5] * z * (xx - yy) * sh[..., 14] + C3[6] * x * (xx - 3 * yy) * sh[..., 15])
-    return result
+    """sh [..., C, K >= (deg+1)^2], dirs [..., 3] unit -> [..., C]."""
+    n = (deg + 1) ** 2
+    if sh.shape[-1] < n:
+        raise ValueError(f"{sh.shape[-1]} coefficients given, degree {deg} needs {n}")
+    return (sh[..., :n] * sh_basis(deg, dirs).unsqueeze(-2)).sum(dim=-1)
 
 
 def RGB2SH(rgb):
-    return (rgb - 0.5) / C0
+    return (rgb - 0.5) / Y00
 
 
 def SH2RGB(sh):
-    return sh * C0 + 0.5
+    return sh * Y00 + 0.5
