@@ -106,10 +106,13 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, aps = 0.f, adp = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
+    // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
+    // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
+    // instruction count), and per-lane selects take their condition from the mask for free
+    uint64_t alive = __builtin_amdgcn_ballot_w64(inside);
 
     for (int base = 0; base < len; base += BATCH) {
-        if (__syncthreads_and(done)) break;          // barrier also protects the LDS batch
+        if (__syncthreads_and(alive == 0)) break;    // barrier also protects the LDS batch
         const int n = min(BATCH, len - base);
         if (tid < n) {
             const uint32_t id = ids[range.x + base + tid];
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             cnt += __popcll(b);
         }
         for (int j = 0; j < cnt; ++j) {
-            if (__ballot(!done) == 0) break;
+            if (alive == 0) break;
             // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front
             //  of the LDS reads costs more than the two address instructions it saves)
             const int e = s_list[w][j];
@@ -137,11 +140,14 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             const float dx = r0.x - pxf, dy = r0.y - pyf;
             const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
             const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
-            const bool valid = !done && ev.p <= r1.y && alpha >= ALPHA_MIN;   // power <= 0, alpha >= 1/255
             const float test_T = __fmaf_rn(-T, alpha, T);
-            const bool stop = valid && test_T < T_MIN;
-            done = done || stop;
-            const bool blend = valid && !stop;
+            const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
+            const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
+            const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
+            const uint64_t validm = alive & m_pow & m_alpha;
+            const uint64_t stopm = validm & m_stop;
+            alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
+            const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
             const float wgt = blend ? alpha * T : 0.0f;
             C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
             adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
