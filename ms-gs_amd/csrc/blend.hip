@@ -259,8 +259,11 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
             const float a_raw = __builtin_amdgcn_exp2f(ev.p);
             const float alpha = fminf(0.99f, a_raw);
-            const bool valid = (uint32_t)(base + e) < last && ev.p <= r1.y && alpha >= ALPHA_MIN;
-            if (__ballot(valid) == 0) continue;
+            const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < last) &
+                                    __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
+                                    __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+            if (validm == 0) continue;
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
             const float alpha_m = valid ? alpha : 0.0f;            // masked lanes: no state change, zero output
             const float a_m = valid ? a_raw : 0.0f;
             const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -473,12 +476,16 @@ struct BwdSums { float v0, v1, v2, v3, v4, v5, v6, v7, v8; };
 // one (pixel, Gaussian) backward step accumulated into the per-lane partial sums; returns the lane's validity
 // (no wave-level early-out here: every ballot-driven branch is a VALU -> SALU -> branch round trip, and the
 // quadrant hit masks already removed the quadrants the record cannot touch)
-__device__ __forceinline__ bool bwd_quad_step(BwdQuad& s, BwdSums& v, const float4& r0, const float4& r1, float cb,
-                                              float dx, float dy, uint32_t pos0) {
+// (returns the lanes that contributed as a scalar mask: three ballots of direct comparisons and scalar ANDs — a ballot
+//  of a derived bool costs two VALU instructions, and the caller only needs "any lane?")
+__device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSums& v, const float4& r0, const float4& r1, float cb,
+                                                  float dx, float dy, uint32_t pos0) {
     const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
     const float a_raw = __builtin_amdgcn_exp2f(ev.p);
     const float alpha = fminf(0.99f, a_raw);
-    const bool valid = pos0 < s.last && ev.p <= r1.y && alpha >= ALPHA_MIN;
+    const uint64_t validm = __builtin_amdgcn_ballot_w64(pos0 < s.last) & __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
+                            __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+    const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
     const float alpha_m = valid ? alpha : 0.0f;               // masked lanes: no state change, zero output
     const float a_m = valid ? a_raw : 0.0f;
     const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -495,7 +502,7 @@ __device__ __forceinline__ bool bwd_quad_step(BwdQuad& s, BwdSums& v, const floa
     v.v2 = fmaf(h, dx, v.v2); v.v3 = fmaf(h, dy, v.v3); v.v4 = fmaf(qy, dy, v.v4);
     v.v5 += qq;
     v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
-    return valid;
+    return validm;
 }
 
 // DET = true (deterministic mode): instead of atomics, the nine sums of tile entry j (its position in the sorted instance
@@ -578,12 +585,12 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             const float cb = s_b[e];
             const float dx = r0.x - bxf, dy = r0.y - byf;
             BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            bool any = false;
+            uint64_t any = 0;
             if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
             if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
             if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
             if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
-            if (__ballot(any) == 0) continue;              // the ONE sync point per (tile, Gaussian)
+            if (any == 0) continue;                        // no lane contributed: nothing to reduce
             // ---- one 64-lane reduce-scatter per (tile, Gaussian) ----
             const float a0 = (p0 ? v.v4 : v.v0) + dpp_mov<0xB1>(p0 ? v.v0 : v.v4);
             const float a1 = (p0 ? v.v5 : v.v1) + dpp_mov<0xB1>(p0 ? v.v1 : v.v5);
