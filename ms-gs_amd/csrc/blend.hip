@@ -258,17 +258,16 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const float dx = r0.x - pxf, dy = r0.y - pyf;
             const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
             const float a_raw = __builtin_amdgcn_exp2f(ev.p);
-            const float alpha = fminf(0.99f, a_raw);
             const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < last) &
                                     __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
-                                    __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+                                    __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);   // <=> min(0.99, a_raw) >= 1/255
             if (validm == 0) continue;
             const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
-            const float alpha_m = valid ? alpha : 0.0f;            // masked lanes: no state change, zero output
-            const float a_m = valid ? a_raw : 0.0f;
-            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+            const float a_m = valid ? a_raw : 0.0f;                // the one select: a masked lane is the identity below
+            const float alpha_m = fminf(0.99f, a_m);
+            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha_m);
             const float Tn = T * inv;
-            T = valid ? Tn : T;
+            T = Tn;
             const float dch = alpha_m * Tn;
             const float d0 = r1.z - acc0, d1 = r1.w - acc1, d2 = cb - acc2;
             const float s = fmaf(d2, dL2, fmaf(d1, dL1, d0 * dL0));
@@ -482,15 +481,17 @@ __device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSums& v, const 
                                                   float dx, float dy, uint32_t pos0) {
     const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
     const float a_raw = __builtin_amdgcn_exp2f(ev.p);
-    const float alpha = fminf(0.99f, a_raw);
+    // alpha = min(0.99, a_raw) >= 1/255  <=>  a_raw >= 1/255
     const uint64_t validm = __builtin_amdgcn_ballot_w64(pos0 < s.last) & __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
-                            __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+                            __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
-    const float alpha_m = valid ? alpha : 0.0f;               // masked lanes: no state change, zero output
+    // ONE select masks the lane: with a_m = 0 everything downstream is the identity (alpha 0, 1/(1-0) = 1 exactly,
+    // T unchanged, zero contributions), so neither alpha nor T needs a select of its own
     const float a_m = valid ? a_raw : 0.0f;
-    const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+    const float alpha_m = fminf(0.99f, a_m);
+    const float inv = __builtin_amdgcn_rcpf(1.0f - alpha_m);
     const float Tn = s.T * inv;
-    s.T = valid ? Tn : s.T;
+    s.T = Tn;
     const float dch = alpha_m * Tn;
     const float d0 = r1.z - s.acc0, d1 = r1.w - s.acc1, d2 = cb - s.acc2;
     const float sm = fmaf(d2, s.dL2, fmaf(d1, s.dL1, d0 * s.dL0));
