@@ -121,22 +121,24 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
         }
         __syncthreads();
-        // per-wave compaction of the batch to this wave's quadrant
+        // per-wave compaction of the batch to this wave's quadrant; the list holds BYTE offsets of the 16-byte records
+        // (one shift less per pair evaluation)
         int cnt = 0;
 #pragma unroll
         for (int c = 0; c < BATCH / 64; ++c) {
             const int e = c * 64 + lane;
             const bool hit = e < n && ((s_mask[e] >> w) & 1u);
             const uint64_t b = __ballot(hit);
-            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)e;
+            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
             cnt += __popcll(b);
         }
-        for (int j = 0; j < cnt; ++j) {
-            if (alive == 0) break;
-            // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front
-            //  of the LDS reads costs more than the two address instructions it saves)
-            const int e = s_list[w][j];
-            const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+        uint32_t last_off = 0xFFFFFFFFu;                     // byte offset of the last entry blended in THIS batch
+        // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
+        //  the LDS reads costs more than the two address instructions it saves)
+        auto blend_entry = [&](uint32_t off) {
+            const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
+            const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
+            const float4 r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
             const float dx = r0.x - pxf, dy = r0.y - pyf;
             const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
             const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
@@ -152,8 +154,19 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
             adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
             T = blend ? test_T : T;
-            last = blend ? (uint32_t)(base + e + 1) : last;
+            last_off = blend ? off : last_off;
+        };
+        const uint16_t* lp = s_list[w];
+        int j = 0;
+        for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
+            if (alive == 0) break;
+            const uint32_t o0 = lp[j], o1 = lp[j + 1];
+            blend_entry(o0);
+            if (alive == 0) break;
+            blend_entry(o1);
         }
+        if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
+        if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
     if (inside) {
         const size_t N = (size_t)vp.W * vp.H;
