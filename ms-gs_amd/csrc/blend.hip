@@ -530,8 +530,8 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                                                                  const float* __restrict__ dL_dcolor,
                                                                  float* __restrict__ grad_rec) {
     __shared__ float4 s_r0[WB], s_r1[WB];
-    __shared__ float s_b[WB];
-    __shared__ uint32_t s_id[WB];
+    __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
+                                                           // address register serves every LDS read of an entry
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
         const int base = b * WB;
         const int n = min(WB, (int)tile_last - base);
         wave_fence();
-        s_r0[lane] = n0; s_r1[lane] = n1; s_b[lane] = n2.x; s_id[lane] = nid;
+        s_r0[lane] = n0; s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
         // quadrant hit masks of the batch as four 64-bit ballots; a record beyond the last blended entry of a
         // quadrant cannot matter to that quadrant
         const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             todo &= ~bit;
             const uint32_t pos0 = (uint32_t)(base + e);   // 0-based position in the tile list
             const float4 r0 = s_r0[e], r1 = s_r1[e];
-            const float cb = s_b[e];
+            const float cb = s_bi[e].x;
             const float dx = r0.x - bxf, dy = r0.y - byf;
             BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             uint64_t any = 0;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                 float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
                 if (alane) idst[aoff] = lane == 4 ? r2s : r01;
             } else {
-                const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
                 float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
                 if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r2s : r01);
             }
