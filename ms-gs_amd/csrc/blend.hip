@@ -563,8 +563,9 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
     const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
     const int vbase = 4 * (int)p0 + 2 * (int)p1;
-    const bool alane = lane < 5 || (lane >= 32 && lane < 36);          // lanes that issue the per-entry atomics
-    const int aoff = lane == 4 ? 8 : (lane < 4 ? vbase : vbase + 1);
+    const bool alane = lane < 9;                                         // lanes that issue the per-entry atomics
+    const int aoff = lane == 8 ? 8 : (lane < 4 ? vbase : vbase + 1);
+    const int xrow16 = (lane ^ 16) << 2, xrow32 = (lane ^ 32) << 2;     // ds_bpermute byte addresses of the partner lanes
 
     const int nb = ((int)tile_last + WB - 1) / WB;
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
@@ -616,24 +617,22 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             r2s += dpp_mov<0x4E>(r2s);
             r0s += dpp_mov<0x124>(r0s); r1s += dpp_mov<0x124>(r1s); r2s += dpp_mov<0x124>(r2s);
             r0s += dpp_mov<0x128>(r0s); r1s += dpp_mov<0x128>(r1s); r2s += dpp_mov<0x128>(r2s);
-            // across the four rows: r0s and r1s share ONE exchange per level (v_permlane32_swap hands the upper half of
-            // its first operand to the lower half of the second: the sum of the two results is r0s over both halves in
-            // lanes 0..31 and r1s over both halves in lanes 32..63; v_permlane16_swap then folds the row pairs)
-            typedef unsigned u2 __attribute__((ext_vector_type(2)));
-            const u2 h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0s), __float_as_uint(r1s), false, false);
-            const float hs = __uint_as_float(h.x) + __uint_as_float(h.y);
-            const u2 g = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
-            const float r01 = __uint_as_float(g.x) + __uint_as_float(g.y);
-            r2s = cross_row_allreduce(r2s);
-            // lanes 0..3: components vbase = (0 | 4 | 2 | 6) from r0s; lanes 32..35: vbase + 1 from r1s; lane 4: #8.
-            // The record id is wave-uniform: scalar address arithmetic, one atomic instruction.
+            // across the four rows through the LDS crossbar (ds_bpermute: lane ^ 16, lane ^ 32): two adds per sum on the
+            // VALU — the kernel's time is its VALU issue count, and v_permlane16/32_swap are multi-cycle there
+            r0s = cross_row_allreduce_bperm(r0s, xrow16, xrow32);
+            r1s = cross_row_allreduce_bperm(r1s, xrow16, xrow32);
+            r2s = cross_row_allreduce_bperm(r2s, xrow16, xrow32);
+            // every lane now holds the totals of its class: lanes 0..3 deliver components vbase = (0 | 4 | 2 | 6) from r0s,
+            // lanes 4..7 components vbase + 1 from r1s, lane 8 component 8 — one atomic instruction.
+            // The record id is wave-uniform: scalar address arithmetic.
+            const float outv = lane == 8 ? r2s : ((lane & 4) ? r1s : r0s);
             if (DET) {
                 float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
-                if (alane) idst[aoff] = lane == 4 ? r2s : r01;
+                if (alane) idst[aoff] = outv;
             } else {
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
                 float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-                if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r2s : r01);
+                if (alane) unsafeAtomicAdd(gdst + aoff, outv);
             }
         }
     }

@@ -235,6 +235,14 @@ __device__ __forceinline__ float cross_row_allreduce(float x) {
     return __uint_as_float(b.x) + __uint_as_float(b.y);
 }
 
+// the same sum through the LDS crossbar: no VALU cycles beyond the two adds (addr16 / addr32 = (lane ^ 16) << 2,
+// (lane ^ 32) << 2, computed once per kernel)
+__device__ __forceinline__ float cross_row_allreduce_bperm(float x, int addr16, int addr32) {
+    x += __int_as_float(__builtin_amdgcn_ds_bpermute(addr16, __float_as_int(x)));
+    x += __int_as_float(__builtin_amdgcn_ds_bpermute(addr32, __float_as_int(x)));
+    return x;
+}
+
 // every lane receives the wave total
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
     v += dpp_mov<0xB1>(v);            // xor 1
