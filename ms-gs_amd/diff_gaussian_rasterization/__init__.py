@@ -59,6 +59,24 @@ def _opt(t):
     return t
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on_device(dev):
+    """torch.cuda.device(dev) only when a switch is needed: entering and leaving that context costs ~15 us of host time,
+    twice per step on the path between the forward's host synchronisation and the backward launches, where the GPU
+    has only the forward's second stage queued."""
+    return _NO_SWITCH if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -150,7 +168,7 @@ def _forward_impl(call):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
     key = (dev.index, P, W, H)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         pixel_sizes = torch.empty(P, dtype=torch.float32, device=dev)
@@ -228,7 +246,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom, binning, image, D = ctx.state
         dev, P, K = call.device, call.P, call.K
         lib = _C.lib
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dL = _f32c(grad_color)
             g_means3D = torch.empty(P, 3, dtype=torch.float32, device=dev)
@@ -306,7 +324,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         dev, P = call.device, call.P
         lib = _C.lib
         m2_shape, dc_shape, rest_shape, op_shape = ctx.shapes
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dL = _f32c(grad_color)
             kx, kdc, krest, kop, ksc, krot = ctx.leaf_keys
@@ -439,7 +457,7 @@ class GaussianRasterizer(nn.Module):
                 raise RuntimeError("markVisible: positions must live on a HIP device")
             vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
             out = torch.empty(pos.shape[0], dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 _C.check(_C.lib.msgs_mark_visible(int(pos.shape[0]), _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out),
                                                   stream), "msgs_mark_visible")
@@ -464,7 +482,7 @@ class GaussianRasterizer(nn.Module):
             if P == 0:
                 return radii, pixel_sizes
             lib = _C.lib
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 geom = torch.empty(int(lib.msgs_geom_bytes(P)), dtype=torch.uint8, device=dev)
                 _C.check(lib.msgs_preprocess_only(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(pixel_sizes),
