@@ -14,10 +14,12 @@
 //
 // Both kernels are VALU-issue bound (rocprofv3 PMC, profiles/), so the per-(pixel, Gaussian) math is
 // kept minimal: the record carries the conic pre-scaled into the log2 domain and log2(opacity), so
-//     alpha_raw = exp2( dx*u + dy*w + log2 o ),  u = A'dx + B'dy,  w = C'dy + B'dx
-// is six FMA-class ops and one v_exp_f32; u and w double as the screen-space gradient directions in
-// the backward, and every per-Gaussian constant factor (0.5 W, -1/2, 1/o, 2 ln 2) is applied once per
-// Gaussian in preprocess_backward_kernel instead of once per pixel here.
+//     alpha_raw = exp2( A' dx^2 + 2B' dx dy + C' dy^2 + log2 o )
+// is six FMA-class ops and one v_exp_f32; the three monomials double as the weights of the conic sums in
+// the backward, the mean gradient is accumulated as (sum q dx, sum q dy), the colour recurrence is one
+// scalar (see blend_backward_kernel), and every per-Gaussian constant factor (0.5 W, -1/2, 1/o, 2 ln 2,
+// the conic in front of the mean sums) is applied once per Gaussian in preprocess_backward_kernel
+// instead of once per pixel here.
 //
 // Backward reduction: per (wave, record) the nine partial sums are reduced across the 64 lanes with a
 // DPP reduce-scatter (two halving steps inside quads: 8 -> 4 -> 2 values per lane) and a row_ror
@@ -44,16 +46,21 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_MIN = 0.0001f;
 
 // Shared by forward and backward so both take bit-identical skip decisions: explicit FMA order.
-//   p = dx*u + dy*w + lo   with u = A'dx + Bh'dy, w = C'dy + Bh'dx   (log2 of the unclamped alpha)
-struct PairEval { float u, w, p; };
-__device__ __forceinline__ PairEval eval_pair(float A, float Bh, float C, float lo, float dx, float dy) {
+//   p = A' dx^2 + B2' dx dy + C' dy^2 + lo     (log2 of the unclamped alpha; B2' = 2 Bh', doubled when the record is
+// staged into LDS).  The three monomials double as the weights of the backward's conic sums, and the mean gradient is
+// accumulated as (sum q dx, sum q dy) — preprocess_backward_kernel applies the per-Gaussian (A', Bh', C') to them —
+// so the backward needs no product beyond these.
+struct PairEval { float dxx, dxy, dyy, p; };
+__device__ __forceinline__ PairEval eval_pair(float A, float B2, float C, float lo, float dx, float dy) {
 #pragma clang fp contract(off)   // only the explicit FMAs below; nothing else may be fused differently per kernel
     PairEval e;
-    e.u = __fmaf_rn(A, dx, __fmul_rn(Bh, dy));
-    e.w = __fmaf_rn(C, dy, __fmul_rn(Bh, dx));
-    e.p = __fmaf_rn(dx, e.u, __fmaf_rn(dy, e.w, lo));
+    e.dxx = __fmul_rn(dx, dx);
+    e.dxy = __fmul_rn(dx, dy);
+    e.dyy = __fmul_rn(dy, dy);
+    e.p = __fmaf_rn(A, e.dxx, __fmaf_rn(B2, e.dxy, __fmaf_rn(C, e.dyy, lo)));
     return e;
 }
+__device__ __forceinline__ float4 doubled_w(const float4& r) { return make_float4(r.x, r.y, r.z, r.w + r.w); }
 
 // quadrant hit mask of one record (bit q: quadrant q = qx + 2*qy of the tile at (tx0, ty0))
 __device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, float C, float tau2, float tx0, float ty0) {
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
         if (tid < n) {
             const uint32_t id = ids[range.x + base + tid];
             const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
-            s_r0[tid] = r0; s_r1[tid] = r1; s_r2[tid] = r2;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
         }
         __syncthreads();
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
 // ---------------------------------------------------------------------------------------------
 // Gradient record components accumulated here (scaled to dL/d{mean2D, conic, opacity} per Gaussian
 // in preprocess_backward_kernel):
-//   [0] sum q u   [1] sum q w   [2] sum q dx dx   [3] sum q dx dy   [4] sum q dy dy   [5] sum q
+//   [0] sum q dx  [1] sum q dy  [2] sum q dx dx   [3] sum q dx dy   [4] sum q dy dy   [5] sum q
 //   [6..8] sum alpha T dL/dC_c                     with q = alpha_raw * dL/dalpha
 constexpr int ACC_STRIDE = BATCH + 1;
 
@@ -224,7 +231,6 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     const uint32_t last = inside ? n_contrib[pix] : 0u;
     float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
     if (inside) { dL0 = dL_dcolor[pix]; dL1 = dL_dcolor[N + pix]; dL2 = dL_dcolor[2 * N + pix]; }
-    const float nTf_bg = -T_final * (vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2);
 
     const uint32_t wave_last = wave_max_u32(last);
     if (lane == 0) s_wmax[w] = wave_last;
@@ -235,7 +241,11 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     const uint32_t tile_last = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
     float T = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;       // accum_rec as the NEXT (nearer) entry will see it
+    // S = sum_c dL/dC_c * (colour composited BEHIND the current entry, background included, normalised by the
+    // transmittance in front of it).  dL/dalpha_i = T_i (g_i - S_i) with g_i = sum_c dL/dC_c colour_i,c, and
+    // S_{i-1} = S_i + alpha_i (g_i - S_i): the three per-channel recurrences of the textbook form collapse into one
+    // scalar, and starting it at bg . dL/dC absorbs the separate background term (-T_final bg.dL / (1 - alpha_i)).
+    float S = vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2;
     const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
     const int vbase = 4 * (int)p0 + 2 * (int)p1;
     const int sub = lane & 15;                       // position inside the 16-lane row
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const uint32_t id = ids[range.x + base + tid];
             const float4 r0 = rec[id].r0, r1 = rec[id].r1;
             const float4 r2 = rec[id].r2;
-            s_r0[tid] = r0; s_r1[tid] = r1; s_b[tid] = r2.x; s_id[tid] = id;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_b[tid] = r2.x; s_id[tid] = id;
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
         }
         __syncthreads();
@@ -282,15 +292,13 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const float Tn = T * inv;
             T = Tn;
             const float dch = alpha_m * Tn;
-            const float d0 = r1.z - acc0, d1 = r1.w - acc1, d2 = cb - acc2;
-            const float s = fmaf(d2, dL2, fmaf(d1, dL1, d0 * dL0));
-            const float dL_dalpha = fmaf(s, Tn, nTf_bg * inv);
-            acc0 = fmaf(alpha_m, d0, acc0); acc1 = fmaf(alpha_m, d1, acc1); acc2 = fmaf(alpha_m, d2, acc2);
+            const float sm = fmaf(cb, dL2, fmaf(r1.w, dL1, r1.z * dL0)) - S;
+            const float dL_dalpha = sm * Tn;
+            S = fmaf(alpha_m, sm, S);
             const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
-            const float h = q * dx, qy = q * dy;
             float v[9];
-            v[0] = q * ev.u; v[1] = q * ev.w;
-            v[2] = h * dx; v[3] = h * dy; v[4] = qy * dy;
+            v[0] = q * dx; v[1] = q * dy;
+            v[2] = q * ev.dxx; v[3] = q * ev.dxy; v[4] = q * ev.dyy;
             v[5] = q;
             v[6] = dch * dL0; v[7] = dch * dL1; v[8] = dch * dL2;
             // ---- reduce-scatter of v[0..7] inside quads, v[8] all-reduced alongside ----
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
     for (int base = 0; base < len && alive; base += WB) {
         const int n = min(WB, len - base);
         wave_fence();                                     // previous batch fully consumed
-        s_r0[lane] = n0; s_r1[lane] = n1; s_r2[lane] = n2;
+        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_r2[lane] = n2;
         // quadrant hit masks of the whole batch as four 64-bit ballots (bit e = record e): wave-uniform, in SGPRs
         const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
         const uint64_t h0 = __ballot(mymask & 1u), h1 = __ballot(mymask & 2u), h2 = __ballot(mymask & 4u),
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
 }
 
 struct BwdQuad {
-    float T, acc0, acc1, acc2, dL0, dL1, dL2, nTf_bg;
+    float T, S, dL0, dL1, dL2;       // S: see blend_backward_kernel
     uint32_t last;
 };
 
@@ -506,14 +514,12 @@ __device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSums& v, const 
     const float Tn = s.T * inv;
     s.T = Tn;
     const float dch = alpha_m * Tn;
-    const float d0 = r1.z - s.acc0, d1 = r1.w - s.acc1, d2 = cb - s.acc2;
-    const float sm = fmaf(d2, s.dL2, fmaf(d1, s.dL1, d0 * s.dL0));
-    const float dL_dalpha = fmaf(sm, Tn, s.nTf_bg * inv);
-    s.acc0 = fmaf(alpha_m, d0, s.acc0); s.acc1 = fmaf(alpha_m, d1, s.acc1); s.acc2 = fmaf(alpha_m, d2, s.acc2);
+    const float sm = fmaf(cb, s.dL2, fmaf(r1.w, s.dL1, r1.z * s.dL0)) - s.S;
+    const float dL_dalpha = sm * Tn;
+    s.S = fmaf(alpha_m, sm, s.S);
     const float qq = a_m * dL_dalpha;                         // Q6: gradient passes the 0.99 clamp
-    const float h = qq * dx, qy = qq * dy;
-    v.v0 = fmaf(qq, ev.u, v.v0); v.v1 = fmaf(qq, ev.w, v.v1);
-    v.v2 = fmaf(h, dx, v.v2); v.v3 = fmaf(h, dy, v.v3); v.v4 = fmaf(qy, dy, v.v4);
+    v.v0 = fmaf(qq, dx, v.v0); v.v1 = fmaf(qq, dy, v.v1);
+    v.v2 = fmaf(qq, ev.dxx, v.v2); v.v3 = fmaf(qq, ev.dxy, v.v3); v.v4 = fmaf(qq, ev.dyy, v.v4);
     v.v5 += qq;
     v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
     return validm;
@@ -554,8 +560,8 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             s.dL0 = inside ? dL_dcolor[pix] : 0.f;
             s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
             s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
-            s.nTf_bg = -Tf * (vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2);
-            s.T = Tf; s.acc0 = s.acc1 = s.acc2 = 0.f;
+            s.S = vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2;
+            s.T = Tf;
             return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
         };
         ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
         const int base = b * WB;
         const int n = min(WB, (int)tile_last - base);
         wave_fence();
-        s_r0[lane] = n0; s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
+        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
         // quadrant hit masks of the batch as four 64-bit ballots; a record beyond the last blended entry of a
         // quadrant cannot matter to that quadrant
         const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;

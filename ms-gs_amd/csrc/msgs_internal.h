@@ -24,7 +24,7 @@ constexpr int WAVE = 64;
 struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2; };
 
 // Per-Gaussian 2-D gradient record accumulated by the blend backward: 12 floats = 48 B.
-//   [0] sum q u  [1] sum q w  [2] sum q dx^2  [3] sum q dx dy  [4] sum q dy^2  [5] sum q  [6..8] dL/drgb
+//   [0] sum q dx  [1] sum q dy  [2] sum q dx^2  [3] sum q dx dy  [4] sum q dy^2  [5] sum q  [6..8] dL/drgb
 //   [9..11] pad, with q = alpha_raw dL/dalpha; preprocess_backward_kernel turns [0..5] into
 //   dL/dmean2D (NDC-ish units), dL/dconic (A, B-half, C) and dL/dopacity with per-Gaussian factors.
 constexpr int GRAD_REC_FLOATS = 12;

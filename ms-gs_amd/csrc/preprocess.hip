@@ -603,10 +603,8 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
         const float4 ga = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 0];
         const float4 gb = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 1];
         const float4 gc = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 2];
-        // blend_backward_kernel accumulates [sum q u, sum q w, sum q dx^2, sum q dx dy, sum q dy^2, sum q]
+        // blend_backward_kernel accumulates [sum q dx, sum q dy, sum q dx^2, sum q dx dy, sum q dy^2, sum q]
         // with q = alpha_raw dL/dalpha; the per-Gaussian constant factors are applied here (blend.hip).
-        constexpr float LN2 = 0.69314718055994530942f;
-        g2x = ga.x * (LN2 * vp.W); g2y = ga.y * (LN2 * vp.H);           // 2 ln2 * 0.5 W  (NDC-ish units)
         const float gA = -0.5f * ga.z, gBh = -0.5f * ga.w, gC = -0.5f * gb.x;
         const float o_in = act_opacity(g, i);
         dopac = o_in > 0.f ? gb.y / o_in : 0.f;                         // (q / (o w)) * w, SPEC M4
@@ -642,6 +640,16 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
         compute_cov2d(t, vp, cov3D, cm.V, c2);
         const float ca = c2.a, cb = c2.b, cc = c2.c;
         const float denom = ca * cc - cb * cb;
+        {
+            // dL/dmean2D = sum q (u, w) with u = A' dx + Bh' dy, w = C' dy + Bh' dx and (A', Bh', C') the log2-scaled
+            // conic exactly as preprocess_kernel built it for the record
+            constexpr float KLOG = -0.72134752044448170368f;            // -1/2 log2(e)
+            constexpr float LN2 = 0.69314718055994530942f;
+            const float det_inv = 1.f / denom;
+            const float sA = KLOG * (cc * det_inv), sBh = KLOG * (-cb * det_inv), sC = KLOG * (ca * det_inv);
+            g2x = (sA * ga.x + sBh * ga.y) * (LN2 * vp.W);              // 2 ln2 * 0.5 W  (NDC-ish units)
+            g2y = (sC * ga.y + sBh * ga.x) * (LN2 * vp.H);
+        }
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
         float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
         if (denom2inv != 0.f) {
