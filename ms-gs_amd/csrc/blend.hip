@@ -22,12 +22,11 @@
 // instead of once per pixel here.
 //
 // Backward reduction: per (wave, record) the nine partial sums are reduced across the 64 lanes with a
-// DPP reduce-scatter (two halving steps inside quads: 8 -> 4 -> 2 values per lane) and a row_ror
-// all-reduce inside each 16-lane row, a cross-row all-reduce with v_permlane16/32_swap, and two
-// global_atomic_add_f32 instructions (4 + 5 lanes) into the 48-byte per-Gaussian gradient record — one
-// atomic per (quadrant, Gaussian, component) instead of the reference's one per (pixel, Gaussian,
-// component).  (Template variant LDS_ACC accumulates the four row partials in LDS and commits once per
-// batch; measured slower, kept for A/B runs.)
+// hand-scheduled DPP reduce-scatter inside each 16-lane row (row_reduce_scatter9: 8 -> 4 -> 2 -> 1 values per
+// lane, the ninth riding on the duplicate lanes), one cross-row all-reduce of the single remaining value, and ONE
+// global_atomic_add_f32 instruction from nine lanes into the 48-byte per-Gaussian gradient record — one atomic per
+// (quadrant or tile, Gaussian, component) instead of the reference's one per (pixel, Gaussian, component).
+// (An LDS accumulator committed once per batch was measured slower and removed, profiles/r1_notes.md.)
 //
 // Roofline: HBM-bound by contract (BASELINE.json); algorithmic bytes K6 = 48*D_trav + 28*N + 8*tiles,
 // K7 = 48*D_trav + 20*N + 36*V.
@@ -191,13 +190,60 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
+// 64 lanes x 9 partial sums -> ONE value per lane holding a 16-lane-row total, hand-scheduled DPP (the backward's
+// time is its VALU instruction count; this is 21 instructions against 34 for selects + quad_perm exchanges):
+//   * v0..v7 are reduce-scattered 8 -> 4 -> 2 -> 1 values per lane: across the half rows (row_ror:8) and across
+//     neighbouring quads (row_half_mirror) the "keep mine / add the partner's" choice is the DPP bank mask — a bank is
+//     a quad of lanes, so a second, bank-masked add overwrites the half of the lanes that keep the other operand and no
+//     select is needed; only the last level (lane parity inside a quad) takes the two selects.
+//   * v8 is all-reduced inside the row (4 adds) and rides on the lanes whose bit 1 is set, which would otherwise hold a
+//     duplicate of their lane ^ 2 neighbour.
+// Result: lane l holds the row total of component comp(l) = 4*((l>>3)&1) + 2*((l>>2)&1) + (l&1) when (l & 2) == 0, and
+// the row total of component 8 when (l & 2) != 0.  The caller adds the four rows.
+// All hazards (VALU write -> DPP read needs two wait states) are resolved by the instruction order inside the block;
+// the leading s_nop covers whatever the compiler scheduled right before it.
+struct BwdSums { float v0, v1, v2, v3, v4, v5, v6, v7, v8; };
+__device__ __forceinline__ float row_reduce_scatter9(const BwdSums& v) {
+    float a0, a1, a2, a3, b0, b1, t8, keep, send, c;
+    const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, bit1 = 0xCCCCCCCCCCCCCCCCull;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[a0], %[v0], %[v0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a1], %[v1], %[v1] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a2], %[v2], %[v2] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a3], %[v3], %[v3] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a0], %[v4], %[v4] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a1], %[v5], %[v5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a2], %[v6], %[v6] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a3], %[v7], %[v7] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[t8], %[v8], %[v8] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[b0], %[a0], %[a0] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[b1], %[a1], %[a1] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[b0], %[a2], %[a2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[b1], %[a3], %[a3] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[t8], %[t8], %[t8] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %[send], %[b1], %[b0], %[odd]\n\t"
+        "v_cndmask_b32_e64 %[keep], %[b0], %[b1], %[odd]\n\t"
+        "v_add_f32_dpp %[t8], %[t8], %[t8] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[c], %[send], %[keep] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[t8], %[t8], %[t8] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[c], %[c], %[c] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %[c], %[c], %[t8], %[bit1]"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1),
+          [t8] "=&v"(t8), [keep] "=&v"(keep), [send] "=&v"(send), [c] "=&v"(c)
+        : [v0] "v"(v.v0), [v1] "v"(v.v1), [v2] "v"(v.v2), [v3] "v"(v.v3), [v4] "v"(v.v4), [v5] "v"(v.v5),
+          [v6] "v"(v.v6), [v7] "v"(v.v7), [v8] "v"(v.v8), [odd] "s"(odd), [bit1] "s"(bit1));
+    return c;
+}
+// component (0..8) that lane l of a row delivers after row_reduce_scatter9
+__device__ __forceinline__ uint32_t row_reduce_component(int l) {
+    return (l & 2) ? 8u : (uint32_t)(4 * ((l >> 3) & 1) + 2 * ((l >> 2) & 1) + (l & 1));
+}
 // Gradient record components accumulated here (scaled to dL/d{mean2D, conic, opacity} per Gaussian
 // in preprocess_backward_kernel):
 //   [0] sum q dx  [1] sum q dy  [2] sum q dx dx   [3] sum q dx dy   [4] sum q dy dy   [5] sum q
 //   [6..8] sum alpha T dL/dC_c                     with q = alpha_raw * dL/dalpha
-constexpr int ACC_STRIDE = BATCH + 1;
-
-template <bool LDS_ACC>
 __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                              const uint32_t* __restrict__ ids,
                                                              const uint2* __restrict__ ranges,
@@ -211,7 +257,6 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     __shared__ uint32_t s_mask[BATCH];
     __shared__ uint16_t s_list[4][BATCH];
     __shared__ uint32_t s_wmax[4];
-    __shared__ float s_acc[LDS_ACC ? 9 * ACC_STRIDE : 1];
 
     const int num_tiles = vp.gx * vp.gy;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -234,9 +279,6 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
 
     const uint32_t wave_last = wave_max_u32(last);
     if (lane == 0) s_wmax[w] = wave_last;
-    if (LDS_ACC) {
-        for (int k = tid; k < 9 * ACC_STRIDE; k += 256) s_acc[k] = 0.f;
-    }
     __syncthreads();
     const uint32_t tile_last = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
@@ -246,11 +288,8 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     // S_{i-1} = S_i + alpha_i (g_i - S_i): the three per-channel recurrences of the textbook form collapse into one
     // scalar, and starting it at bg . dL/dC absorbs the separate background term (-T_final bg.dL / (1 - alpha_i)).
     float S = vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2;
-    const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
-    const int vbase = 4 * (int)p0 + 2 * (int)p1;
-    const int sub = lane & 15;                       // position inside the 16-lane row
-    const bool alane = lane < 5 || (lane >= 32 && lane < 36);          // lanes that issue the per-entry atomics
-    const int aoff = lane == 4 ? 8 : (lane < 4 ? vbase : vbase + 1);
+    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);        // the nine lanes that issue the per-entry atomics
+    const uint32_t aoff = row_reduce_component(lane);
 
     const int nb = ((int)tile_last + BATCH - 1) / BATCH;
     for (int b = nb - 1; b >= 0; --b) {
@@ -296,64 +335,13 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const float dL_dalpha = sm * Tn;
             S = fmaf(alpha_m, sm, S);
             const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
-            float v[9];
-            v[0] = q * dx; v[1] = q * dy;
-            v[2] = q * ev.dxx; v[3] = q * ev.dxy; v[4] = q * ev.dyy;
-            v[5] = q;
-            v[6] = dch * dL0; v[7] = dch * dL1; v[8] = dch * dL2;
-            // ---- reduce-scatter of v[0..7] inside quads, v[8] all-reduced alongside ----
-            float a[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float keep = p0 ? v[4 + k] : v[k];
-                const float send = p0 ? v[k] : v[4 + k];
-                a[k] = keep + dpp_mov<0xB1>(send);
-            }
-            float r[3];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float keep = p1 ? a[2 + k] : a[k];
-                const float send = p1 ? a[k] : a[2 + k];
-                r[k] = keep + dpp_mov<0x4E>(send);
-            }
-            r[2] = v[8] + dpp_mov<0xB1>(v[8]);
-            r[2] += dpp_mov<0x4E>(r[2]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {                          // all-reduce inside each 16-lane row
-                r[k] += dpp_mov<0x124>(r[k]);
-                r[k] += dpp_mov<0x128>(r[k]);
-            }
-            // positions 0..3 of every row hold components (vbase, vbase+1) = (0,1 | 4,5 | 2,3 | 6,7), position 4 adds #8
-            if (LDS_ACC) {
-                if (sub < 4) atomicAdd(&s_acc[vbase * ACC_STRIDE + e], r[0]);
-                if (sub < 5) atomicAdd(&s_acc[(sub == 4 ? 8 : vbase + 1) * ACC_STRIDE + e], sub == 4 ? r[2] : r[1]);
-            } else {
-                // r[0] and r[1] share one exchange per level, scalar record address, one atomic instruction
-                // (same scheme as the one-wave-per-tile kernel below)
-                typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                const u2 hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
-                const float hs = __uint_as_float(hx.x) + __uint_as_float(hx.y);
-                const u2 gx = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs), __float_as_uint(hs), false, false);
-                const float r01 = __uint_as_float(gx.x) + __uint_as_float(gx.y);
-                r[2] = cross_row_allreduce(r[2]);
-                const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
-                float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-                if (alane) unsafeAtomicAdd(gdst + aoff, lane == 4 ? r[2] : r01);
-            }
-        }
-        if (LDS_ACC) {
-            __syncthreads();
-            // commit the batch: 16 lanes per record (9 active) -> 4 records per wave instruction
-            for (int i = tid; i < n * 16; i += 256) {
-                const int e = i >> 4, k = i & 15;
-                if (k < 9) {
-                    const float val = s_acc[k * ACC_STRIDE + e];
-                    if (val != 0.0f) {
-                        s_acc[k * ACC_STRIDE + e] = 0.0f;
-                        unsafeAtomicAdd(grad_rec + (size_t)s_id[e] * GRAD_REC_FLOATS + k, val);
-                    }
-                }
-            }
+            const BwdSums v = {q * dx, q * dy, q * ev.dxx, q * ev.dxy, q * ev.dyy, q, dch * dL0, dch * dL1, dch * dL2};
+            // rows by DPP, the four rows with v_permlane16/32_swap (in this latency-bound regime they beat ds_bpermute,
+            // profiles/r1_notes.md); scalar record address, one atomic instruction from nine lanes
+            const float outv = cross_row_allreduce(row_reduce_scatter9(v));
+            const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+            float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+            if (alane) unsafeAtomicAdd(gdst + aoff, outv);
         }
     }
 }
@@ -491,8 +479,6 @@ struct BwdQuad {
     uint32_t last;
 };
 
-struct BwdSums { float v0, v1, v2, v3, v4, v5, v6, v7, v8; };
-
 // one (pixel, Gaussian) backward step accumulated into the per-lane partial sums; returns the lane's validity
 // (no wave-level early-out here: every ballot-driven branch is a VALU -> SALU -> branch round trip, and the
 // quadrant hit masks already removed the quadrants the record cannot touch)
@@ -567,10 +553,8 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
         ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
     }
     const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
-    const bool p0 = lane & 1, p1 = (lane >> 1) & 1;
-    const int vbase = 4 * (int)p0 + 2 * (int)p1;
-    const bool alane = lane < 9;                                         // lanes that issue the per-entry atomics
-    const int aoff = lane == 8 ? 8 : (lane < 4 ? vbase : vbase + 1);
+    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);         // the nine lanes that issue the per-entry atomics
+    const uint32_t aoff = row_reduce_component(lane);
     const int xrow16 = (lane ^ 16) << 2, xrow32 = (lane ^ 32) << 2;     // ds_bpermute byte addresses of the partner lanes
 
     const int nb = ((int)tile_last + WB - 1) / WB;
@@ -612,30 +596,17 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
             if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
             if (any == 0) continue;                        // no lane contributed: nothing to reduce
-            // ---- one 64-lane reduce-scatter per (tile, Gaussian) ----
-            const float a0 = (p0 ? v.v4 : v.v0) + dpp_mov<0xB1>(p0 ? v.v0 : v.v4);
-            const float a1 = (p0 ? v.v5 : v.v1) + dpp_mov<0xB1>(p0 ? v.v1 : v.v5);
-            const float a2 = (p0 ? v.v6 : v.v2) + dpp_mov<0xB1>(p0 ? v.v2 : v.v6);
-            const float a3 = (p0 ? v.v7 : v.v3) + dpp_mov<0xB1>(p0 ? v.v3 : v.v7);
-            float r0s = (p1 ? a2 : a0) + dpp_mov<0x4E>(p1 ? a0 : a2);
-            float r1s = (p1 ? a3 : a1) + dpp_mov<0x4E>(p1 ? a1 : a3);
-            float r2s = v.v8 + dpp_mov<0xB1>(v.v8);
-            r2s += dpp_mov<0x4E>(r2s);
-            r0s += dpp_mov<0x124>(r0s); r1s += dpp_mov<0x124>(r1s); r2s += dpp_mov<0x124>(r2s);
-            r0s += dpp_mov<0x128>(r0s); r1s += dpp_mov<0x128>(r1s); r2s += dpp_mov<0x128>(r2s);
-            // across the four rows through the LDS crossbar (ds_bpermute: lane ^ 16, lane ^ 32): two adds per sum on the
-            // VALU — the kernel's time is its VALU issue count, and v_permlane16/32_swap are multi-cycle there
-            r0s = cross_row_allreduce_bperm(r0s, xrow16, xrow32);
-            r1s = cross_row_allreduce_bperm(r1s, xrow16, xrow32);
-            r2s = cross_row_allreduce_bperm(r2s, xrow16, xrow32);
-            // every lane now holds the totals of its class: lanes 0..3 deliver components vbase = (0 | 4 | 2 | 6) from r0s,
-            // lanes 4..7 components vbase + 1 from r1s, lane 8 component 8 — one atomic instruction.
-            // The record id is wave-uniform: scalar address arithmetic.
-            const float outv = lane == 8 ? r2s : ((lane & 4) ? r1s : r0s);
+            // ---- one 64-lane reduction per (tile, Gaussian): rows by DPP (row_reduce_scatter9), then the four rows
+            // through the LDS crossbar (ds_bpermute lane ^ 16, lane ^ 32: two adds on the VALU; v_permlane16/32_swap are
+            // multi-cycle there).  Lanes 0,1,4,5,8,9,12,13 then hold components 0..7 and lane 2 component 8: one atomic
+            // instruction; the record id is wave-uniform (scalar address arithmetic).
+            const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
             if (DET) {
                 float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
                 if (alane) idst[aoff] = outv;
             } else {
+                // (record id through v_readlane of a register copy and a scalar-base atomic — no 64-bit VALU multiply-add —
+                //  were measured: no difference, 357..382 us for all four combinations)
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
                 float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
                 if (alane) unsafeAtomicAdd(gdst + aoff, outv);
@@ -715,18 +686,11 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    // Default: cross-row reduction in registers + direct global atomics (664 us at C3).  MSGS_BWD_LDS_ACC=1
-    // selects the per-batch LDS accumulator variant (4x fewer global atomics but an extra barrier and a
-    // flush pass per batch: 903 us at C3, profiles/r1_notes.md) for A/B measurements.
-    static const bool direct = [] { const char* e = getenv("MSGS_BWD_LDS_ACC"); return !(e && e[0] == '1'); }();
     if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
-    else if (direct)
-        hipLaunchKernelGGL(blend_backward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
-                           n_contrib, dL_dcolor, grad_rec);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
+        hipLaunchKernelGGL(blend_backward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
     return hipGetLastError();
 }

@@ -46,8 +46,12 @@ def test_bitwise_reproducible_and_close_to_atomic_mode(ms, fused, deterministic)
         c = _grads(sc, cam, st, dL, fused)
         for k in a:
             # summation order only; 3e-4 because two different reduction trees may sit on opposite sides of the exact
-            # value (each is within 1e-4 of the oracle: tests/test_parity_gpu.py, test_deterministic_backward_vs_oracle)
-            assert rel_err(a[k], c[k]) <= 3e-4, (k, gen)
+            # value (each is within 1e-4 of the oracle: tests/test_parity_gpu.py, test_deterministic_backward_vs_oracle).
+            # The conic -> covariance -> (scale, rotation) chain amplifies that noise on these random scenes' most
+            # elongated Gaussian: over 40 such scenes every path sits at median 1.3e-5 / p90 1e-4 / max 2.4e-4 from
+            # the float32 oracle (tools/diag_det_vs_atomic.py), so two paths can be 5e-4 apart there
+            tol = 1e-3 if k in ("_scaling", "_rotation") else 3e-4
+            assert rel_err(a[k], c[k]) <= tol, (k, gen)
     dgr._C.lib.msgs_set_backward_generation(0)
     dgr.set_deterministic(True)
 
