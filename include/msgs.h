@@ -219,6 +219,15 @@ size_t msgs_backward_scratch_bytes_deterministic(int32_t P, int64_t D);
  * value from MSGS_BWD_GEN.  Returns the previous value. */
 int msgs_set_backward_generation(int32_t gen);
 
+/* Pixel granularity of the blend kernels' workgroups: 0 (default) = by tile count, 1 = always one wave64 per 8x8 pixel
+ * quadrant (forward) / per quadrant or tile (backward, see above), 2 = always the fine-grained kernels — sixteen waves
+ * per 16x16 tile, one per 4x4 pixel sub-block — which the default picks below 600 (forward) / 300 (backward) tiles (the low levels of the
+ * resolution pyramid MS-GS trains on, utils/camera_utils.py:38-39), where the blend kernels are latency-bound and a
+ * shorter per-wave entry list matters more than idle lanes.  Same per-pixel arithmetic in the same order: forward
+ * results are bit-identical across granularities.  2 overrides msgs_set_backward_generation.  Initial value from
+ * MSGS_BLEND_GRANULARITY.  Returns the previous value. */
+int msgs_set_blend_granularity(int32_t mode);
+
 /* msgs_forward: both stages in ONE call.  Runs stage 1, synchronises once to learn the instance count D, and — when
  * the caller's `binning` and `scratch2` buffers are large enough for D (msgs_binning_bytes(D, W, H),
  * msgs_stage2_scratch_bytes(D, W, H)) — launches stage 2 immediately, with no allocation and no second library call

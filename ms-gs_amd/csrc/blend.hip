@@ -187,6 +187,132 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
     }
 }
 
+// Fine-grained variant for FEW tiles (low pyramid levels): sixteen wave64s per tile, each owning one 4x4 pixel sub-block
+// (lanes 0..15).  With fewer than ~500 tiles the kernel above is latency-bound — one wave per SIMD at best, and a
+// pixel's list is inherently sequential — so its time is the length of the longest per-wave entry chain; splitting a
+// quadrant into four sub-blocks with their own exact hit lists shortens that chain (an entry reaches a 4x4 block far
+// less often than an 8x8 one) at the price of idle lanes, which are free in that regime.  Same arithmetic per pixel in
+// the same order: results are bit-identical to blend_forward_kernel.
+__global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                            const uint32_t* __restrict__ ids,
+                                                            const uint2* __restrict__ ranges,
+                                                            float* __restrict__ out_color,
+                                                            float* __restrict__ out_ps,
+                                                            float* __restrict__ out_depth,
+                                                            float* __restrict__ final_T,
+                                                            uint32_t* __restrict__ n_contrib) {
+    __shared__ float4 s_r0[BATCH], s_r1[BATCH], s_r2[BATCH];
+    __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
+    __shared__ uint16_t s_list[16][BATCH];
+
+    const int num_tiles = vp.gx * vp.gy;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int px = tx * TILE + (w & 3) * 4 + (lane & 3);
+    const int py = ty * TILE + (w >> 2) * 4 + ((lane >> 2) & 3);
+    const bool inside = lane < 16 && px < vp.W && py < vp.H;     // lanes 16..63 idle: this variant buys latency, not throughput
+    const float pxf = (float)px, pyf = (float)py;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, aps = 0.f, adp = 0.f;
+    uint32_t last = 0;
+    // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
+    // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
+    // instruction count), and per-lane selects take their condition from the mask for free
+    uint64_t alive = __builtin_amdgcn_ballot_w64(inside);
+
+    for (int base = 0; base < len; base += BATCH) {
+        if (__syncthreads_and(alive == 0)) break;    // barrier also protects the LDS batch
+        const int n = min(BATCH, len - base);
+        if (tid < n) {
+            const uint32_t id = ids[range.x + base + tid];
+            const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
+        }
+        __syncthreads();
+        {   // classification spread over the 1024 threads: thread -> (record e, sub-block row g), four 4x4 rectangles each
+            const int e = tid & (BATCH - 1), g = tid >> 8;
+            uint32_t m = 0;
+            if (e < n) {
+                const float4 r0 = s_r0[e];
+                const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                if (!(tau2 > -1.0e38f)) m = 0xFu;
+                else {
+                    const float y0 = ty0 + (float)(4 * g);
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) {
+                        const float x0 = tx0 + (float)(4 * sx);
+                        if (levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, x0, x0 + 3.0f, y0, y0 + 3.0f)) m |= 1u << sx;
+                    }
+                }
+            }
+            s_mask[g][e] = (uint8_t)m;
+        }
+        __syncthreads();
+        // per-wave compaction of the batch to this wave's quadrant; the list holds BYTE offsets of the 16-byte records
+        // (one shift less per pair evaluation)
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < BATCH / 64; ++c) {
+            const int e = c * 64 + lane;
+            const bool hit = e < n && ((s_mask[w >> 2][e] >> (w & 3)) & 1u);
+            const uint64_t b = __ballot(hit);
+            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
+            cnt += __popcll(b);
+        }
+        uint32_t last_off = 0xFFFFFFFFu;                     // byte offset of the last entry blended in THIS batch
+        // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
+        //  the LDS reads costs more than the two address instructions it saves)
+        auto blend_entry = [&](uint32_t off) {
+            const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
+            const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
+            const float4 r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
+            const float dx = r0.x - pxf, dy = r0.y - pyf;
+            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
+            const float test_T = __fmaf_rn(-T, alpha, T);
+            const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
+            const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
+            const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
+            const uint64_t validm = alive & m_pow & m_alpha;
+            const uint64_t stopm = validm & m_stop;
+            alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
+            const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
+            const float wgt = blend ? alpha * T : 0.0f;
+            C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
+            adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
+            T = blend ? test_T : T;
+            last_off = blend ? off : last_off;
+        };
+        const uint16_t* lp = s_list[w];
+        int j = 0;
+        for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
+            if (alive == 0) break;
+            const uint32_t o0 = lp[j], o1 = lp[j + 1];
+            blend_entry(o0);
+            if (alive == 0) break;
+            blend_entry(o1);
+        }
+        if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
+        if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
+    }
+    if (inside) {
+        const size_t N = (size_t)vp.W * vp.H;
+        const size_t pix = (size_t)py * vp.W + px;
+        out_color[pix] = C0 + T * vp.bg[0];
+        out_color[N + pix] = C1 + T * vp.bg[1];
+        out_color[2 * N + pix] = C2 + T * vp.bg[2];
+        out_ps[pix] = aps;
+        out_depth[pix] = adp;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7
 // ---------------------------------------------------------------------------------------------
@@ -339,6 +465,131 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             // rows by DPP, the four rows with v_permlane16/32_swap (in this latency-bound regime they beat ds_bpermute,
             // profiles/r1_notes.md); scalar record address, one atomic instruction from nine lanes
             const float outv = cross_row_allreduce(row_reduce_scatter9(v));
+            const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+            float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+            if (alane) unsafeAtomicAdd(gdst + aoff, outv);
+        }
+    }
+}
+
+// Fine-grained variant for FEW tiles (low pyramid levels), the counterpart of blend_forward_fine_kernel: sixteen wave64s
+// per tile on 4x4 pixel sub-blocks (lanes 0..15), same per-pixel arithmetic in the same order as blend_backward_kernel;
+// one atomic per (sub-block, Gaussian, component).
+__global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                             const uint32_t* __restrict__ ids,
+                                                             const uint2* __restrict__ ranges,
+                                                             const float* __restrict__ final_T,
+                                                             const uint32_t* __restrict__ n_contrib,
+                                                             const float* __restrict__ dL_dcolor,
+                                                             float* __restrict__ grad_rec) {
+    __shared__ float4 s_r0[BATCH], s_r1[BATCH];
+    __shared__ float s_b[BATCH], s_tau[BATCH];
+    __shared__ uint32_t s_id[BATCH];
+    __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
+    __shared__ uint16_t s_list[16][BATCH];
+    __shared__ uint32_t s_wmax[16];
+
+    const int num_tiles = vp.gx * vp.gy;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int px = tx * TILE + (w & 3) * 4 + (lane & 3);
+    const int py = ty * TILE + (w >> 2) * 4 + ((lane >> 2) & 3);
+    const bool inside = lane < 16 && px < vp.W && py < vp.H;     // lanes 16..63 idle (see blend_forward_fine_kernel)
+    const float pxf = (float)px, pyf = (float)py;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const size_t N = (size_t)vp.W * vp.H;
+    const size_t pix = (size_t)py * vp.W + px;
+
+    const float T_final = inside ? final_T[pix] : 1.0f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
+    if (inside) { dL0 = dL_dcolor[pix]; dL1 = dL_dcolor[N + pix]; dL2 = dL_dcolor[2 * N + pix]; }
+
+    const uint32_t wave_last = wave_max_u32(last);
+    if (lane == 0) s_wmax[w] = wave_last;
+    __syncthreads();
+    uint32_t tile_last = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile_last = max(tile_last, s_wmax[k]);
+
+    float T = T_final;
+    // S = sum_c dL/dC_c * (colour composited BEHIND the current entry, background included, normalised by the
+    // transmittance in front of it).  dL/dalpha_i = T_i (g_i - S_i) with g_i = sum_c dL/dC_c colour_i,c, and
+    // S_{i-1} = S_i + alpha_i (g_i - S_i): the three per-channel recurrences of the textbook form collapse into one
+    // scalar, and starting it at bg . dL/dC absorbs the separate background term (-T_final bg.dL / (1 - alpha_i)).
+    float S = vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2;
+    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);        // the nine lanes that issue the per-entry atomics
+    const uint32_t aoff = row_reduce_component(lane);
+
+    const int nb = ((int)tile_last + BATCH - 1) / BATCH;
+    for (int b = nb - 1; b >= 0; --b) {
+        __syncthreads();                              // previous batch fully consumed (and flushed)
+        const int base = b * BATCH;
+        const int n = min(BATCH, (int)tile_last - base);
+        if (tid < n) {
+            const uint32_t id = ids[range.x + base + tid];
+            const float4 r0 = rec[id].r0, r1 = rec[id].r1;
+            const float4 r2 = rec[id].r2;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_b[tid] = r2.x; s_id[tid] = id;
+            s_tau[tid] = r2.w;
+        }
+        __syncthreads();
+        {   // classification spread over the 1024 threads: thread -> (record e, sub-block row g), four 4x4 rectangles each
+            const int e = tid & (BATCH - 1), g = tid >> 8;
+            uint32_t m = 0;
+            if (e < n) {
+                const float4 r0 = s_r0[e];
+                const float C = s_r1[e].x, tau2 = s_tau[e];
+                if (!(tau2 > -1.0e38f)) m = 0xFu;
+                else {
+                    const float y0 = ty0 + (float)(4 * g);
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) {
+                        const float x0 = tx0 + (float)(4 * sx);
+                        if (levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, x0, x0 + 3.0f, y0, y0 + 3.0f)) m |= 1u << sx;
+                    }
+                }
+            }
+            s_mask[g][e] = (uint8_t)m;
+        }
+        __syncthreads();
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < BATCH / 64; ++c) {
+            const int e = c * 64 + lane;
+            const bool hit = e < n && (uint32_t)(base + e) < wave_last && ((s_mask[w >> 2][e] >> (w & 3)) & 1u);
+            const uint64_t bal = __ballot(hit);
+            if (hit) s_list[w][cnt + __popcll(bal & lt_mask)] = (uint16_t)e;
+            cnt += __popcll(bal);
+        }
+        for (int j = cnt - 1; j >= 0; --j) {
+            const int e = s_list[w][j];
+            const float4 r0 = s_r0[e], r1 = s_r1[e];
+            const float cb = s_b[e];
+            const float dx = r0.x - pxf, dy = r0.y - pyf;
+            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+            const float a_raw = __builtin_amdgcn_exp2f(ev.p);
+            const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < last) &
+                                    __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
+                                    __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);   // <=> min(0.99, a_raw) >= 1/255
+            if (validm == 0) continue;
+            const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
+            const float a_m = valid ? a_raw : 0.0f;                // the one select: a masked lane is the identity below
+            const float alpha_m = fminf(0.99f, a_m);
+            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha_m);
+            const float Tn = T * inv;
+            T = Tn;
+            const float dch = alpha_m * Tn;
+            const float sm = fmaf(cb, dL2, fmaf(r1.w, dL1, r1.z * dL0)) - S;
+            const float dL_dalpha = sm * Tn;
+            S = fmaf(alpha_m, sm, S);
+            const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
+            const BwdSums v = {q * dx, q * dy, q * ev.dxx, q * ev.dxy, q * ev.dyy, q, dch * dL0, dch * dL1, dch * dL2};
+            // the sixteen pixels live in row 0 of the wave: the row reduction is the whole reduction
+            const float outv = row_reduce_scatter9(v);
             const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
             float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
             if (alane) unsafeAtomicAdd(gdst + aoff, outv);
@@ -657,8 +908,19 @@ static int env_gen(const char* name, int dflt) {
 // >= ~4000 tiles to occupy 1024 SIMDs, below that four waves per tile (gen 1) win (C3 scene, profiles/r1_notes.md:
 // 8160 tiles 437 vs 667 us; 2040 tiles 334 vs 297; 510 tiles 481 vs 205; 135 tiles 834 vs 303; 2 tiles 1378 vs 431)
 constexpr int BWD_GEN2_MIN_TILES = 4096;
+// below these tile counts: the sixteen-waves-per-tile kernels (latency-bound regime).  C3 scene, profiles/r1_notes.md:
+// forward 510 tiles 109 -> 100 us, 135 tiles 184 -> 112, 40 tiles 285 -> 161; backward 510 tiles 167 -> 184 (worse),
+// 135 tiles 262 -> 185, 40 tiles 372 -> 236
+constexpr int FINE_MAX_TILES_FWD = 600, FINE_MAX_TILES_BWD = 300;
 static std::atomic<int> g_bwd_gen{[] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen == 2 ? gen : 0); }
+// blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
+static std::atomic<int> g_granularity{[] { const char* e = getenv("MSGS_BLEND_GRANULARITY"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
+int set_blend_granularity(int mode) { return g_granularity.exchange(mode == 1 || mode == 2 ? mode : 0); }
+static bool use_fine(int tiles, int max_tiles) {
+    const int g = g_granularity.load();
+    return g == 2 || (g == 0 && tiles < max_tiles);
+}
 static bool bwd_v1(int tiles) {
     const int forced = g_bwd_gen.load();
     return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
@@ -671,7 +933,10 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
     static const int fwd_gen = env_gen("MSGS_FWD_GEN", 1);
-    if (fwd_gen == 1)
+    if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
+        hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib);
+    else if (fwd_gen == 1)
         hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
     else
@@ -686,7 +951,10 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    if (!bwd_v1(tiles))
+    if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD)))
+        hipLaunchKernelGGL(blend_backward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, final_T,
+                           n_contrib, dL_dcolor, grad_rec);
+    else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
     else

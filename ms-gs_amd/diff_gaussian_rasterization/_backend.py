@@ -100,6 +100,8 @@ def _load():
     lib.msgs_backward_scratch_bytes_deterministic.argtypes = [C.c_int32, C.c_int64]
     lib.msgs_set_backward_generation.restype = C.c_int
     lib.msgs_set_backward_generation.argtypes = [C.c_int32]
+    lib.msgs_set_blend_granularity.restype = C.c_int
+    lib.msgs_set_blend_granularity.argtypes = [C.c_int32]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
@@ -161,7 +163,7 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
-           "msgs_set_backward_generation")
+           "msgs_set_backward_generation", "msgs_set_blend_granularity")
 
 
 def check(rc, where):

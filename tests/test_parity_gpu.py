@@ -13,19 +13,23 @@ pytestmark = pytest.mark.gpu
 ST0 = dict(filter_small=False, filter_large=False, fade_size=1.0)
 
 
-@pytest.fixture(autouse=True, params=[(1, True), (2, True), (1, False), (2, False)],
-                ids=["bwd4-chained", "bwd1-chained", "bwd4-plain", "bwd1-plain"])
+@pytest.fixture(autouse=True, params=[(1, 1, True), (2, 1, True), (1, 1, False), (2, 1, False), (0, 2, True), (0, 2, False)],
+                ids=["bwd4-chained", "bwd1-chained", "bwd4-plain", "bwd1-plain", "fine-chained", "fine-plain"])
 def backward_variants(request):
-    """Every test runs with both blend-backward kernels (by default the library picks by tile count, which would leave
-    the one-wave-per-tile kernel to the full-size tests only) and with the recognition of the reference's getters on
+    """Every test runs with every blend kernel: the quadrant-per-wave forward with both coarse backward kernels (by
+    default the library picks by tile count, which would leave the one-wave-per-tile kernel to the full-size tests
+    only), and the fine-grained forward + backward (sixteen waves per tile; by default below 600 tiles, which would
+    leave the coarse kernels to the larger tests only) — and with the recognition of the reference's getters on
     (gradients chained to the leaf parameters inside msgs_backward) and off (autograd runs the getters' backward)."""
     import diff_gaussian_rasterization as dgr
-    gen, chain = request.param
+    gen, gran, chain = request.param
     prev_gen = dgr._C.lib.msgs_set_backward_generation(gen)
+    prev_gran = dgr._C.lib.msgs_set_blend_granularity(gran)
     prev_chain = dgr.chain_reference_getters
     dgr.chain_reference_getters = chain
     yield request.param
     dgr._C.lib.msgs_set_backward_generation(prev_gen)
+    dgr._C.lib.msgs_set_blend_granularity(prev_gran)
     dgr.chain_reference_getters = prev_chain
 
 
@@ -267,3 +271,31 @@ def test_forward_capacity_guess_paths_give_identical_results():
         for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
             assert torch.equal(out[k], ref[k]), (k, guess)
         assert rel_err(pc._xyz.grad, pref._xyz.grad) <= 1e-4 and rel_err(m2, mref) <= 1e-4
+
+
+def test_blend_granularities_agree():
+    """The fine-grained kernels (sixteen waves per tile, 4x4 sub-blocks) evaluate every pixel with the same arithmetic in
+    the same order as the quadrant-per-wave kernels: forward outputs bit-identical, gradients equal up to the order of
+    the float atomics.  Ragged image (W, H not multiples of 16 or 4), multi-scale filters on, non-zero background."""
+    import diff_gaussian_rasterization as dgr
+    W, H = 203, 117
+    sc, cam = small_scene(6000, W, H, 57, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.2)
+    st = dict(filter_small=True, filter_large=True, fade_size=0.0)
+    bg = torch.tensor([0.2, 0.5, 0.1])
+    dL = scenes.grad_seed(W, H, 11)
+    res = {}
+    prev = dgr._C.lib.msgs_set_blend_granularity(1)
+    try:
+        for gran in (1, 2):
+            dgr._C.lib.msgs_set_blend_granularity(gran)
+            res[gran] = hip_render(sc, cam, st, bg, dL)
+    finally:
+        dgr._C.lib.msgs_set_blend_granularity(prev)
+    (a, pa, ma), (b, pb, mb) = res[1], res[2]
+    for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["render"].abs().max().item() > 0
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        tol = 1e-3 if n in ("_scaling", "_rotation") else 3e-4      # float-atomic order (tests/test_deterministic_gpu.py)
+        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= tol, n
+    assert rel_err(mb, ma) <= 3e-4
