@@ -338,9 +338,27 @@ def main():
                     traffic = int(tj[key]["hbm_bytes"])
             except Exception:
                 traffic = None
+            # what actually bounds the kernel: VALU issue.  Wave-instructions per launch from the committed
+            # PMC summary of this same command; issue model = instructions x 4.2 cycles / (1024 SIMDs x 2.4 GHz)
+            valu = None
+            try:
+                import csv as _csv
+                rows = [r for r in _csv.reader(l for l in open(os.path.join(ROOT, "profiles", "r1j_pmc_sq_final.csv"))
+                                               if not l.startswith("#"))]
+                col = rows[0].index("SQ_INSTS_VALU")
+                key = {"blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_tile_kernel"}[dom]
+                for r in rows[1:]:
+                    if r[0].startswith(key) and (P, W, H) == (1_000_000, 1920, 1080):
+                        insts = float(r[col])
+                        model_ms = insts * 4.2 / (1024 * 2.4e9) * 1e3
+                        valu = {"wave_instructions": insts, "issue_model_ms": round(model_ms, 4),
+                                "frac_of_issue_rate": round(model_ms / kernels[dom], 4),
+                                "source": "profiles/r1j_pmc_sq_final.csv"}
+            except Exception:
+                valu = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom],
+                    "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom], "valu_issue": valu,
                     "blend_fwd_plus_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
                                            "algorithmic_bytes": alg["blend_fwd"] + alg["blend_bwd"],
                                            "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
