@@ -691,9 +691,15 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     // ping-pong so that the LAST pass writes keys_out/vals_out
     const uint32_t* src_k = keys_in;
     const uint32_t* src_v = vals_in;
+    int next_shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
-        const int shift = begin_bit + 8 * p;
-        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        // grouped path: digit widths balanced over the passes (13 tile bits -> 7 + 6, not 8 + 5): a block's keys of one
+        // digit leave as one run, and the run length — hence the write coalescing of the scatter — is set by the pass
+        // with the MOST digits
+        const int shift = grouped ? next_shift : begin_bit + 8 * p;
+        const int left = end_bit - shift;
+        const int bits = grouped ? (left + (passes - p) - 1) / (passes - p) : (left < 8 ? left : 8);
+        next_shift = shift + bits;
         const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << (bits > 0 ? bits : 1)) - 1u);
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         uint32_t* dst_k = to_out ? keys_out : keys_alt;
