@@ -97,11 +97,9 @@ def render_fused(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mod
     (:127-153) and the SH concatenation (:144-149) inside its kernels.  Same result dict as render(); gradients land
     on the same leaf Parameters.  Not usable with override_color / convert_SHs_python / compute_cov3D_python."""
     xyz = pc._xyz
-    viewspace = torch.zeros_like(xyz, requires_grad=True) + 0
-    try:
-        viewspace.retain_grad()
-    except Exception:
-        pass
+    # gradient sink for the screen-space means: the op never reads its values, so — unlike render(), which keeps the
+    # reference's `zeros_like(...) + 0` — a leaf without the fill and add kernels will do (.grad is populated the same)
+    viewspace = torch.empty_like(xyz, requires_grad=True)
     rasterizer = GaussianRasterizer(raster_settings=_settings(
         viewpoint_camera, pc, pipe, bg_color, scaling_modifier, filter_small, filter_large, fade_size))
     image, acc_pixel_size, depth, radii, pixel_sizes = rasterizer.forward_raw(
