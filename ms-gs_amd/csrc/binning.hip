@@ -37,16 +37,15 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     const GeomLayout L(P);
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
     const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
-    const uint32_t* tiles = reinterpret_cast<const uint32_t*>(geom + L.tiles);
-    const uint2* rect = reinterpret_cast<const uint2*>(geom + L.rect);
-    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + L.rec);
+    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
 
     const int r0 = blockIdx.x * blockDim.x;
     const int r = r0 + threadIdx.x;
     const int rlast = min(r0 + (int)blockDim.x, P) - 1;
     uint32_t gi = 0, count = 0;
     int64_t off = 0;
-    if (r < P) { gi = order[r]; count = tiles[gi]; off = offs[r]; }
+    // the count of rank r is the difference of consecutive scanned offsets (coalesced; no gather of tiles[order[r]])
+    if (r < P) { gi = order[r]; off = offs[r]; count = (uint32_t)((r + 1 < P ? (int64_t)offs[r + 1] : D) - off); }
     if (threadIdx.x == 0) s_range[0] = off;
     if (r == rlast) s_range[1] = min((int64_t)off + count, D);
     __syncthreads();
@@ -57,11 +56,11 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
 
     if (count) {
         const int64_t end = min((int64_t)off + count, D);
-        const uint2 rc = rect[gi];
-        const int minx = rc.x & 0xFFFF, miny = rc.x >> 16, maxx = rc.y & 0xFFFF, maxy = rc.y >> 16;
-        const float4 q0 = rec[gi].r0;
-        const float conC = rec[gi].r1.x;
-        const float tau2 = rec[gi].r2.w;
+        const float4 q0 = binrec[gi].q0, q1 = binrec[gi].q1;
+        const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
+        const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
+        const float conC = q1.x;
+        const float tau2 = q1.y;
         const bool test = tau2 > -1.0e38f;
         const LevelSetRows ls = test ? levelset_rows_setup(q0.z, q0.w, conC, tau2) : LevelSetRows{};
         for (int ty = miny; ty < maxy && off < end; ++ty) {

@@ -23,6 +23,11 @@ constexpr int WAVE = 64;
 //                                           form is not negative definite and cannot be bounded)
 struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2; };
 
+// Per-Gaussian record read by emit_kernel through the depth order (a random gather): everything it needs in one
+// aligned 32-byte line instead of pieces of four arrays —
+//   q0 = { px, py, k*conic.A, k*conic.B },  q1 = { k*conic.C, tau2, bits(minx | miny<<16), bits(maxx | maxy<<16) }
+struct __attribute__((aligned(32))) BinRec { float4 q0, q1; };
+
 // Per-Gaussian 2-D gradient record accumulated by the blend backward: 12 floats = 48 B.
 //   [0] sum q dx  [1] sum q dy  [2] sum q dx^2  [3] sum q dx dy  [4] sum q dy^2  [5] sum q  [6..8] dL/drgb
 //   [9..11] pad, with q = alpha_raw dL/dalpha; preprocess_backward_kernel turns [0..5] into
@@ -33,11 +38,11 @@ constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode:
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct GeomLayout {
-    size_t rec, rect, tiles, key, flags, weight, order, offs, total;
+    size_t rec, binrec, tiles, key, flags, weight, order, offs, total;
     __host__ __device__ explicit GeomLayout(int64_t P) {
         size_t o = 0;
         rec = o;    o = align256(o + sizeof(GaussRec) * P);
-        rect = o;   o = align256(o + 8 * P);        // uint2: (minx | miny<<16, maxx | maxy<<16)
+        binrec = o; o = align256(o + sizeof(BinRec) * P);   // what emit needs, in ONE 32-byte line (rendered Gaussians)
         tiles = o;  o = align256(o + 4 * P);        // exact tile-overlap count
         key = o;    o = align256(o + 4 * P);        // depth sort key (float bits / 0xFFFFFFFF)
         flags = o;  o = align256(o + 4 * P);        // bit0..2 colour clamped, bit3 rendered

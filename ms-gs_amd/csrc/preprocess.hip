@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     const bool in_range = i < P;
     const GeomLayout L(P);
     GaussRec* rec = reinterpret_cast<GaussRec*>(geom + L.rec);
-    uint2* rect = reinterpret_cast<uint2*>(geom + L.rect);
+    BinRec* binrec = reinterpret_cast<BinRec*>(geom + L.binrec);
     uint32_t* tiles = reinterpret_cast<uint32_t*>(geom + L.tiles);
     uint32_t* key = reinterpret_cast<uint32_t*>(geom + L.key);
     uint32_t* flags = reinterpret_cast<uint32_t*>(geom + L.flags);
@@ -381,7 +381,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     int32_t out_radius = 0;
     float out_psize = 0.f;
     uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, out_flags = 0;
-    uint2 out_rect = make_uint2(0, 0);
     float out_weight = 0.f;
 
     // ---- phase A: geometry, pixel size, multi-scale filters (one lane per Gaussian) ----
@@ -530,17 +529,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         rec[i].r0 = make_float4(px, py, sA, sBh);
         rec[i].r1 = make_float4(sC, __log2f(o_eff), rgb[0], rgb[1]);
         rec[i].r2 = make_float4(rgb[2], t[2], out_psize, tau2);
+        if (count) {
+            binrec[i].q0 = make_float4(px, py, sA, sBh);
+            binrec[i].q1 = make_float4(sC, tau2, __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
+                                       __uint_as_float((uint32_t)maxx | ((uint32_t)maxy << 16)));
+        }
         out_radius = (int32_t)my_radius;
         out_tiles = count;
         out_key = count ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
         out_flags |= 8u;
-        out_rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
         out_weight = w;
     }
     if (in_range) {
         radii[i] = out_radius;
         pixel_sizes[i] = out_psize;
-        rect[i] = out_rect;
         tiles[i] = out_tiles;
         key[i] = out_key;
         flags[i] = out_flags;
