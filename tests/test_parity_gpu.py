@@ -299,3 +299,42 @@ def test_blend_granularities_agree():
         tol = 1e-3 if n in ("_scaling", "_rotation") else 3e-4      # float-atomic order (tests/test_deterministic_gpu.py)
         assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= tol, n
     assert rel_err(mb, ma) <= 3e-4
+
+
+def test_kernel_variants_agree_on_random_shapes():
+    """Differential stress of the blend kernel variants (quadrant-per-wave forward with the four-waves and one-wave
+    backward, fine-grained forward + backward) over random image shapes, densities and footprint sizes, including
+    images smaller than one tile / one 4x4 sub-block and footprints of many tiles: forward outputs bit-identical,
+    gradients equal up to float-atomic order."""
+    import random
+    import diff_gaussian_rasterization as dgr
+    rnd = random.Random(20261002)
+    shapes = [(1, 1), (3, 5), (4, 4), (17, 33), (16, 16), (31, 16)]
+    shapes += [(rnd.randint(20, 260), rnd.randint(20, 200)) for _ in range(6)]
+    prev_gen = dgr._C.lib.msgs_set_backward_generation(0)
+    prev_gran = dgr._C.lib.msgs_set_blend_granularity(0)
+    try:
+        for n, (W, H) in enumerate(shapes):
+            P = rnd.choice([50, 800, 5000])
+            k = rnd.choice([0.05, 0.2, 0.5, 2.0]) * 0.004 * 1920.0 / W
+            ms = bool(n & 1)
+            sc, cam = small_scene(P, W, H, 900 + n, multiscale=ms, scale_k=k)
+            st = dict(filter_small=ms, filter_large=ms, fade_size=0.0 if ms else 1.0)
+            bg = torch.tensor([0.1 * (n % 3), 0.3, 0.7])
+            dL = scenes.grad_seed(W, H, 40 + n)
+            res = []
+            for gen, gran in ((1, 1), (2, 1), (0, 2)):
+                dgr._C.lib.msgs_set_backward_generation(gen)
+                dgr._C.lib.msgs_set_blend_granularity(gran)
+                res.append(hip_render(sc, cam, st, bg, dL))
+            (a, pa, ma) = res[0]
+            for (b, pb, mb) in res[1:]:
+                for key in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
+                    assert torch.equal(a[key], b[key]), (key, W, H, P)
+                for nm in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+                    tol = 2e-3 if nm in ("_scaling", "_rotation") else 5e-4
+                    assert rel_err(getattr(pb, nm).grad, getattr(pa, nm).grad) <= tol, (nm, W, H, P)
+                assert rel_err(mb, ma) <= 5e-4, (W, H, P)
+    finally:
+        dgr._C.lib.msgs_set_backward_generation(prev_gen)
+        dgr._C.lib.msgs_set_blend_granularity(prev_gran)
