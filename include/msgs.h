@@ -101,8 +101,8 @@ typedef struct msgs_gaussians {
     const float* cov3D_precomp;    /* [P,6]    xx,xy,xz,yy,yz,zz (general_utils.py:64-73)            */
     const float* max_pixel_sizes;  /* [P]      -1 = unset (gaussian_model.py:224)                    */
     const float* min_pixel_sizes;  /* [P]      -1 = unset (gaussian_model.py:225)                    */
-    const float* occ_multiplier;   /* [P,4]    accepted; identity semantics (DESIGN.md SPEC M5)      */
-    const float* dc_delta;         /* [P,12]   accepted; identity semantics (DESIGN.md SPEC M5)      */
+    const float* occ_multiplier;   /* [P,4]    never read: the caller guarantees all ones (SPEC M5)   */
+    const float* dc_delta;         /* [P,12]   never read: the caller guarantees all zeros (SPEC M5)  */
     const uint8_t* base_mask;      /* [P]      bool                                                  */
     const float* features_dc;      /* [P,1,3]  modes 1, 2    (gaussian_model.py:55)                          */
     const float* features_rest;    /* [P,15,3] modes 1, 2    (gaussian_model.py:56)                          */

@@ -18,6 +18,7 @@ this package without lib/libmsgs_hip.so raises ImportError, and calling it with 
 """
 import ctypes as C
 import os
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -85,6 +86,51 @@ def _bytes(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=device)
 
 
+# occ_multiplier / dc_delta: this build implements their identity configuration only (ones / zeros, DESIGN SPEC M5 — every
+# published MS-GS configuration; the level-selection semantics of --multi_occ / --multi_dc live in the un-vendored CUDA
+# kernels).  Anything else is REFUSED instead of rendered wrongly.  A leaf tensor (the reference passes the Parameter
+# itself when multi_occ is off, scene/gaussian_model.py:156-164) is checked once per (tensor object, version): one tiny
+# reduction + host read on the first call after creation / densification, nothing afterwards.  A computed tensor (e.g.
+# sigmoid(_occ_multiplier) under --multi_occ, :158) is checked on every call.
+_identity_checked = {}
+
+
+def _require_identity(t, name, value, flag):
+    if t is None:
+        return
+    leaf = t.grad_fn is None
+    if leaf:
+        hit = _identity_checked.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == t._version:
+            return
+    if not bool((t.detach() == value).all().item()):
+        raise NotImplementedError(
+            f"diff_gaussian_rasterization (MI355X build): {name} must be all {value:g} — the {flag} semantics of the "
+            "MS-GS rasterizer (scene/gaussian_model.py:156-164,203-213) are not implemented; refusing to render "
+            "with them silently ignored")
+    if leaf:
+        if len(_identity_checked) > 64:
+            for k in [k for k, v in _identity_checked.items() if v[0]() is None]:
+                del _identity_checked[k]
+        _identity_checked[id(t)] = (weakref.ref(t), t._version)
+
+
+def _check_rows(name, t, P, tail):
+    """per-Gaussian tensor `t` must be [P, *tail] (element count per row checked; a stale tensor after densify / prune
+    would otherwise be read out of bounds by preprocess_kernel)"""
+    if t is None:
+        return
+    if tail is None:                       # width not fixed by the ABI (never read: identity-checked): rows only
+        if t.dim() == 0 or int(t.shape[0]) != P:
+            raise ValueError(f"{name} must have {P} rows, got {tuple(t.shape)}")
+        return
+    n = 1
+    for d in tail:
+        n *= d
+    if t.dim() == 0 or int(t.shape[0]) != P or t.numel() != P * n:
+        raise ValueError(f"{name} must have shape [{P}, {', '.join(str(d) for d in tail)}], got {tuple(t.shape)}")
+
+
 class _Call:
     """Marshals one (settings, tensors) pair into the C structs; keeps the tensors alive."""
 
@@ -98,6 +144,18 @@ class _Call:
         self.device = dev
         P = int(means3D.shape[0])
         self.P = P
+        _check_rows("means3D", means3D, P, (3,))
+        _check_rows("scales", scales, P, (3,))
+        _check_rows("rotations", rotations, P, (4,))
+        _check_rows("cov3D_precomp", cov3D_precomp, P, (6,))
+        _check_rows("colors_precomp", colors_precomp, P, (3,))
+        _check_rows("occ_multiplier", occ_multiplier, P, None)
+        _check_rows("dc_delta", dc_delta, P, None)
+        _check_rows("rotations_raw", rotations_raw, P, (4,))
+        if sh is not None and (sh.dim() != 3 or int(sh.shape[0]) != P or int(sh.shape[2]) != 3):
+            raise ValueError(f"shs must have shape [{P}, K, 3], got {tuple(sh.shape)}")
+        _require_identity(occ_multiplier, "occ_multiplier", 1.0, "--multi_occ")
+        _require_identity(dc_delta, "dc_delta", 0.0, "--multi_dc")
         self.means3D = _f32c(means3D)
         self.sh = _f32c(sh) if sh is not None else None
         self.colors = _f32c(colors_precomp) if colors_precomp is not None else None
@@ -235,6 +293,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.state = state
         ctx.radii = radii
         ctx.shapes = (means2D.shape, opacities.shape)
+        _save_inputs(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
         return color, acc_ps, depth, radii, pixel_sizes
 
@@ -242,6 +301,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
         if ctx.empty:
             return tuple(torch.zeros(s, device=ctx.dev) for s in ctx.in_shapes) + (None,) * 6
+        _check_saved(ctx)
         call = ctx.call
         geom, binning, image, D = ctx.state
         dev, P, K = call.device, call.P, call.K
@@ -274,8 +334,26 @@ class _RasterizeGaussians(torch.autograd.Function):
 # Gradient sinks (view-parallel training): a trainer that exchanges gradients through one flat bucket registers, per leaf
 # parameter, the slice of the bucket its gradient belongs in.  The backward of the raw / chained entries then writes the
 # gradient THERE and returns a fresh alias of that slice; with param.grad = None autograd adopts the alias as .grad (no
-# copy), so neither a zero-fill of the bucket nor an accumulation pass over it is needed.  Keys: leaf.data_ptr().
+# copy), so neither a zero-fill of the bucket nor an accumulation pass over it is needed.  Keys: id() of the leaf tensor
+# OBJECT, validated through a weak reference (an address-based key could match an unrelated tensor after densification
+# re-allocates the parameters).
 _grad_sinks = {}
+
+
+def _sink_key(t):
+    return id(t)
+
+
+def _save_inputs(ctx, *tensors):
+    """Everything the backward re-reads goes through save_for_backward, so that an in-place edit between forward and
+    backward (optimizer step, reset_opacity-style edit) raises autograd's version-counter error instead of yielding
+    silently wrong gradients.  (The ctypes structs on ctx.call point at the same storage.)"""
+    ctx.save_for_backward(*[t for t in tensors if torch.is_tensor(t) and t.numel() > 0])
+
+
+def _check_saved(ctx):
+    if not getattr(ctx, "empty", False):
+        ctx.saved_tensors              # raises "modified by an inplace operation" when a version changed
 
 
 def set_grad_sinks(mapping):
@@ -285,13 +363,15 @@ def set_grad_sinks(mapping):
         for leaf, dest in mapping.items():
             if dest.dtype != torch.float32 or not dest.is_contiguous() or dest.numel() != leaf.numel():
                 raise ValueError("grad sink must be a contiguous float32 tensor with the parameter's numel")
-            _grad_sinks[leaf.data_ptr()] = dest
+            if dest.data_ptr() % 16:
+                raise ValueError("grad sink must be 16-byte aligned (the backward stores float4 rows)")
+            _grad_sinks[id(leaf)] = (weakref.ref(leaf), dest)
 
 
 def _grad_out(key, shape, dev):
-    dest = _grad_sinks.get(key)
-    if dest is not None and dest.device == dev:
-        return dest.view(shape)                     # a NEW alias: autograd may adopt it as param.grad
+    hit = _grad_sinks.get(key)
+    if hit is not None and hit[0]() is not None and hit[1].device == dev:
+        return hit[1].view(shape)                   # a NEW alias: autograd may adopt it as param.grad
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
@@ -312,13 +392,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
-        ctx.leaf_keys = tuple(t.data_ptr() for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
-                                                      rotation_raw))
+        ctx.leaf_keys = tuple(_sink_key(t) for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
+                                                     rotation_raw))
+        _save_inputs(ctx, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
         return color, acc_ps, depth, radii, pixel_sizes
 
     @staticmethod
     def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
+        _check_saved(ctx)
         call = ctx.call
         geom, binning, image, D = ctx.state
         dev, P = call.device, call.P
@@ -358,8 +440,10 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
-        ctx.leaf_keys = tuple(t.data_ptr() for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
-                                                      rotation_raw))
+        ctx.leaf_keys = tuple(_sink_key(t) for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
+                                                     rotation_raw))
+        _save_inputs(ctx, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw, shs, opacities,
+                     scales, rotations)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
         return color, acc_ps, depth, radii, pixel_sizes
 

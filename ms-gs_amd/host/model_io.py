@@ -172,8 +172,8 @@ def restore(model, model_args, make_optimizer):
     optimizer = make_optimizer(model)               # may re-allocate the accumulators like training_setup does
     model.xyz_gradient_accum, model.denom = xyz_gradient_accum, denom
     optimizer.load_state_dict(opt_dict)
-    if model.active_sh_degree < model.max_sh_degree:     # gaussian_model.py:122-123
-        model.active_sh_degree += 1
+    # active_sh_degree is restored verbatim (gaussian_model.py:101-125 has no SH bump; oneupSHdegree is only called
+    # from the train loop, train.py)
     return optimizer, spatial_lr_scale
 
 

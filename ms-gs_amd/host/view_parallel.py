@@ -16,7 +16,10 @@ import torch.distributed as dist
 class FlatGradBucket:
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        # every slice starts on a 16-byte boundary: in direct mode the HIP backward stores float4 rows into the slices
+        # (dL/drotation, the features_rest rows), whatever P is
+        pad4 = lambda n: (n + 3) & ~3
+        n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
@@ -25,7 +28,7 @@ class FlatGradBucket:
             v = self.flat[off:off + p.numel()].view_as(p)
             p.grad = v
             self.views.append(v)
-            off += p.numel()
+            off += pad4(p.numel())
 
     def sinks(self):
         """{parameter: its slice of the bucket} for diff_gaussian_rasterization.set_grad_sinks (direct mode)."""

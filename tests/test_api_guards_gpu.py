@@ -1,0 +1,124 @@
+"""Guards of the drop-in Python boundary: inputs this build cannot honour are refused, never silently mis-rendered
+(occ_multiplier / dc_delta away from their identity values, /root/reference/scene/gaussian_model.py:156-164,203-213),
+mismatched per-Gaussian shapes raise before any kernel reads out of bounds, and an in-place edit of an input between
+forward and backward raises autograd's version error instead of yielding wrong gradients."""
+import math
+
+import pytest
+import torch
+
+import scenes
+from parity_utils import small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, bg, deg=3):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(image_height=cam.image_height, image_width=cam.image_width,
+                                         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg,
+                                         scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                                         projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center,
+                                         prefiltered=False, debug=False)
+
+
+def _inputs(P=500, W=64, H=48, seed=3):
+    sc, cam = small_scene(P, W, H, seed)
+    d = lambda t: t.to("cuda")
+    kw = dict(means3D=d(sc.means3D), means2D=torch.zeros(P, 3, device="cuda"), opacities=d(sc.opacities), shs=d(sc.shs),
+              scales=d(sc.scales), rotations=d(sc.rotations), max_pixel_sizes=d(sc.max_pixel_sizes),
+              min_pixel_sizes=d(sc.min_pixel_sizes), occ_multiplier=d(sc.occ_multiplier), dc_delta=d(sc.dc_delta),
+              base_mask=d(sc.base_mask))
+    return kw, cam.to("cuda")
+
+
+def test_non_identity_occ_multiplier_and_dc_delta_are_refused():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    kw, cam = _inputs()
+    r = GaussianRasterizer(_settings(cam, torch.zeros(3, device="cuda")))
+    img = r(**kw)[0]                                           # identity values: accepted
+    assert torch.isfinite(img).all()
+    bad = dict(kw)
+    bad["occ_multiplier"] = torch.sigmoid(torch.full_like(kw["occ_multiplier"], 4.6))     # --multi_occ: sigmoid(raw)
+    with pytest.raises(NotImplementedError, match="occ_multiplier"):
+        r(**bad)
+    bad = dict(kw)
+    bad["dc_delta"] = kw["dc_delta"].clone()
+    bad["dc_delta"][7, 3, 0] = 0.01
+    with pytest.raises(NotImplementedError, match="dc_delta"):
+        r(**bad)
+    # a leaf that passed is not re-read ... until it is modified in place
+    occ = torch.nn.Parameter(kw["occ_multiplier"].clone())
+    ok = dict(kw)
+    ok["occ_multiplier"] = occ
+    r(**ok)
+    r(**ok)
+    with torch.no_grad():
+        occ[3, 1, 0] = 0.5
+    with pytest.raises(NotImplementedError):
+        r(**ok)
+
+
+@pytest.mark.parametrize("name,shape", [("scales", (499, 3)), ("rotations", (500, 3)), ("shs", (501, 16, 3)),
+                                        ("occ_multiplier", (499, 4, 1)), ("opacities", (499, 1)),
+                                        ("min_pixel_sizes", (499,)), ("base_mask", (10,))])
+def test_mismatched_per_gaussian_shapes_raise(name, shape):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    kw, cam = _inputs()
+    r = GaussianRasterizer(_settings(cam, torch.zeros(3, device="cuda")))
+    fill = torch.ones if name == "occ_multiplier" else torch.zeros
+    kw[name] = fill(*shape, device="cuda", dtype=torch.bool if name == "base_mask" else torch.float32)
+    with pytest.raises(ValueError, match=name):
+        r(**kw)
+
+
+def test_inplace_edit_between_forward_and_backward_raises():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    kw, cam = _inputs()
+    r = GaussianRasterizer(_settings(cam, torch.zeros(3, device="cuda")))
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        kw[k] = kw[k].clone().requires_grad_(True)
+    img = r(**kw)[0]
+    with torch.no_grad():
+        kw["opacities"].mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        img.sum().backward()
+    # and through the getter-recognising path on leaf parameters
+    from gaussian_renderer import render
+    from parity_utils import PIPE
+    from synthetic_model import SyntheticGaussians
+    sc, cam2 = small_scene(400, 64, 48, 5)
+    pc = SyntheticGaussians(sc, "cuda")
+    out = render(cam2.to("cuda"), pc, PIPE, torch.zeros(3, device="cuda"), filter_small=False, filter_large=False,
+                 fade_size=1.0)
+    with torch.no_grad():
+        pc._scaling.add_(0.1)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out["render"].sum().backward()
+
+
+def test_direct_gradient_sinks_with_odd_gaussian_count():
+    """P % 4 != 0: every bucket slice is still 16-byte aligned, the gradients written straight into the bucket equal
+    the ones autograd accumulates the ordinary way."""
+    from gaussian_renderer import render
+    from parity_utils import PIPE
+    from synthetic_model import SyntheticGaussians
+    from view_parallel import PipelinedGradExchange
+    P, W, H = 1003, 96, 64
+    sc, cam = small_scene(P, W, H, 9)
+    st = dict(filter_small=False, filter_large=False, fade_size=1.0)
+    dL = scenes.grad_seed(W, H, 9).cuda()
+    bg = torch.zeros(3, device="cuda")
+    ref = SyntheticGaussians(sc, "cuda")
+    render(cam.to("cuda"), ref, PIPE, bg, **st)["render"].backward(dL)
+    pc = SyntheticGaussians(sc, "cuda")
+    ex = PipelinedGradExchange(pc.parameters(), world=1, direct=True)
+    assert all(v.data_ptr() % 16 == 0 for b in ex.buckets for v in b.views)
+    ex.begin_view()
+    render(cam.to("cuda"), pc, PIPE, bg, **st)["render"].backward(dL)
+    b = ex.end_view()
+    ex.drain()
+    for p, q, v in zip(pc.parameters(), ref.parameters(), b.views):
+        assert p.grad.data_ptr() == v.data_ptr()
+        scale = q.grad.abs().max().clamp_min(1e-30)
+        assert ((p.grad - q.grad).abs().max() / scale).item() <= 3e-4        # two float-atomic runs

@@ -88,7 +88,7 @@ def test_checkpoint_tuple_round_trip_in_capture_order():
     assert tup[11] is m.max_pixel_sizes and tup[12] is m.min_pixel_sizes and tup[15] is m.target_reso_lvl and tup[17] == 2.5
     fresh = types.SimpleNamespace(max_sh_degree=3)
     opt2, scale = model_io.restore(fresh, tup, mk)
-    assert scale == 2.5 and fresh.active_sh_degree == 3                 # :122-123 bumps the degree on restore
+    assert scale == 2.5 and fresh.active_sh_degree == 2                 # restored verbatim (gaussian_model.py:101-125)
     assert fresh.base_gaussian_mask is m.base_gaussian_mask and fresh.min_pixel_sizes is m.min_pixel_sizes
     assert fresh.max_pixel_sizes is m.max_pixel_sizes and fresh.denom is m.denom
     st = opt2.state[fresh._xyz]

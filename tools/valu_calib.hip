@@ -1,0 +1,189 @@
+// valu_calib.hip — measures the issue cost of the VALU / LDS instructions the blend kernels are made of, on gfx950.
+//
+// Why: DESIGN §5.4 prices the blend kernels against a VALU issue ceiling.  Round 1 modelled 4.2 cycles per wave64
+// VALU instruction from kernel durations; the hardware guide (MI355X_MICROARCH.md, per-instruction constants) quotes
+// 2 cycles for v_fma_f32 (SIMD-32).  This tool settles it with a direct measurement:
+//   for each instruction stream S and each occupancy w = 1, 2, 4, 8 waves per SIMD, every SIMD of the chip runs w waves
+//   that each execute ITER x 4 copies of the 8-instruction body (independent register chains unless the name says
+//   "dep"); reported per (stream, w):
+//     cyc_tick = s_memtime ticks of the slowest wave / (w x instructions per wave)        [in-kernel, shader clock]
+//     cyc_wall = wall time (hipEvent) x 2.4 GHz / (w x instructions per wave)            [includes launch + tail]
+//     Ginstr/s = wave-instructions per second over the whole chip (wall)
+// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_calib.hip -o tools/valu_calib
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int ITER = 2000;
+constexpr int REP = 4;          // copies of the body per loop trip
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// operands of every body:  %0..%7 float accumulators, %8..%11 float-pair accumulators, %12 = a, %13 = b (floats),
+// %14 = pair {a, b}, %15 = LDS byte address of the lane (bpermute / ds_read), %16 = 64-bit lane mask in SGPRs
+#define STREAM_KERNEL(NAME, BODY)                                                                                   \
+    __global__ __launch_bounds__(256) void NAME(float* out, unsigned long long* ticks, float a, float b) {          \
+        float v0 = threadIdx.x * 1e-3f, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f, v4 = v0 + 4.f, v5 = v0 + 5.f,  \
+              v6 = v0 + 6.f, v7 = v0 + 7.f;                                                                         \
+        f2 d0 = {v0, v1}, d1 = {v2, v3}, d2 = {v4, v5}, d3 = {v6, v7};                                              \
+        const f2 pa = {a, b};                                                                                       \
+        __shared__ float lds[1024];                                                                                 \
+        lds[threadIdx.x] = v0; lds[threadIdx.x + 256] = v1; lds[threadIdx.x + 512] = v2; lds[threadIdx.x + 768] = v3; \
+        __syncthreads();                                                                                            \
+        const unsigned ldsaddr = ((threadIdx.x & 63) ^ 16) * 4u;                                                    \
+        const unsigned long long mask = 0xAAAAAAAAAAAAAAAAull;                                                      \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                                 \
+        for (int it = 0; it < ITER; ++it) {                                                                         \
+            asm volatile(BODY BODY BODY BODY                                                                        \
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7),          \
+                           "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)                                                   \
+                         : "v"(a), "v"(b), "v"(pa), "v"(ldsaddr), "s"(mask)                                         \
+                         : "vcc", "s20", "s21", "s22", "s23", "memory");                                            \
+        }                                                                                                           \
+        const unsigned long long t1 = __builtin_readcyclecounter();                                                 \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + d0.x + d0.y + d1.x +   \
+                                                     d1.y + d2.x + d2.y + d3.x + d3.y;                              \
+        if ((threadIdx.x & 63) == 0) ticks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                \
+    }
+
+STREAM_KERNEL(k_fma_indep,
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n")
+STREAM_KERNEL(k_fma_dep,
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %0, %0, %12, %13\n"
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %0, %0, %12, %13\n")
+STREAM_KERNEL(k_fma_dep2,    // two interleaved chains
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n"
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n")
+STREAM_KERNEL(k_mul_indep,
+    "v_mul_f32 %0, %0, %12\n v_mul_f32 %1, %1, %12\n v_mul_f32 %2, %2, %12\n v_mul_f32 %3, %3, %12\n"
+    "v_mul_f32 %4, %4, %12\n v_mul_f32 %5, %5, %12\n v_mul_f32 %6, %6, %12\n v_mul_f32 %7, %7, %12\n")
+STREAM_KERNEL(k_add_indep,
+    "v_add_f32 %0, %0, %12\n v_add_f32 %1, %1, %12\n v_add_f32 %2, %2, %12\n v_add_f32 %3, %3, %12\n"
+    "v_add_f32 %4, %4, %12\n v_add_f32 %5, %5, %12\n v_add_f32 %6, %6, %12\n v_add_f32 %7, %7, %12\n")
+// packed fp32: one instruction = two floats per lane (a VGPR pair); 8 instructions on 4 independent pairs
+STREAM_KERNEL(k_pk_fma_indep,
+    "v_pk_fma_f32 %8, %8, %14, %14\n v_pk_fma_f32 %9, %9, %14, %14\n v_pk_fma_f32 %10, %10, %14, %14\n v_pk_fma_f32 %11, %11, %14, %14\n"
+    "v_pk_fma_f32 %8, %8, %14, %14\n v_pk_fma_f32 %9, %9, %14, %14\n v_pk_fma_f32 %10, %10, %14, %14\n v_pk_fma_f32 %11, %11, %14, %14\n")
+STREAM_KERNEL(k_pk_mul_indep,
+    "v_pk_mul_f32 %8, %8, %14\n v_pk_mul_f32 %9, %9, %14\n v_pk_mul_f32 %10, %10, %14\n v_pk_mul_f32 %11, %11, %14\n"
+    "v_pk_mul_f32 %8, %8, %14\n v_pk_mul_f32 %9, %9, %14\n v_pk_mul_f32 %10, %10, %14\n v_pk_mul_f32 %11, %11, %14\n")
+STREAM_KERNEL(k_pk_add_indep,
+    "v_pk_add_f32 %8, %8, %14\n v_pk_add_f32 %9, %9, %14\n v_pk_add_f32 %10, %10, %14\n v_pk_add_f32 %11, %11, %14\n"
+    "v_pk_add_f32 %8, %8, %14\n v_pk_add_f32 %9, %9, %14\n v_pk_add_f32 %10, %10, %14\n v_pk_add_f32 %11, %11, %14\n")
+STREAM_KERNEL(k_exp_indep,
+    "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+    "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n")
+STREAM_KERNEL(k_rcp_indep,
+    "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+    "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n")
+// one transcendental per eight instructions (the blend forward's mix is about 1 in 25, the backward's 2 in 35)
+STREAM_KERNEL(k_mix_7fma_1exp,
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_exp_f32 %3, %3\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n")
+STREAM_KERNEL(k_add_dpp_row_ror,
+    "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n")
+STREAM_KERNEL(k_add_dpp_quad_perm,
+    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+    "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
+STREAM_KERNEL(k_cndmask_sgpr,
+    "v_cndmask_b32_e64 %0, %0, %12, %16\n v_cndmask_b32_e64 %1, %1, %12, %16\n v_cndmask_b32_e64 %2, %2, %12, %16\n v_cndmask_b32_e64 %3, %3, %12, %16\n"
+    "v_cndmask_b32_e64 %4, %4, %12, %16\n v_cndmask_b32_e64 %5, %5, %12, %16\n v_cndmask_b32_e64 %6, %6, %12, %16\n v_cndmask_b32_e64 %7, %7, %12, %16\n")
+// compare into an SGPR pair (what a ballot of a direct comparison is)
+STREAM_KERNEL(k_cmp_to_sgpr,
+    "v_cmp_lt_f32_e64 s[20:21], %0, %12\n v_cmp_lt_f32_e64 s[22:23], %1, %12\n v_cmp_lt_f32_e64 s[20:21], %2, %12\n v_cmp_lt_f32_e64 s[22:23], %3, %12\n"
+    "v_cmp_lt_f32_e64 s[20:21], %4, %12\n v_cmp_lt_f32_e64 s[22:23], %5, %12\n v_cmp_lt_f32_e64 s[20:21], %6, %12\n v_cmp_lt_f32_e64 s[22:23], %7, %12\n")
+// compare -> scalar and -> select: the VALU -> SALU -> VALU round trip of the blend forward's predicates
+STREAM_KERNEL(k_cmp_sand_cndmask,
+    "v_cmp_lt_f32_e64 s[20:21], %0, %12\n s_and_b64 s[22:23], s[20:21], %16\n v_cndmask_b32_e64 %1, %1, %12, s[22:23]\n v_fma_f32 %2, %2, %12, %13\n"
+    "v_cmp_lt_f32_e64 s[20:21], %3, %12\n s_and_b64 s[22:23], s[20:21], %16\n v_cndmask_b32_e64 %4, %4, %12, s[22:23]\n v_fma_f32 %5, %5, %12, %13\n")
+STREAM_KERNEL(k_ds_bpermute,
+    "ds_bpermute_b32 %0, %15, %0\n ds_bpermute_b32 %1, %15, %1\n ds_bpermute_b32 %2, %15, %2\n ds_bpermute_b32 %3, %15, %3\n"
+    "ds_bpermute_b32 %4, %15, %4\n ds_bpermute_b32 %5, %15, %5\n ds_bpermute_b32 %6, %15, %6\n ds_bpermute_b32 %7, %15, %7\n s_waitcnt lgkmcnt(0)\n")
+
+struct Stream { const char* name; void (*fn)(float*, unsigned long long*, float, float); int instr_per_body; const char* note; };
+
+int main(int argc, char** argv) {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const double clock_ghz = prop.clockRate * 1e-6;        // kHz -> GHz
+    printf("# device %s, %d CUs, clockRate %.3f GHz; ITER=%d, body x%d\n", prop.gcnArchName, cus, clock_ghz, ITER, REP);
+    const Stream streams[] = {
+        {"v_fma_f32 x8 independent", k_fma_indep, 8, ""},
+        {"v_fma_f32 one dependent chain", k_fma_dep, 8, ""},
+        {"v_fma_f32 two dependent chains", k_fma_dep2, 8, ""},
+        {"v_mul_f32 x8 independent", k_mul_indep, 8, ""},
+        {"v_add_f32 x8 independent", k_add_indep, 8, ""},
+        {"v_pk_fma_f32 x4 pairs independent", k_pk_fma_indep, 8, "2 floats per lane per instruction"},
+        {"v_pk_mul_f32 x4 pairs independent", k_pk_mul_indep, 8, "2 floats per lane per instruction"},
+        {"v_pk_add_f32 x4 pairs independent", k_pk_add_indep, 8, "2 floats per lane per instruction"},
+        {"v_exp_f32 x8 independent", k_exp_indep, 8, ""},
+        {"v_rcp_f32 x8 independent", k_rcp_indep, 8, ""},
+        {"7 v_fma_f32 + 1 v_exp_f32", k_mix_7fma_1exp, 8, ""},
+        {"v_add_f32_dpp row_ror:8 x8", k_add_dpp_row_ror, 8, ""},
+        {"v_add_f32_dpp quad_perm x8", k_add_dpp_quad_perm, 8, ""},
+        {"v_cndmask_b32 (SGPR mask) x8", k_cndmask_sgpr, 8, ""},
+        {"v_cmp_lt_f32 -> SGPR pair x8", k_cmp_to_sgpr, 8, ""},
+        {"v_cmp -> s_and -> v_cndmask, + v_fma (x2)", k_cmp_sand_cndmask, 8, "6 VALU + 2 SALU per body"},
+        {"ds_bpermute_b32 x8 + wait", k_ds_bpermute, 8, "LDS crossbar"},
+    };
+    const int max_waves = cus * 4 * 8;
+    float* out; unsigned long long* ticks;
+    CHECK(hipMalloc(&out, sizeof(float) * 64 * (size_t)max_waves));
+    CHECK(hipMalloc(&ticks, 8 * (size_t)max_waves));
+    std::vector<unsigned long long> h(max_waves);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    printf("%-44s %5s %9s %9s %10s  %s\n", "stream", "w/SIMD", "cyc_tick", "cyc_wall", "Ginstr/s", "note");
+    for (const Stream& st : streams) {
+        for (int w : {1, 2, 4, 8}) {
+            // 256-thread blocks = 4 waves = one wave per SIMD of a CU; w blocks per CU
+            const int blocks = cus * w;
+            const double instr_per_wave = (double)ITER * REP * st.instr_per_body;
+            st.fn<<<blocks, 256>>>(out, ticks, 1.0000001f, 1e-9f);      // warm-up
+            CHECK(hipDeviceSynchronize());
+            double best_ms = 1e30; unsigned long long worst_tick = 0;
+            for (int rep = 0; rep < 5; ++rep) {
+                CHECK(hipEventRecord(e0));
+                st.fn<<<blocks, 256>>>(out, ticks, 1.0000001f, 1e-9f);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    CHECK(hipMemcpy(h.data(), ticks, 8 * (size_t)blocks * 4, hipMemcpyDeviceToHost));
+                    worst_tick = *std::max_element(h.begin(), h.begin() + blocks * 4);
+                }
+            }
+            const double cyc_tick = (double)worst_tick / (w * instr_per_wave);
+            const double cyc_wall = best_ms * 1e-3 * clock_ghz * 1e9 / (w * instr_per_wave);
+            const double ginstr = (double)blocks * 4 * instr_per_wave / (best_ms * 1e-3) * 1e-9;
+            printf("%-44s %5d %9.2f %9.2f %10.1f  %s\n", st.name, w, cyc_tick, cyc_wall, ginstr, st.note);
+        }
+    }
+    // s_memtime tick vs wall: one long kernel, ticks / wall seconds
+    {
+        k_fma_indep<<<cus, 256>>>(out, ticks, 1.0000001f, 1e-9f);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        k_fma_indep<<<cus, 256>>>(out, ticks, 1.0000001f, 1e-9f);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipMemcpy(h.data(), ticks, 8 * (size_t)cus * 4, hipMemcpyDeviceToHost));
+        const unsigned long long t = *std::max_element(h.begin(), h.begin() + cus * 4);
+        printf("# readcyclecounter: %llu ticks in %.3f us of wall (incl. launch) => >= %.3f GHz tick rate\n", t, ms * 1e3, t / (ms * 1e-3) * 1e-9);
+    }
+    return 0;
+}
