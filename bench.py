@@ -10,14 +10,16 @@ Workload (config.workload):
   N = 1 : BASELINE.json configs[2] "C3": 1M Gaussians, 1920x1080, SH degree 3, multi-scale fields with
           filter_small + filter_large, fade_size 0 (train.py:124-125), the seeded synthetic scene of
           scenes.config("C3"), all inputs resident in HBM before the timed region.
-  N > 1 : the same 1M-Gaussian scene replicated on every GPU, ONE view per GPU per step (camera yawed
-          per rank so the views differ), each followed by ONE flat fp32 all-reduce (RCCL) of the 59 floats /
-          Gaussian gradient bucket -> weak scaling (per-GPU work fixed), BASELINE.json configs[3] pattern.
-          The all-reduce of view k is issued asynchronously and overlaps the rendering of view k+1 (two buckets,
-          view_parallel.PipelinedGradExchange: the gradient-accumulation pipeline of a trainer whose optimizer
-          step covers >= 2 views per GPU); all K exchanges complete inside the timed region.  The JSON line also
-          carries `exchange.serial_allreduce` (exchange serialised after every view) and
-          `exchange.without_allreduce` (no exchange at all) measured the same way.
+  N > 1 : BASELINE.json configs[3] "C4": ONE shared 1M-Gaussian set (scenes.ball_scene, seed 4) replicated on every
+          GPU and the 8 ring cameras of scenes.config_c4(); in step k rank r renders view (k*N + r) mod 8 — ONE view
+          per GPU per step, weak scaling (per-GPU work fixed) — and the per-Gaussian gradients of the N views are
+          exchanged over RCCL INSIDE the step (an optimizer could step after every step): `value` uses
+          view_parallel.FactoredGradExchange (all-gather of the [P,3] dL/drgb factors + all-reduce of the 11 non-SH
+          floats per Gaussian, SH rows rebuilt on every rank: 161 MB per GPU per step at 8 ranks instead of 413 MB).
+          The JSON line also carries, measured the same way (SURVEY 8(e) "with and without the all-reduce"):
+          `exchange.dense_serial_allreduce` (one flat 59-float all-reduce after every view),
+          `exchange.dense_pipelined` (that all-reduce overlapped with the NEXT view: only valid when an optimizer step
+          covers >= 2 views per GPU) and `exchange.without_exchange`.
 
 Output: ONE JSON line on rank 0 (see the driver contract in the task statement) carrying `roofline`
 (dominant blend kernel: algorithmic bytes / HIP-event time / 8 TB/s) and `cpu_baseline` (the CPU oracle
@@ -42,42 +44,33 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def yawed_front_camera(scenes, width, height, rank, world):
-    """front camera rotated about +y by (rank - (world-1)/2) * 2 degrees"""
-    if world == 1:
-        return scenes.front_camera(width, height)
-    a = math.radians(2.0 * (rank - 0.5 * (world - 1)))
-    R = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
-    f = 1000.0 * width / 1920.0
-    fovx = 2.0 * math.atan(width / (2.0 * f))
-    fovy = 2.0 * math.atan(height / (2.0 * f))
-    return scenes.make_camera(R, np.zeros(3), fovx, fovy, width, height)
-
-
 def cpu_baseline(scenes, scene, settings, W, H, runs=2):
-    """The CPU oracle (kind "port": there is no reference CPU path) on the SAME workload: the
-    full scene rendered forward+backward at full resolution on all host cores (about 5-10 s per run on
-    8 cores), best of `runs`."""
+    """The CPU oracle (kind "port": there is no reference CPU path) on the SAME workload: the full scene
+    rendered forward+backward at full resolution (i) on all host cores, best of `runs` (about 1-6 s per run), and
+    (ii) once on a single thread (about 30 s) — SURVEY §8(d) asks for both."""
     from oracle import oracle_ctypes as oc
     cam = scenes.front_camera(W, H)
     bg = torch.zeros(3)
     dL = scenes.grad_seed(W, H, 2)
     cores = os.cpu_count() or 1
-    best = None
-    for _ in range(runs):
+
+    def run(nt):
         t0 = time.perf_counter()
-        r = oc.rasterize(scene, cam, settings, bg, num_threads=cores)
+        r = oc.rasterize(scene, cam, settings, bg, num_threads=nt)
         t1 = time.perf_counter()
-        oc.backward(r, dL, num_threads=cores)
+        oc.backward(r, dL, num_threads=nt)
         t2 = time.perf_counter()
-        if best is None or (t2 - t0) < best[0]:
-            best = (t2 - t0, t1 - t0, t2 - t1)
         del r
+        return (t2 - t0, t1 - t0, t2 - t1)
+    best = min((run(cores) for _ in range(runs)), key=lambda t: t[0])
+    one = run(1)
     dt = best[0]
     return {"value": round(W * H / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "seconds": round(dt, 2), "fwd_s": round(best[1], 2), "bwd_s": round(best[2], 2),
+            "single_thread": {"value": round(W * H / 1e6 / one[0], 4), "cores": 1, "seconds": round(one[0], 2),
+                              "fwd_s": round(one[1], 2), "bwd_s": round(one[2], 2)},
             "sample": f"the whole workload (same scene, settings, {W}x{H}), forward+backward, float32 "
-                      f"C++/OpenMP oracle on all {cores} host cores, best of {runs} runs"}
+                      f"C++/OpenMP oracle: all {cores} host cores (best of {runs} runs) and one thread (one run)"}
 
 
 def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup):
@@ -86,7 +79,7 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
     from synthetic_model import SyntheticGaussians
     from train_epilogue import FusedAdam
     from train_step import fused_train_iteration
-    from parity_utils import PIPE
+    from gaussian_renderer import PIPE
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
     out = {}
 
@@ -173,12 +166,18 @@ def main():
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
     from view_parallel import PipelinedGradExchange
-    from parity_utils import PIPE
+    from gaussian_renderer import PIPE
 
     W, H, P = args.width, args.height, args.gaussians
-    settings = dict(filter_small=True, filter_large=True, fade_size=0.0)
-    scene = scenes.frustum_scene(P, W, H, seed=2, sh_degree=3, multiscale=True)
-    cam = yawed_front_camera(scenes, W, H, rank, world).to(dev)
+    if world == 1:      # C3
+        settings = dict(filter_small=True, filter_large=True, fade_size=0.0)
+        scene = scenes.frustum_scene(P, W, H, seed=2, sh_degree=3, multiscale=True)
+        cams = [scenes.front_camera(W, H).to(dev)]
+    else:               # C4: one shared world-space set, 8 ring cameras, view v -> rank v mod N
+        scene, cams, settings = scenes.config_c4(n_views=8, P=P, width=W, height=H)
+        cams = [c.to(dev) for c in cams]
+    n_views = len(cams)
+    cam = cams[0]
     pc = SyntheticGaussians(scene, dev, requires_grad=True)
     # N > 1: parameter .grad tensors are views into a flat fp32 bucket (two buckets, used alternately): the all-reduce
     #        of view k runs on RCCL's stream while view k+1 is rendered (PipelinedGradExchange); every exchange
@@ -187,7 +186,8 @@ def main():
     # (direct: the backward writes each view's gradients straight into the bucket — no zero-fill, no accumulation pass;
     #  available because the op chains the reference's getters itself)
     direct = bool(dgr.chain_reference_getters)
-    exchange = PipelinedGradExchange(pc.parameters(), world, direct=direct) if world > 1 else None
+    from view_parallel import FactoredGradExchange
+    exchange = FactoredGradExchange(pc, world) if world > 1 else None
     bg = torch.zeros(3, device=dev)
     dL = scenes.grad_seed(W, H, 2).to(dev)
     torch.cuda.synchronize()
@@ -197,20 +197,29 @@ def main():
     TIMER_STRIDE = 4
     timers = {} if args.no_kernel_timing else {k: dgr._C.KernelTimer() for k in range(0, args.steps, TIMER_STRIDE)}
 
+    step_no = [0]
+
+    def next_cam():
+        c = cams[(step_no[0] * world + rank) % n_views]
+        step_no[0] += 1
+        return c
+
     def step(timer=None):
         dgr._C.set_timer(timer)
+        c = next_cam()
         if exchange is not None:
             exchange.begin_view()
         else:
             for p_ in pc.parameters():
                 p_.grad = None
-        out = render(cam, pc, PIPE, bg, **settings)
+        out = render(c, pc, PIPE, bg, **settings)
         out["render"].backward(dL)               # fixed dL/dimage (SURVEY §8(d) 'backward seed')
-        if exchange is not None:
-            exchange.end_view()
+        if exchange is not None:                 # the exchange completes INSIDE the step: every .grad is final here
+            exchange.end_view(c.camera_center)
+            exchange.finish()
         return out
 
-    def timed_region(fn, n):
+    def timed_region(fn, n, drain=None):
         """barrier + synchronize on both sides, MAX over ranks (the driver's contract)"""
         if world > 1:
             dist.barrier()
@@ -218,8 +227,8 @@ def main():
         t = time.perf_counter()
         for k in range(n):
             fn(k)
-        if exchange is not None:
-            exchange.drain()
+        if drain is not None:
+            drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -233,20 +242,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if exchange is not None:
-        exchange.drain()
     elapsed = timed_region(lambda k: step(timers.get(k)), args.steps)
     dgr._C.set_timer(None)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * (W * H / 1e6) / (elapsed / args.steps)
 
-    # N > 1, informational ("with and without the all-reduce"): the same K steps (a) with the exchange
-    # serialised after each view (one optimizer step per view: nothing to overlap with) and (b) without any exchange,
-    # i.e. pure view-sharded rendering fwd+bwd.  `value` above INCLUDES every all-reduce (overlapped).
+    # N > 1, informational ("with and without the all-reduce"), the same K steps with
+    #   (a) the dense exchange serialised after each view: ONE flat all-reduce of the 59 floats / Gaussian
+    #   (b) that dense all-reduce overlapped with the rendering of the NEXT view (two buckets; an optimizer step then
+    #       has to cover >= 2 views per GPU)
+    #   (c) no exchange at all: pure view-sharded rendering fwd+bwd
+    # `value` above INCLUDES the complete (factored) exchange in every step.
     extra = None
     if world > 1:
-        bucket = exchange.buckets[0]
+        from view_parallel import FlatGradBucket
+        for p_ in pc.parameters():
+            p_.grad = None
+        bucket = FlatGradBucket(pc.parameters())
 
         def prepare(bk):
             if direct:
@@ -257,36 +270,60 @@ def main():
 
         def step_serial(k):
             prepare(bucket)
-            render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+            render(next_cam(), pc, PIPE, bg, **settings)["render"].backward(dL)
             bucket.all_reduce(average_over=world)
 
         def step_local(k):
             prepare(bucket)
-            render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+            render(next_cam(), pc, PIPE, bg, **settings)["render"].backward(dL)
         step_serial(0)
         ts = timed_region(step_serial, args.steps) / args.steps
         step_local(0)
         tl = timed_region(step_local, args.steps) / args.steps
         dgr.set_grad_sinks(None)
+        del bucket
+        pipe = PipelinedGradExchange(pc.parameters(), world, direct=direct)
+
+        def step_pipe(k):
+            pipe.begin_view()
+            render(next_cam(), pc, PIPE, bg, **settings)["render"].backward(dL)
+            pipe.end_view()
+        step_pipe(0)
+        pipe.drain()
+        tp = timed_region(step_pipe, args.steps, drain=pipe.drain) / args.steps
+        dgr.set_grad_sinks(None)
         mp = world * (W * H / 1e6)
-        extra = {"serial_allreduce": {"ms_per_step": round(1e3 * ts, 4), "value": round(mp / ts, 3)},
-                 "without_allreduce": {"ms_per_step": round(1e3 * tl, 4), "value": round(mp / tl, 3)},
-                 "unit": "Mpixels/s", "allreduce_bytes_per_step": 4 * sum(p_.numel() for p_ in pc.parameters())}
+        dense_bytes = 4 * sum(p_.numel() for p_ in pc.parameters())
+        extra = {"dense_serial_allreduce": {"ms_per_step": round(1e3 * ts, 4), "value": round(mp / ts, 3)},
+                 "dense_pipelined": {"ms_per_step": round(1e3 * tp, 4), "value": round(mp / tp, 3),
+                                     "note": "all-reduce of view k overlapped with view k+1: needs >= 2 views per GPU "
+                                             "per optimizer step"},
+                 "without_exchange": {"ms_per_step": round(1e3 * tl, 4), "value": round(mp / tl, 3)},
+                 "unit": "Mpixels/s", "dense_allreduce_bytes": dense_bytes,
+                 "factored_bytes_received_per_gpu": exchange.bytes_per_step()}
 
     result = {
         "metric": "Mpixels/s fwd+bwd @1080p, 1M Gaussians; fraction of HBM roofline",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("C3: 1M Gaussians, 1920x1080, SH3, multi-scale filter_small+filter_large, fade 0"
-                                if (P, W, H) == (1_000_000, 1920, 1080) else f"custom: {P} Gaussians {W}x{H}"),
+        "config": {"workload": (
+            ("C3 (BASELINE configs[2]): 1M Gaussians, 1920x1080, SH3, multi-scale fields, filter_small+filter_large, "
+             "fade 0; frozen seeded scene scenes.config('C3') [SCALE_K 0.004: D/P = 9.6 instances per Gaussian by the "
+             "reference's 3-sigma-rect duplication (SURVEY 8(d) asks 8-12), 4.1 after this build's exact culling, "
+             "V/P = 0.56 rendered]" if world == 1 else
+             "C4 (BASELINE configs[3]): ONE shared 1M-Gaussian ball (scenes.config_c4, seed 4), 8 ring cameras, "
+             "1920x1080, SH3; step k: rank r renders view (k*N + r) mod 8; per-Gaussian gradients exchanged over RCCL "
+             "inside every step")
+            if (P, W, H) == (1_000_000, 1920, 1080) else f"custom: {P} Gaussians {W}x{H}"),
                    "gaussians": P, "width": W, "height": H, "views_per_gpu_per_step": 1,
                    "api": "reference API: gaussian_renderer.render() -> GaussianRasterizer.forward(13 kwargs); the op "
                           "recognises the reference's getters in the autograd graph and chains their backward inside "
                           "msgs_backward (chain_reference_getters=" + str(bool(dgr.chain_reference_getters)) + ")",
-                   "parallelism": f"view-parallel x{world}" + (", flat fp32 grad all-reduce (RCCL) of view k overlapped with "
-                                                                "the rendering of view k+1 (2 buckets" + (", gradients written straight into the "
-                                                                "bucket" if world > 1 and direct else "") + ")" if world > 1 else "")},
+                   "parallelism": f"view-parallel x{world}" + (
+                       ": replicated parameters, one view per GPU per step, factored gradient exchange (all-gather of "
+                       "the [P,3] dL/drgb factors + all-reduce of the 11 non-SH floats; SH gradient rows rebuilt on "
+                       "every rank), complete inside the step" if world > 1 else "")},
     }
 
     if rank == 0:

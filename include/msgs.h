@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 3
+#define MSGS_ABI_VERSION 4
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -115,7 +115,9 @@ typedef struct msgs_grads {
     float* dL_dmeans3D;        /* [P,3]                                                              */
     float* dL_dmeans2D;        /* [P,3]   (x,y in the NDC-ish units of SURVEY App. A.3; z = 0)       */
     float* dL_dshs;            /* [P,K,3] when shs was given                                         */
-    float* dL_dcolors;         /* [P,3]   when colors_precomp was given                              */
+    float* dL_dcolors;         /* [P,3]   when colors_precomp was given; also in the raw modes with both
+                                *          dL_dfeatures_* NULL: the FACTORED SH gradient — the clamp-masked dL/drgb
+                                *          of this view, from which msgs_sh_grad_from_views rebuilds dL/dSH      */
     float* dL_dopacities;      /* [P]                                                                */
     float* dL_dscales;         /* [P,3]   when scales/rotations were given                           */
     float* dL_drotations;      /* [P,4]                                                              */
@@ -189,6 +191,19 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g,
                   void* scratch, size_t scratch_bytes,
                   const msgs_grads_t* grads,
                   const msgs_timing_t* timing, void* stream);
+
+/* ---- view-parallel gradient exchange (new relative to the single-GPU reference) -------------------
+ * The SH part of one view's gradient (48 of the 59 floats per Gaussian) is the outer product of the 16 SH basis values
+ * of the viewing direction and the 3 floats dL/drgb: msgs_backward delivers just dL/drgb (msgs_grads_t.dL_dcolors in
+ * the raw modes), the ranks all-gather those [P,3] factors and every rank rebuilds
+ *     dL/dfeatures_{dc,rest}[i] = scale * sum_v basis(normalize(means3D[i] - campos[v])) x drgb[v][i]
+ * with the products msgs_backward itself would have formed (bit-identical per view), added in view order.
+ * View v's camera centre is campos + v * campos_stride (3 floats), its factors drgb + v * drgb_stride ([P,3] floats,
+ * zeros where the view did not render the Gaussian) — strides in floats, so the rows of one all-gathered buffer
+ * {factors | camera centre} can be read in place.  Outputs are fully written. */
+int msgs_sh_grad_from_views(int32_t P, int32_t n_views, int32_t sh_degree, const float* means3D, const float* campos,
+                            int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
+                            float* dL_dfeatures_dc, float* dL_dfeatures_rest, void* stream);
 
 /* ---- optional -------------------------------------------------------------------------------- */
 /* visibility mask only (upstream markVisible; present[P] uint8) */

@@ -320,7 +320,9 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
         scratch_bytes < (det ? msgs_backward_scratch_bytes_deterministic(P, D) : msgs_backward_scratch_bytes(P)))
         return MSGS_ERR_CAPACITY;
     if (g->shs && !g->raw_params && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
-    if (g->raw_params && (!grads->dL_dfeatures_dc || !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
+    // raw modes: either both SH gradient tensors, or neither plus dL_dcolors (factored SH gradient, msgs.h)
+    if (g->raw_params && (!grads->dL_dfeatures_dc != !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
+    if (g->raw_params && !grads->dL_dfeatures_dc && !grads->dL_dcolors) return MSGS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const char* geom = (const char*)geom_v;
     const char* binning = (const char*)binning_v;
@@ -348,6 +350,17 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s));
     tm.end(MSGS_K_PREPROCESS_BWD);
     return debug_sync(view, s);
+}
+
+int msgs_sh_grad_from_views(int32_t P, int32_t n_views, int32_t sh_degree, const float* means3D, const float* campos,
+                            int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
+                            float* dL_dfeatures_dc, float* dL_dfeatures_rest, void* stream) {
+    if (P < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || campos_stride < 0 || drgb_stride < 0)
+        return MSGS_ERR_INVALID_ARG;
+    if (P > 0 && (!means3D || !campos || !drgb || !dL_dfeatures_dc || !dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
+    HIP_TRY(launch_sh_grad_from_views(P, n_views, sh_degree, means3D, campos, campos_stride, drgb, drgb_stride, scale,
+                                      dL_dfeatures_dc, dL_dfeatures_rest, (hipStream_t)stream));
+    return MSGS_OK;
 }
 
 int msgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

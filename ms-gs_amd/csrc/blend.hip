@@ -85,6 +85,7 @@ __device__ __forceinline__ int swizzled_tile(int bid, int num_tiles) {
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
+template <bool PREFETCH>
 __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
@@ -141,10 +142,12 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
         uint32_t last_off = 0xFFFFFFFFu;                     // byte offset of the last entry blended in THIS batch
         // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
         //  the LDS reads costs more than the two address instructions it saves)
-        auto blend_entry = [&](uint32_t off) {
-            const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
-            const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
-            const float4 r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
+        auto fetch = [&](uint32_t off, float4& r0, float4& r1, float4& r2) {
+            r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
+            r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
+            r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
+        };
+        auto blend_rec = [&](uint32_t off, const float4& r0, const float4& r1, const float4& r2) {
             const float dx = r0.x - pxf, dy = r0.y - pyf;
             const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
             const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
@@ -162,16 +165,44 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             T = blend ? test_T : T;
             last_off = blend ? off : last_off;
         };
+        auto blend_entry = [&](uint32_t off) {
+            float4 r0, r1, r2;
+            fetch(off, r0, r1, r2);
+            blend_rec(off, r0, r1, r2);
+        };
         const uint16_t* lp = s_list[w];
-        int j = 0;
-        for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
-            if (alive == 0) break;
-            const uint32_t o0 = lp[j], o1 = lp[j + 1];
-            blend_entry(o0);
-            if (alive == 0) break;
-            blend_entry(o1);
+        if (PREFETCH) {
+            // software pipeline: the record of entry j+1 is fetched from LDS (list offset, then three 16-byte reads: two
+            // dependent LDS round trips) while entry j is evaluated — PMC showed the waves parked on s_waitcnt half of
+            // their time with the fetch in front of every evaluation (two register sets, ping-pong: no moves)
+            if (cnt > 0) {
+                uint32_t offA = lp[0], offB = 0;
+                float4 a0, a1, a2, b0, b1, b2;
+                fetch(offA, a0, a1, a2);
+                for (int j = 0;; j += 2) {
+                    const bool hasB = j + 1 < cnt;
+                    if (hasB) { offB = lp[j + 1]; fetch(offB, b0, b1, b2); }
+                    if (alive == 0) break;
+                    blend_rec(offA, a0, a1, a2);
+                    if (!hasB) break;
+                    const bool hasA = j + 2 < cnt;
+                    if (hasA) { offA = lp[j + 2]; fetch(offA, a0, a1, a2); }
+                    if (alive == 0) break;
+                    blend_rec(offB, b0, b1, b2);
+                    if (!hasA) break;
+                }
+            }
+        } else {
+            int j = 0;
+            for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
+                if (alive == 0) break;
+                const uint32_t o0 = lp[j], o1 = lp[j + 1];
+                blend_entry(o0);
+                if (alive == 0) break;
+                blend_entry(o1);
+            }
+            if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
         }
-        if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
     if (inside) {
@@ -866,6 +897,131 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     }
 }
 
+// Software-pipelined variant of blend_backward_tile_kernel (same arithmetic, same sums, bit-identical values per
+// (tile, Gaussian); only WHEN things are issued differs).  PMC of the plain kernel: a wave issues one VALU instruction
+// per ~16 cycles (tools/valu_calib: one wave alone can issue every 5, the SIMD every 2) — its time is latency, not
+// issue: per entry the LDS record fetch, the two DEPENDENT ds_bpermute of the cross-row step and the atomics sit
+// exposed on the wave's in-order stream, and with ~3.5 resident waves per SIMD nothing covers them.  Here
+//   * the records of the NEXT entry are fetched from LDS before the current entry is evaluated, and
+//   * the cross-row reduction + atomic of entry k are deferred into entry k+1's evaluation: first ds_bpermute at the
+//     top, second one after two quadrant steps, atomic after the last — each LDS round trip is covered by ~70 VALU
+//     instructions of independent work.
+template <bool DET>
+__global__ __launch_bounds__(64) void blend_backward_tile_pipe_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                                      const uint32_t* __restrict__ ids,
+                                                                      const uint2* __restrict__ ranges,
+                                                                      const float* __restrict__ final_T,
+                                                                      const uint32_t* __restrict__ n_contrib,
+                                                                      const float* __restrict__ dL_dcolor,
+                                                                      float* __restrict__ grad_rec) {
+    __shared__ float4 s_r0[WB], s_r1[WB];
+    __shared__ float4 s_bi[WB];
+    const int num_tiles = vp.gx * vp.gy;
+    const int lane = threadIdx.x;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
+    const float bxf = (float)bx, byf = (float)by;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const size_t N = (size_t)vp.W * vp.H;
+
+    BwdQuad q0, q1, q2, q3;
+    uint32_t ql0, ql1, ql2, ql3;
+    {
+        auto init = [&](BwdQuad& s, int qi) -> uint32_t {
+            const int px = bx + (qi & 1) * 8, py = by + (qi >> 1) * 8;
+            const bool inside = px < vp.W && py < vp.H;
+            const size_t pix = (size_t)py * vp.W + px;
+            const float Tf = inside ? final_T[pix] : 1.0f;
+            s.last = inside ? n_contrib[pix] : 0u;
+            s.dL0 = inside ? dL_dcolor[pix] : 0.f;
+            s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
+            s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
+            s.S = vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2;
+            s.T = Tf;
+            return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
+        };
+        ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
+    }
+    const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
+    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);
+    const uint32_t aoff = row_reduce_component(lane);
+    const int xrow16 = (lane ^ 16) << 2, xrow32 = (lane ^ 32) << 2;
+
+    // deferred reduction of the previous contributing entry (wave-uniform control)
+    float pend = 0.f;
+    float* pend_dst = nullptr;                             // wave-uniform destination record; nullptr = nothing pending
+    auto finish1 = [&]() { return __int_as_float(__builtin_amdgcn_ds_bpermute(xrow16, __float_as_int(pend))); };
+    auto finish2 = [&]() { return __int_as_float(__builtin_amdgcn_ds_bpermute(xrow32, __float_as_int(pend))); };
+    auto commit = [&]() {
+        if (alane) {
+            if (DET) pend_dst[aoff] = pend; else unsafeAtomicAdd(pend_dst + aoff, pend);
+        }
+        pend_dst = nullptr;
+    };
+
+    const int nb = ((int)tile_last + WB - 1) / WB;
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    uint32_t nid = 0;
+    if (nb > 0) {
+        const int i0 = (nb - 1) * WB + lane;
+        if (i0 < (int)tile_last) { nid = ids[range.x + i0]; n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2; }
+    }
+    for (int b = nb - 1; b >= 0; --b) {
+        const int base = b * WB;
+        const int n = min(WB, (int)tile_last - base);
+        wave_fence();
+        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
+        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
+        const uint32_t mypos = (uint32_t)(base + lane);
+        const uint64_t h0 = __ballot((mymask & 1u) && mypos < ql0), h1 = __ballot((mymask & 2u) && mypos < ql1),
+                       h2 = __ballot((mymask & 4u) && mypos < ql2), h3 = __ballot((mymask & 8u) && mypos < ql3);
+        wave_fence();
+        if (b > 0) {
+            nid = ids[range.x + base - WB + lane];
+            n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2;
+        }
+        uint64_t todo = h0 | h1 | h2 | h3;
+        if (todo == 0) continue;
+        int e = 63 - __builtin_clzll(todo);
+        float4 pr0 = s_r0[e], pr1 = s_r1[e], pbi = s_bi[e];            // records of the first entry of the batch
+        while (todo) {
+            const uint64_t bit = 1ull << e;
+            todo &= ~bit;
+            const uint32_t pos0 = (uint32_t)(base + e);
+            const float4 r0 = pr0, r1 = pr1;
+            const float cb = pbi.x;
+            const uint32_t gid_v = __float_as_uint(pbi.y);
+            if (todo) {                                                // next entry's records: in flight during this one
+                e = 63 - __builtin_clzll(todo);
+                pr0 = s_r0[e]; pr1 = s_r1[e]; pbi = s_bi[e];
+            }
+            const float dx = r0.x - bxf, dy = r0.y - byf;
+            float b16 = 0.f;
+            if (pend_dst) b16 = finish1();
+            BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            uint64_t any = 0;
+            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
+            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
+            float b32 = 0.f;
+            if (pend_dst) { pend += b16; b32 = finish2(); }
+            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
+            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
+            if (pend_dst) { pend += b32; commit(); }
+            if (any == 0) continue;
+            pend = row_reduce_scatter9(v);
+            if (DET) pend_dst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;
+            else pend_dst = grad_rec + (size_t)__builtin_amdgcn_readfirstlane(gid_v) * GRAD_REC_FLOATS;
+        }
+    }
+    if (pend_dst) {
+        pend += finish1();
+        pend += finish2();
+        commit();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // statistics for the algorithmic-bytes formula: D_trav = sum_tiles max_pixels n_contrib, V = #radii>0
 // ---------------------------------------------------------------------------------------------
@@ -921,6 +1077,10 @@ static bool use_fine(int tiles, int max_tiles) {
     const int g = g_granularity.load();
     return g == 2 || (g == 0 && tiles < max_tiles);
 }
+// MSGS_FWD_PREFETCH=0 selects the forward without the LDS record prefetch (A/B measurements)
+static const bool g_fwd_prefetch = [] { const char* e = getenv("MSGS_FWD_PREFETCH"); return !(e && e[0] == '0'); }();
+// MSGS_BWD_PIPE=0 selects the un-pipelined one-wave-per-tile backward (A/B measurements)
+static const bool g_bwd_pipe = [] { const char* e = getenv("MSGS_BWD_PIPE"); return !(e && e[0] == '0'); }();
 static bool bwd_v1(int tiles) {
     const int forced = g_bwd_gen.load();
     return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
@@ -936,8 +1096,11 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
         hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
+    else if (fwd_gen == 1 && g_fwd_prefetch)
+        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib);
     else if (fwd_gen == 1)
-        hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
@@ -954,6 +1117,9 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD)))
         hipLaunchKernelGGL(blend_backward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
+    else if (!bwd_v1(tiles) && g_bwd_pipe)
+        hipLaunchKernelGGL(blend_backward_tile_pipe_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
+                           final_T, n_contrib, dL_dcolor, grad_rec);
     else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
@@ -977,17 +1143,20 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const uint32_t* __restr
     if (q >= D) return;
     const uint32_t g = gid_sorted[q];
     if (q > 0 && gid_sorted[q - 1] == g) return;               // not the head of its segment
-    float acc[DET_INST_FLOATS];
+    // the per-tile sums of one Gaussian are added in DOUBLE: a Gaussian that covers hundreds of tiles otherwise loses
+    // ~1e-6 of its sums to float32 accumulation, which the conic -> covariance chain of K8 amplifies by the squared
+    // aspect ratio (measured at C2: dL/dscale 2.5e-4 from the oracle with float accumulation; profiles/r2_parity_floor.md)
+    double acc[DET_INST_FLOATS];
 #pragma unroll
-    for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] = 0.f;
+    for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] = 0.0;
     for (int64_t k = q; k < D && gid_sorted[k] == g; ++k) {
         const float* src = inst_grad + (size_t)entry_of[k] * DET_INST_FLOATS;
 #pragma unroll
-        for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] += src[c];
+        for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] += (double)src[c];
     }
     float* dst = grad_rec + (size_t)g * GRAD_REC_FLOATS;
 #pragma unroll
-    for (int c = 0; c < DET_INST_FLOATS; ++c) dst[c] = acc[c];
+    for (int c = 0; c < DET_INST_FLOATS; ++c) dst[c] = (float)acc[c];
 }
 }  // namespace
 
@@ -1017,8 +1186,12 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
     hipError_t e = launch_zero(inst, sizeof(float) * DET_INST_FLOATS * (size_t)D, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
-                       n_contrib, dL_dcolor, inst);
+    if (g_bwd_pipe)
+        hipLaunchKernelGGL(blend_backward_tile_pipe_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
+                           final_T, n_contrib, dL_dcolor, inst);
+    else
+        hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
+                           n_contrib, dL_dcolor, inst);
     e = hipMemcpyAsync(keys, ids, 4 * (size_t)D, hipMemcpyDeviceToDevice, s);      // the sort clobbers its input
     if (e != hipSuccess) return e;
     int bits = 1;

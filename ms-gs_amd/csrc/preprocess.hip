@@ -581,6 +581,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     const bool raw = g.raw_params != 0;
     const bool split_in = raw && g.shs == nullptr;
     const bool staged_sh = raw || (g.shs != nullptr && grads.dL_dshs != nullptr && K == 16);   // wave-uniform
+    // factored SH gradient (view-parallel exchange, msgs_sh_grad_from_views): dL/dSH of one view is the outer product
+    // basis(direction) x dL/drgb, so only the (clamp-masked) dL/drgb is delivered and the 192-byte rows are not written
+    const bool factored_sh = raw && grads.dL_dfeatures_dc == nullptr;
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
     if (split_in) {
@@ -595,8 +598,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
                        sh_row_float4s(deg), lane);
         wave_lds_fence();
     }
-    float* dsh = staged_sh ? &s_rows[wv][lane * ROW_LDS]
-                           : (grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr);
+    float* dsh = factored_sh ? nullptr
+                 : staged_sh ? &s_rows[wv][lane * ROW_LDS]
+                             : (grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr);
     // (raw mode: the LDS row receives the gradient of the concatenated [dc | rest] coefficients)
 
     if (rendered) {
@@ -795,13 +799,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     } else if (dsh && !staged_sh) {
         for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
     }
-    if (raw) {
+    if (raw && !factored_sh) {
         wave_lds_fence();
         const int nrow = min(64, P - wave_first);
         if (nrow > 0)
             coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range, wave_first,
                                   nrow, live, 3 * (deg + 1) * (deg + 1), lane);
-    } else if (staged_sh) {
+    } else if (staged_sh && !raw) {
         wave_lds_fence();
         const int nrow = min(64, P - wave_first);
         if (nrow > 0)
@@ -820,6 +824,56 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
 #pragma unroll
         for (int k = 0; k < 6; ++k) grads.dL_dcov3D[6 * i + k] = dcov[k];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Factored SH gradient of N views -> dL/dfeatures_dc, dL/dfeatures_rest  (view-parallel exchange)
+//   dL/dSH[i][k][c] = scale * sum_v basis_k(normalize(p_i - campos_v)) * drgb[v][i][c]
+// — exactly the products preprocess_backward_kernel forms for one view (same expressions, contraction off), added in
+// view order, so every rank reconstructs bit-identical sums from the gathered [N,P,3] factors instead of exchanging
+// 48 floats per Gaussian.  One thread per Gaussian, rows leave through LDS like K9's.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sh_grad_from_views_kernel(int P, int n_views, int deg,
+                                                                 const float* __restrict__ means3D,
+                                                                 const float* __restrict__ campos,   // view v at campos + v*cs
+                                                                 int64_t cs,
+                                                                 const float* __restrict__ drgb,     // view v: [P,3] at drgb + v*ds
+                                                                 int64_t ds, float scale, float* __restrict__ d_dc,
+                                                                 float* __restrict__ d_rest) {
+    __shared__ float s_rows[4][64 * ROW_LDS];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in_range = i < P;
+    const int wave_first = blockIdx.x * blockDim.x + wv * 64;
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+    if (in_range) {
+        const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+        for (int v = 0; v < n_views; ++v) {
+            const float* d = drgb + (size_t)v * ds + (size_t)i * 3;
+            const float* cp = campos + (size_t)v * cs;
+            const float d0 = d[0], d1 = d[1], d2 = d[2];
+            if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;          // not rendered in this view (or fully clamped)
+            const float dox = p[0] - cp[0], doy = p[1] - cp[1], doz = p[2] - cp[2];
+            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+            float b[16];
+            sh_basis(deg, dox / len, doy / len, doz / len, b);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[3 * k] = acc[3 * k] + b[k] * d0;
+                acc[3 * k + 1] = acc[3 * k + 1] + b[k] * d1;
+                acc[3 * k + 2] = acc[3 * k + 2] + b[k] * d2;
+            }
+        }
+    }
+    float* row = &s_rows[wv][lane * ROW_LDS];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) row[k] = acc[k] * scale;
+    wave_lds_fence();
+    const int nrow = min(64, P - wave_first);
+    if (nrow > 0)
+        coop_store_split_rows(s_rows[wv], d_dc, d_rest, i, in_range, wave_first, nrow, ~0ull, 48, lane);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ V,
@@ -853,6 +907,15 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
     if (g.P == 0) return hipSuccess;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
                        grad_rec, grads);
+    return hipGetLastError();
+}
+
+hipError_t launch_sh_grad_from_views(int P, int n_views, int deg, const float* means3D, const float* campos,
+                                     int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
+                                     float* d_dc, float* d_rest, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, n_views, deg, means3D,
+                       campos, campos_stride, drgb, drgb_stride, scale, d_dc, d_rest);
     return hipGetLastError();
 }
 

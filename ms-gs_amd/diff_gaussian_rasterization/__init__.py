@@ -356,9 +356,21 @@ def _check_saved(ctx):
         ctx.saved_tensors              # raises "modified by an inplace operation" when a version changed
 
 
-def set_grad_sinks(mapping):
-    """mapping: {leaf parameter: destination tensor (float32, contiguous, same numel)} or None to clear."""
+_sh_factor_sink = [None]
+
+
+def set_grad_sinks(mapping, sh_factor=None):
+    """mapping: {leaf parameter: destination tensor (float32, contiguous, same numel)} or None to clear.
+    sh_factor: optional [P,3] float32 destination.  When given, the backward of the raw / chained entries does NOT form
+    the 48-float SH gradient rows: it writes this view's clamp-masked dL/drgb there (the SH gradient is the outer product
+    basis(direction) x dL/drgb, rebuilt by sh_grad_from_views after the ranks have exchanged the factors) and returns
+    None for features_dc / features_rest."""
     _grad_sinks.clear()
+    _sh_factor_sink[0] = None
+    if sh_factor is not None:
+        if sh_factor.dtype != torch.float32 or not sh_factor.is_contiguous() or sh_factor.dim() != 2 or sh_factor.shape[1] != 3:
+            raise ValueError("sh_factor sink must be a contiguous float32 [P,3] tensor")
+        _sh_factor_sink[0] = sh_factor
     if mapping:
         for leaf, dest in mapping.items():
             if dest.dtype != torch.float32 or not dest.is_contiguous() or dest.numel() != leaf.numel():
@@ -411,10 +423,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             dL = _f32c(grad_color)
             kx, kdc, krest, kop, ksc, krot = ctx.leaf_keys
             g_m2 = torch.empty(P, 3, dtype=torch.float32, device=dev)
-            g_xyz, g_dc, g_rest = _grad_out(kx, (P, 3), dev), _grad_out(kdc, dc_shape, dev), _grad_out(krest, rest_shape, dev)
+            factor = _sh_factor_sink[0]
+            if factor is not None and (factor.device != dev or factor.shape[0] != P):
+                raise ValueError("sh_factor sink does not match this model (device / number of Gaussians)")
+            g_xyz = _grad_out(kx, (P, 3), dev)
+            g_dc = g_rest = None
+            if factor is None:
+                g_dc, g_rest = _grad_out(kdc, dc_shape, dev), _grad_out(krest, rest_shape, dev)
             g_opac, g_scal, g_rot = _grad_out(kop, op_shape, dev), _grad_out(ksc, (P, 3), dev), _grad_out(krot, (P, 4), dev)
             scratch = _backward_scratch(P, D, dev)
-            grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, None, _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
+            grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, _ptr(factor), _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
                              _ptr(g_dc), _ptr(g_rest))
             _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
@@ -509,6 +527,28 @@ def _match_reference_getters(means3D, sh, opacities, scales, rotations):
         return leaves
     except (AttributeError, IndexError, TypeError):
         return None
+
+
+def sh_grad_from_views(means3D, gathered, n_views, sh_degree, scale, out_dc, out_rest):
+    """out_dc [P,1,3], out_rest [P,15,3] = scale * sum_v basis(normalize(means3D - campos_v)) x drgb_v
+    (include/msgs.h msgs_sh_grad_from_views): the SH gradient of n_views views rebuilt from their factors.
+    `gathered` is the all-gathered exchange buffer [n_views, 3P + 4]: row v = {drgb_v [P,3] | campos_v [3] | pad}."""
+    P = int(means3D.shape[0])
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("sh_grad_from_views: tensors must live on a HIP device (no CPU path)")
+    row = 3 * P + 4
+    for t, name, numel in ((means3D, "means3D", 3 * P), (gathered, "gathered", n_views * row), (out_dc, "out_dc", 3 * P),
+                           (out_rest, "out_rest", 45 * P)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != numel or t.device != dev:
+            raise ValueError(f"sh_grad_from_views: {name} must be a contiguous float32 tensor of {numel} elements on {dev}")
+    base = gathered.data_ptr()
+    with _on_device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _C.check(_C.lib.msgs_sh_grad_from_views(P, int(n_views), int(sh_degree), _ptr(means3D),
+                                                C.c_void_p(base + 4 * 3 * P), row, C.c_void_p(base), row, float(scale),
+                                                _ptr(out_dc), _ptr(out_rest), stream), "msgs_sh_grad_from_views")
+    return out_dc, out_rest
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,

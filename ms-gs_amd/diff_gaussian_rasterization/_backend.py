@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -113,6 +113,9 @@ def _load():
     lib.msgs_backward.restype = C.c_int
     lib.msgs_backward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, sz, C.c_int64, vp, sz, vp, sz,
                                   vp, vp, sz, C.POINTER(Grads), C.POINTER(Timing), vp]
+    lib.msgs_sh_grad_from_views.restype = C.c_int
+    lib.msgs_sh_grad_from_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, C.c_int64,
+                                                C.c_float, vp, vp, vp]
     lib.msgs_mark_visible.restype = C.c_int
     lib.msgs_mark_visible.argtypes = [C.c_int32, vp, vp, vp, vp, vp]
     lib.msgs_binning_stats.restype = C.c_int
@@ -163,7 +166,7 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
-           "msgs_set_backward_generation", "msgs_set_blend_granularity")
+           "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views")
 
 
 def check(rc, where):

@@ -14,11 +14,15 @@ Duck typing:
   viewpoint_camera — Camera / MiniCam attributes (/root/reference/scene/cameras.py:17-76)
 """
 import math
+import types
 
 import torch
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
 from .sh import eval_sh
+
+# PipelineParams defaults of the reference (/root/reference/arguments/__init__.py:64-69)
+PIPE = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 RESULT_KEYS = ("render", "acc_pixel_size", "depth", "viewspace_points", "visibility_filter", "radii",
                "pixel_sizes")

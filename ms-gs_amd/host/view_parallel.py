@@ -143,6 +143,168 @@ class PipelinedGradExchange:
             self._finish(i)
 
 
+class FactoredGradExchange:
+    """Gradient exchange for ONE view per GPU per optimizer step (BASELINE config C4: 8 views over 8 GPUs), where
+    nothing can hide a dense 59-floats-per-Gaussian all-reduce (every gradient is final only after the last backward
+    kernel and the optimizer needs it before the next forward).  It moves 2.6x fewer bytes instead:
+
+      * 48 of the 59 floats are the SH gradient, which for ONE view is the outer product of the 16 SH basis values of
+        the viewing direction (a function of the replicated means and the view's camera centre, which every rank can
+        evaluate) and the 3 floats dL/drgb.  The rasterizer's backward therefore delivers only dL/drgb [P,3]
+        (diff_gaussian_rasterization.set_grad_sinks(..., sh_factor=...)); the ranks ALL-GATHER {dL/drgb | camera
+        centre} (12 B per Gaussian per rank) and each rank rebuilds  (1/N) sum_v basis_v x drgb_v  with one kernel
+        (msgs_sh_grad_from_views: the same products the backward would have formed, added in view order, so every rank
+        holds bit-identical results);
+      * the remaining 11 floats (xyz 3, opacity 1, scaling 3, rotation 4) go through one flat all-reduce (ncclAvg).
+
+    Per GPU and step at 1 M Gaussians and 8 ranks: 7 x 12 MB received by the all-gather + 2 x 7/8 x 44 MB for the
+    all-reduce = 161 MB, against 413 MB for the dense bucket; both collectives run concurrently on RCCL's stream.
+    Exact: no quantisation, the same float32 terms in a different (fixed) summation order.
+
+        ex = FactoredGradExchange(model, world)
+        ex.begin_view(); loss.backward(); ex.end_view(camera_center); ex.finish()     # then optimizer.step()
+
+    `model` carries the reference's leaf names (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation) and
+    active_sh_degree.  The rasterizer must be called through its raw / chained entry (the reference's getters or
+    render_fused).  `reconstruct` / `set_sinks` are injection points for the CPU (gloo) tests of the exchange logic;
+    the defaults are the HIP implementations and there is no CPU fallback."""
+
+    SMALL = ("_xyz", "_opacity", "_scaling", "_rotation")
+
+    def __init__(self, model, world=None, group=None, reconstruct=None, set_sinks=None):
+        self.model = model
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("MSGS_EXCHANGE_FORCE") == "1")
+        self.world = world if world is not None else (dist.get_world_size(group) if self.active else 1)
+        self.n_rows = dist.get_world_size(group) if self.active else 1          # rows of the gathered buffer
+        self.small = FlatGradBucket([getattr(model, n) for n in self.SMALL])
+        self.small.detach_grads()
+        xyz = model._xyz
+        self.P = int(xyz.shape[0])
+        dev = xyz.device
+        row = 3 * self.P + 4                                                    # {drgb [P,3] | campos [3] | pad}
+        self.send = torch.zeros(row, dtype=torch.float32, device=dev)
+        self.gathered = torch.zeros(self.n_rows, row, dtype=torch.float32, device=dev) if self.active else \
+            self.send.view(1, row)
+        self.g_dc = torch.empty_like(model._features_dc)
+        self.g_rest = torch.empty_like(model._features_rest)
+        self.pending = []
+        self.avg_op = None
+        if self.active and dist.get_backend(group) == "nccl":
+            try:
+                dist.all_reduce(torch.ones(1, device=dev), op=dist.ReduceOp.AVG, group=group)
+                self.avg_op = dist.ReduceOp.AVG
+            except Exception:
+                self.avg_op = None
+        if reconstruct is None or set_sinks is None:
+            import diff_gaussian_rasterization as dgr
+            reconstruct = reconstruct or dgr.sh_grad_from_views
+            set_sinks = set_sinks or dgr.set_grad_sinks
+        self._reconstruct, self._set_sinks = reconstruct, set_sinks
+
+    def begin_view(self):
+        for n in ("_features_dc", "_features_rest"):
+            getattr(self.model, n).grad = None
+        self.small.detach_grads()
+        self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3))
+
+    def end_view(self, camera_center):
+        """after backward(): issue both collectives (asynchronously; they run on the communicator's stream)"""
+        self._set_sinks(None)
+        b = self.small
+        for p, v in zip(b.params, b.views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("FactoredGradExchange: a gradient did not land in the bucket (the rasterizer was "
+                                   "not called through its raw / chained entry)")
+        self.send[3 * self.P:3 * self.P + 3] = camera_center.to(self.send.device, torch.float32).reshape(3)
+        if self.active:
+            op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
+            self.pending = [dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True),
+                            dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)]
+
+    def finish(self):
+        """wait for the exchange (stream-level for NCCL) and rebuild the SH gradient; afterwards every leaf's .grad
+        holds the gradient averaged over the `world` views of this step"""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.world > 1 and (not self.active or self.avg_op is None):
+            self.small.flat.div_(self.world)
+        self._reconstruct(self.model._xyz.detach(), self.gathered, self.n_rows, int(self.model.active_sh_degree),
+                          1.0 / self.world, self.g_dc, self.g_rest)
+        self.model._features_dc.grad = self.g_dc
+        self.model._features_rest.grad = self.g_rest
+
+    def bytes_per_step(self):
+        """bytes a GPU receives per step: all-gather of the factors + ring-equivalent all-reduce of the small bucket"""
+        n = max(self.n_rows, 1)
+        return 4 * ((n - 1) * self.send.numel() + 2 * (n - 1) * self.small.flat.numel() // n)
+
+
+def gather_pixel_size_observations(visibility_filter, pixel_sizes, reso_lvl, group=None):
+    """All-gather of what update_pixel_sizes (scene/gaussian_model.py:663-686) consumes from one view: returns
+    (obs [N,P] float32, levels [N] int64) with obs[v] = pixel_sizes of rank v's view where visible, -1 where not
+    (pixel sizes are >= 0, so the sign carries the mask) — 4 bytes per Gaussian per rank.
+
+    The reference's update is ORDER DEPENDENT (every view that sees a Gaussian first decays max by 0.95 / relaxes min
+    by 1.05, then folds its observation in), so two ways to apply N concurrent views are provided:
+      * sequential (exact): apply the N observations in rank order with the single-view update — bit-identical on every
+        rank and to a single-GPU run that renders the same N views in that order
+        (train_epilogue.update_training_stats per row; see apply_pixel_size_observations_sequential);
+      * batched (documented approximation, batched_pixel_size_update below): ONE decay per iteration, folded with the
+        MAX / MIN over the views — differs from the sequential result by at most the factor 0.95^(k-1) resp. 1.05^(k-1)
+        for a Gaussian seen by k > 1 views of the iteration."""
+    obs = torch.where(visibility_filter, pixel_sizes.to(torch.float32), torch.full_like(pixel_sizes, -1.0, dtype=torch.float32))
+    lvl = torch.tensor([int(reso_lvl)], dtype=torch.int64, device=obs.device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return obs[None], lvl
+    n = dist.get_world_size(group)
+    allobs = torch.empty(n, obs.numel(), dtype=torch.float32, device=obs.device)
+    dist.all_gather_into_tensor(allobs.view(-1), obs.contiguous(), group=group)
+    lvls = torch.empty(n, dtype=torch.int64, device=obs.device)
+    dist.all_gather_into_tensor(lvls, lvl, group=group)
+    return allobs, lvls
+
+
+def batched_pixel_size_update(max_pixel_sizes, min_pixel_sizes, target_reso_lvl, obs, reso_lvl, reso_lvls):
+    """The batched variant of update_pixel_sizes for N views of ONE iteration rendered at the same level (in place):
+        seen   = any_v obs[v] >= 0  and  target_reso_lvl == reso_lvl
+        max    <- max(0.95 max, MAX_v obs[v])                       where seen, reso_lvl > 0
+        grown  = clip(1.05 min, -1)
+        min    <- valid ? (grown < 0 ? MIN_v+ obs : min(grown, MIN_v+ obs)) : grown     where seen, reso_lvl < L - 1
+    with MIN_v+ over the views' valid (> 0) observations.  Equal to the reference's update when one view sees the
+    Gaussian; with k views it applies the decay once instead of k times (see gather_pixel_size_observations)."""
+    vis = obs >= 0
+    seen = vis.any(dim=0) & (target_reso_lvl == reso_lvl)
+    if reso_lvl > 0:
+        ps_max = torch.where(vis, obs, torch.full_like(obs, -1.0)).max(dim=0).values
+        new = torch.maximum(max_pixel_sizes * 0.95, ps_max)
+        max_pixel_sizes.copy_(torch.where(seen, new, max_pixel_sizes))
+    if reso_lvl < reso_lvls - 1:
+        valid = vis & (obs > 0)
+        ps_min = torch.where(valid, obs, torch.full_like(obs, float("inf"))).min(dim=0).values
+        has = valid.any(dim=0)
+        grown = torch.clip(min_pixel_sizes * 1.05, -1)
+        new = torch.where(has, torch.where(grown < 0, ps_min, torch.minimum(grown, ps_min)), grown)
+        min_pixel_sizes.copy_(torch.where(seen, new, min_pixel_sizes))
+
+
+def apply_pixel_size_observations_sequential(model, obs, levels, update_fn=None):
+    """Exact multi-view update: the single-view update of gaussian_model.py:663-686 for each gathered row in rank order.
+    update_fn(model, visibility [P] bool, pixel_sizes [P], reso_lvl) defaults to the HIP statistics kernel
+    (train_epilogue.update_training_stats with only the pixel-size group selected)."""
+    if update_fn is None:
+        from train_epilogue import update_training_stats
+
+        def update_fn(model, vis, ps, lvl):
+            radii = vis.to(torch.int32).contiguous()            # the kernel masks by radii > 0
+            update_training_stats(model, None, radii, ps.contiguous(), lvl, update_pixel_sizes=True, densify=False)
+    for v in range(obs.shape[0]):
+        vis = obs[v] >= 0
+        update_fn(model, vis, torch.where(vis, obs[v], torch.zeros_like(obs[v])), int(levels[v]))
+
+
 def all_reduce_densification_stats(grad_norm_sum, vis_count, max_radii, group=None):
     """Training statistics that must stay equivalent between 1 and N GPUs:
     sum of per-view ||viewspace_points.grad[:, :2]|| and visibility counts (SUM; the norm is taken per

@@ -377,3 +377,94 @@ def forward_backward(scene, cam, settings, bg, dL_dcolor, use_cov_precomp=False,
                 pixel_sizes=psz.detach(), final_T=aux["final_T"], borderline=aux["borderline"],
                 n_blended=aux["n_blended"])
     return outs, grads
+
+
+def forward_backward_tiled(scene, cam, settings, bg, dL_dcolor, progress=None):
+    """The same float64 forward + autograd backward as forward_backward() (scales / rotations / SH inputs), organised so
+    that it scales to the BASELINE configurations (1e5 .. 1e6 Gaussians): the per-Gaussian stage keeps its autograd
+    graph ([P]-sized tensors only), every tile is blended and differentiated on its own (torch.autograd.grad w.r.t. the
+    tile's gathered 2-D quantities, scatter-added into [P]-sized accumulators), and ONE backward through the
+    per-Gaussian stage finishes the chain.  Mathematically identical to forward_backward(); this is the float64
+    "truth" the full-size float32 results (CPU oracle, HIP kernels) are measured against in tools/parity_floor.py.
+    Returns (outputs, grads) like forward_backward()."""
+    dt = torch.float64
+    leaf = lambda t: t.detach().to(dt).clone().requires_grad_(True)
+    means3D, opac = leaf(scene.means3D), leaf(scene.opacities)
+    sc, ro, sh = leaf(scene.scales), leaf(scene.rotations), leaf(scene.shs)
+    view = view_dict(cam, sh_degree=scene.sh_degree, **settings)
+    pre = preprocess(means3D, opac, view, scales=sc, rotations=ro, shs=sh, max_pixel_sizes=scene.max_pixel_sizes,
+                     min_pixel_sizes=scene.min_pixel_sizes, base_mask=scene.base_mask)
+    W, H = int(cam.image_width), int(cam.image_height)
+    P = scene.P
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    bg = bg.to(dt)
+    dL = dL_dcolor.to(dt)
+    d_px, d_py = pre["px"].detach(), pre["py"].detach()
+    d_con, d_op, d_rgb = pre["conic"].detach(), pre["opacity"].detach(), pre["rgb"].detach()
+    g_px, g_py = torch.zeros(P, dtype=dt), torch.zeros(P, dtype=dt)
+    g_con, g_op, g_rgb = torch.zeros(P, 3, dtype=dt), torch.zeros(P, dtype=dt), torch.zeros(P, 3, dtype=dt)
+    color = torch.zeros(3, H, W, dtype=dt)
+    borderline = torch.zeros(H, W, dtype=torch.bool)
+    vis = pre["visible"]
+    rminx, rminy, rmaxx, rmaxy = pre["rect"]
+    order_all = torch.argsort(pre["depth32"], stable=True)           # Q10
+    vis_sorted = order_all[vis[order_all]]
+    rx0, rx1, ry0, ry1 = rminx[vis_sorted], rmaxx[vis_sorted], rminy[vis_sorted], rmaxy[vis_sorted]
+    for ty in range(gy):
+        in_row = (ry0 <= ty) & (ty < ry1)
+        row_ids, row_x0, row_x1 = vis_sorted[in_row], rx0[in_row], rx1[in_row]
+        for tx in range(gx):
+            sel = row_ids[(row_x0 <= tx) & (tx < row_x1)]
+            x0, y0 = tx * TILE, ty * TILE
+            x1, y1 = min(x0 + TILE, W), min(y0 + TILE, H)
+            if sel.numel() == 0:
+                color[:, y0:y1, x0:x1] = bg[:, None, None]
+                continue
+            ys, xs = torch.meshgrid(torch.arange(y0, y1, dtype=dt), torch.arange(x0, x1, dtype=dt), indexing="ij")
+            npix = ys.numel()
+            xs, ys = xs.reshape(-1), ys.reshape(-1)
+            t_px, t_py = d_px[sel].requires_grad_(True), d_py[sel].requires_grad_(True)
+            t_con, t_op, t_rgb = d_con[sel].requires_grad_(True), d_op[sel].requires_grad_(True), d_rgb[sel].requires_grad_(True)
+            dx = t_px[:, None] - xs[None, :]
+            dy = t_py[:, None] - ys[None, :]
+            power = -0.5 * (t_con[:, 0:1] * dx * dx + t_con[:, 2:3] * dy * dy) - t_con[:, 1:2] * dx * dy
+            G = torch.exp(torch.clamp(power, max=0.0))
+            a_raw = t_op[:, None] * G
+            alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()          # Q6
+            valid = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)                   # Q7
+            near = (power.detach() <= 0) & ((alpha.detach() - 1.0 / 255.0).abs() < 2e-6)
+            alpha_v = torch.where(valid, alpha, torch.zeros_like(alpha))
+            one_m = 1.0 - alpha_v
+            T_after = torch.cumprod(one_m, dim=0)
+            T_before = torch.cat([torch.ones(1, npix, dtype=dt), T_after[:-1]], dim=0)
+            fail = valid & (T_after.detach() < 1e-4)
+            near_t = valid & ((T_after.detach() - 1e-4).abs() < 1e-9)
+            any_fail = fail.any(dim=0)
+            first_fail = torch.where(any_fail, fail.to(torch.int64).argmax(dim=0),
+                                     torch.full((npix,), sel.numel(), dtype=torch.int64))
+            idx = torch.arange(sel.numel())[:, None]
+            blended = valid & (idx < first_fail[None, :])
+            bl = ((near | near_t) & (idx <= first_fail[None, :])).any(dim=0)
+            wgt = torch.where(blended, alpha * T_before, torch.zeros_like(alpha))
+            Cc = (wgt[:, None, :] * t_rgb[:, :, None]).sum(dim=0)
+            Tfin = torch.where(blended, one_m, torch.ones_like(one_m)).prod(dim=0)
+            tile_color = Cc + Tfin[None, :] * bg[:, None]
+            loss = (tile_color * dL[:, y0:y1, x0:x1].reshape(3, npix)).sum()
+            gs = torch.autograd.grad(loss, [t_px, t_py, t_con, t_op, t_rgb], allow_unused=True)
+            for acc, g in zip((g_px, g_py, g_con, g_op, g_rgb), gs):
+                if g is not None:
+                    acc.index_add_(0, sel, g)
+            color[:, y0:y1, x0:x1] = tile_color.detach().view(3, y1 - y0, x1 - x0)
+            borderline[y0:y1, x0:x1] = bl.view(y1 - y0, x1 - x0)
+        if progress is not None:
+            progress(ty + 1, gy)
+    torch.autograd.backward([pre["px"], pre["py"], pre["conic"], pre["opacity"], pre["rgb"]],
+                            [g_px, g_py, g_con, g_op, g_rgb])
+    zeros = lambda v: v.grad if v.grad is not None else torch.zeros_like(v)
+    grads = dict(means3D=zeros(means3D), opacities=zeros(opac), scales=zeros(sc), rotations=zeros(ro), shs=zeros(sh))
+    m2 = torch.zeros(P, 3, dtype=dt)
+    m2[:, 0] = g_px * 0.5 * W
+    m2[:, 1] = g_py * 0.5 * H
+    grads["means2D"] = m2
+    outs = dict(color=color, radii=pre["radii"], pixel_sizes=pre["pixel_sizes"].detach(), borderline=borderline)
+    return outs, grads

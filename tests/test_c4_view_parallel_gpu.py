@@ -1,0 +1,194 @@
+"""BASELINE config C4 on one GPU: the 1 M-Gaussian ball rendered from the 8 ring cameras against the
+oracle, and the 1-vs-N gradient equality of the view-parallel exchanges with the real rasterizer:
+8 views accumulated the plain way == the same 8 views pushed through FlatGradBucket / PipelinedGradExchange(direct) /
+FactoredGradExchange, the collectives forced through RCCL on a single rank (MSGS_EXCHANGE_FORCE=1)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import scenes
+from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_err
+
+pytestmark = pytest.mark.gpu
+LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+FULL_RTOL = 1e-3        # tests/test_fullsize_gpu.py: the documented float32 floor at 1e5..1e6 Gaussians
+FULL_Q99 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def c4():
+    return scenes.config_c4()
+
+
+@pytest.fixture(scope="module")
+def rccl_single_rank():
+    """a real RCCL communicator of world size 1 with the collectives forced on"""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    os.environ["MSGS_EXCHANGE_FORCE"] = "1"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    yield dev
+    os.environ.pop("MSGS_EXCHANGE_FORCE", None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("v", [0, 3, 6])
+def test_c4_ring_views_vs_oracle(c4, v):
+    """full size: 1 M Gaussians in the ball of radius 4, camera v of 8 on the ring of radius 8, 1920x1080"""
+    from oracle import oracle_ctypes as oc
+    sc, cams, st = c4
+    cam = cams[v]
+    bg = torch.zeros(3)
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 40 + v)
+    out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+    orc = oc.rasterize(pc.seen, cam, st, bg)
+    og = oc.backward(orc, dL)
+    check_forward(out, orc, f"C4 view {v}")
+    worst = check_backward(pc, m2, og, f"C4 view {v}", flagged=orc.borderline_gaussians, rtol=FULL_RTOL, q99_tol=FULL_Q99)
+    V = int((orc.radii > 0).sum())
+    print(f"C4 view {v}: V={V} D_ref={orc.num_instances} borderline px {orc.borderline.float().mean().item():.5%} "
+          f"borderline Gaussians {orc.borderline_gaussians.float().mean().item():.4%} worst {max(worst.values()):.2e}")
+    assert V > 300_000
+
+
+def _plain_sum(sc, cams, st, dL, dev):
+    """reference: 8 backward passes accumulated by autograd, divided by 8"""
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    pc = SyntheticGaussians(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    for cam in cams:
+        render(cam.to(dev), pc, PIPE, bg, **st)["render"].backward(dL)
+    return {n: getattr(pc, n).grad / len(cams) for n in LEAVES}
+
+
+def test_c4_one_vs_n_gradient_equality(c4, rccl_single_rank):
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    from view_parallel import FactoredGradExchange, FlatGradBucket, PipelinedGradExchange
+    dev = rccl_single_rank
+    sc, cams, st = c4
+    W, H = cams[0].image_width, cams[0].image_height
+    dL = scenes.grad_seed(W, H, 4).to(dev)
+    bg = torch.zeros(3, device=dev)
+    want = _plain_sum(sc, cams, st, dL, dev)
+    tol = {n: (1e-3 if n in ("_scaling", "_rotation") else 3e-4) for n in LEAVES}      # independent float-atomic runs
+
+    # (a) accumulate into one flat bucket, ONE all-reduce for the 8 views (world = 1 rank holding all views)
+    pc = SyntheticGaussians(sc, dev)
+    b = FlatGradBucket(pc.parameters())
+    b.zero()
+    for cam in cams:
+        render(cam.to(dev), pc, PIPE, bg, **st)["render"].backward(dL)
+    b.all_reduce(average_over=len(cams))
+    for n in LEAVES:
+        assert rel_err(getattr(pc, n).grad, want[n]) <= tol[n], ("bucket", n)
+
+    # (b) the pipelined exchange, gradients written straight into the alternating buckets, async RCCL all-reduce
+    pc = SyntheticGaussians(sc, dev)
+    ex = PipelinedGradExchange(pc.parameters(), world=1, direct=True)
+    assert ex.active
+    acc = {n: torch.zeros_like(getattr(pc, n)) for n in LEAVES}
+    for k, cam in enumerate(cams):
+        ex.begin_view()
+        render(cam.to(dev), pc, PIPE, bg, **st)["render"].backward(dL)
+        bk = ex.end_view()
+        ex.drain()
+        for n, v in zip(LEAVES, bk.views):
+            acc[n] += v / len(cams)
+    for n in LEAVES:
+        assert rel_err(acc[n], want[n]) <= tol[n], ("pipelined", n)
+
+    # (c) the factored exchange: every view is a "rank"; rows gathered by hand, the small bucket summed by hand
+    pc = SyntheticGaussians(sc, dev)
+    ex = FactoredGradExchange(pc, world=len(cams))
+    assert ex.active and ex.n_rows == 1
+    P = sc.P
+    rows = torch.zeros(len(cams), 3 * P + 4, device=dev)
+    small = torch.zeros_like(ex.small.flat)
+    for k, cam in enumerate(cams):
+        ex.begin_view()
+        render(cam.to(dev), pc, PIPE, bg, **st)["render"].backward(dL)
+        assert pc._features_dc.grad is None and pc._features_rest.grad is None     # no SH rows were formed
+        ex.end_view(cam.camera_center)
+        for w in ex.pending:                                  # the single-rank RCCL all-gather / all-reduce
+            w.wait()
+        ex.pending = []
+        rows[k] = ex.gathered[0]
+        small += ex.small.flat
+    import diff_gaussian_rasterization as dgr
+    dgr.sh_grad_from_views(pc._xyz.detach(), rows, len(cams), pc.active_sh_degree, 1.0 / len(cams), ex.g_dc, ex.g_rest)
+    got = {"_features_dc": ex.g_dc, "_features_rest": ex.g_rest}
+    for n, v in zip(FactoredGradExchange.SMALL, ex.small.views):
+        got[n] = (small / len(cams))[(v.data_ptr() - ex.small.flat.data_ptr()) // 4:][:v.numel()].view_as(v)
+    for n in LEAVES:
+        assert rel_err(got[n], want[n]) <= tol[n], ("factored", n)
+
+
+def test_factored_sh_gradient_is_the_dense_one_bit_for_bit():
+    """one view: K9 with the factored SH path + msgs_sh_grad_from_views == K9 writing the 48-float rows itself"""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render
+    from parity_utils import small_scene
+    from synthetic_model import SyntheticGaussians
+    for deg, P, seed in ((3, 4001, 5), (1, 1000, 6), (0, 777, 7)):
+        W, H = 128, 96
+        sc, cam = small_scene(P, W, H, seed, sh_degree=deg)
+        st = dict(filter_small=False, filter_large=False, fade_size=1.0)
+        dL = scenes.grad_seed(W, H, seed).cuda()
+        bg = torch.zeros(3, device="cuda")
+        prev = dgr.set_deterministic(True)                  # identical dL/drgb in both runs
+        try:
+            ref = SyntheticGaussians(sc, "cuda")
+            render(cam.to("cuda"), ref, PIPE, bg, **st)["render"].backward(dL)
+            pc = SyntheticGaussians(sc, "cuda")
+            factor = torch.empty(P, 3, device="cuda")
+            dgr.set_grad_sinks({}, sh_factor=factor)
+            render(cam.to("cuda"), pc, PIPE, bg, **st)["render"].backward(dL)
+            dgr.set_grad_sinks(None)
+        finally:
+            dgr.set_deterministic(prev)
+        assert pc._features_dc.grad is None and pc._features_rest.grad is None
+        for n in ("_xyz", "_opacity", "_scaling", "_rotation"):
+            assert torch.equal(getattr(pc, n).grad, getattr(ref, n).grad), n
+        row = torch.zeros(1, 3 * P + 4, device="cuda")
+        row[0, :3 * P] = factor.reshape(-1)
+        row[0, 3 * P:3 * P + 3] = cam.camera_center.cuda()
+        g_dc, g_rest = torch.empty(P, 1, 3, device="cuda"), torch.empty(P, 15, 3, device="cuda")
+        dgr.sh_grad_from_views(pc._xyz.detach(), row, 1, deg, 1.0, g_dc, g_rest)
+        assert torch.equal(g_dc, ref._features_dc.grad), deg
+        assert torch.equal(g_rest, ref._features_rest.grad), deg
+
+
+def test_sequential_pixel_size_update_matches_single_gpu_order():
+    """N gathered observations applied in rank order == the reference's update run view after view"""
+    import types
+    from train_epilogue import update_training_stats
+    from view_parallel import apply_pixel_size_observations_sequential
+    P, L = 5000, 4
+    g = torch.Generator().manual_seed(3)
+    lvl = torch.randint(0, L, (P,), generator=g)
+
+    def fresh():
+        m = types.SimpleNamespace(reso_lvls=L, target_reso_lvl=lvl.cuda(),
+                                  max_pixel_sizes=(3.0 * torch.rand(P, generator=torch.Generator().manual_seed(1))).cuda(),
+                                  min_pixel_sizes=torch.where(torch.arange(P) % 3 == 0, torch.tensor(-1.0), torch.tensor(0.8)).cuda())
+        return m
+    views = []
+    for v in range(3):
+        vis = torch.rand(P, generator=g) < 0.6
+        ps = 4.0 * torch.rand(P, generator=g)
+        ps[torch.rand(P, generator=g) < 0.1] = 0.0
+        views.append((vis.cuda(), ps.cuda(), v % 3))
+    a = fresh()
+    for vis, ps, rl in views:                                # the single-GPU order
+        update_training_stats(a, None, vis.to(torch.int32), ps, rl, update_pixel_sizes=True, densify=False)
+    b = fresh()
+    obs = torch.stack([torch.where(vis, ps, torch.full_like(ps, -1.0)) for vis, ps, _ in views])
+    apply_pixel_size_observations_sequential(b, obs, torch.tensor([rl for _, _, rl in views]))
+    assert torch.equal(a.max_pixel_sizes, b.max_pixel_sizes) and torch.equal(a.min_pixel_sizes, b.min_pixel_sizes)

@@ -101,3 +101,127 @@ def test_single_process_paths():
         b = ex.end_view()
         assert torch.allclose(b.views[0], torch.full((5, 3), (k + 1) / 2.0))
     ex.drain()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FactoredGradExchange (one view per GPU per optimizer step, BASELINE config C4) and the pixel-size statistics
+# ---------------------------------------------------------------------------------------------------------------------
+def _torch_sh_reconstruct(means3D, gathered, n_views, deg, scale, out_dc, out_rest):
+    """host restatement of msgs_sh_grad_from_views (tests only): scale * sum_v basis(dir_v) x drgb_v"""
+    from gaussian_renderer.sh import sh_basis
+    P = means3D.shape[0]
+    acc = torch.zeros(P, 16, 3, dtype=torch.float64)
+    for v in range(n_views):
+        drgb = gathered[v, :3 * P].view(P, 3).double()
+        cam = gathered[v, 3 * P:3 * P + 3].double()
+        d = means3D.double() - cam[None]
+        b = torch.zeros(P, 16, dtype=torch.float64)
+        b[:, :(deg + 1) ** 2] = sh_basis(deg, d / d.norm(dim=1, keepdim=True))
+        acc += b[:, :, None] * drgb[:, None, :]
+    acc *= scale
+    out_dc.copy_(acc[:, :1].float())
+    out_rest.copy_(acc[:, 1:].float())
+
+
+def _factored_worker(rank, world, port, ret):
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ms-gs_amd", "host")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussian_renderer.sh import sh_basis
+    from view_parallel import (FactoredGradExchange, batched_pixel_size_update, gather_pixel_size_observations)
+    torch.manual_seed(0)                                    # identical replicas
+    P, deg = 203, 2                                         # P % 4 != 0
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    shapes = ((P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4))
+    model = types.SimpleNamespace(active_sh_degree=deg)
+    for n, s in zip(names, shapes):
+        setattr(model, n, torch.nn.Parameter(torch.randn(*s)))
+    sinks = {}
+
+    def set_sinks(mapping, sh_factor=None):                 # stands in for diff_gaussian_rasterization.set_grad_sinks
+        sinks.clear()
+        if mapping:
+            sinks.update(mapping=mapping, sh_factor=sh_factor)
+
+    ex = FactoredGradExchange(model, world, reconstruct=_torch_sh_reconstruct, set_sinks=set_sinks)
+    ok = ex.active and all(v.data_ptr() % 16 == 0 for v in ex.small.views)
+
+    def view_grads(v):                                      # the per-view gradients a rasterizer backward would deliver
+        g = torch.Generator().manual_seed(100 + v)
+        small = {n: torch.randn(*s, generator=g) for n, s in zip(names, shapes) if n in FactoredGradExchange.SMALL}
+        drgb = torch.randn(P, 3, generator=g)
+        drgb[torch.rand(P, generator=g) < 0.4] = 0.0        # not rendered in this view
+        cam = torch.randn(3, generator=g) * 5.0
+        return small, drgb, cam
+
+    for it in range(2):                                     # two optimizer steps reuse the same buffers
+        ex.begin_view()
+        small, drgb, cam = view_grads(10 * it + rank)
+        for p, dest in sinks["mapping"].items():            # "backward": write into the sinks, hand aliases to autograd
+            name = next(n for n in names if getattr(model, n) is p)
+            dest.copy_(small[name])
+            p.grad = dest.view(p.shape)
+        sinks["sh_factor"].copy_(drgb)
+        ex.end_view(cam)
+        ex.finish()
+        # expectation: plain average over the ranks' dense per-view gradients
+        want = {n: torch.zeros(*s, dtype=torch.float64) for n, s in zip(names, shapes)}
+        for r in range(world):
+            sm, dr, cm = view_grads(10 * it + r)
+            for n in sm:
+                want[n] += sm[n].double() / world
+            d = model._xyz.detach().double() - cm.double()[None]
+            b = torch.zeros(P, 16, dtype=torch.float64)
+            b[:, :(deg + 1) ** 2] = sh_basis(deg, d / d.norm(dim=1, keepdim=True))
+            dsh = b[:, :, None] * dr.double()[:, None, :] / world
+            want["_features_dc"] += dsh[:, :1]
+            want["_features_rest"] += dsh[:, 1:]
+        for n in names:
+            g = getattr(model, n).grad
+            ok = ok and g is not None and bool(torch.allclose(g.double(), want[n], rtol=1e-5, atol=1e-6))
+        ok = ok and bool((model._features_rest.grad[:, (deg + 1) ** 2 - 1:] == 0).all())    # inactive bands stay zero
+    ok = ok and ex.bytes_per_step() == 4 * ((world - 1) * (3 * P + 4) + 2 * (world - 1) * ex.small.flat.numel() // world)
+
+    # pixel-size observations: gathered rows in rank order, -1 where not visible
+    vis = torch.arange(P) % (rank + 2) == 0
+    ps = torch.full((P,), float(rank + 1)) + torch.arange(P) * 1e-3
+    obs, lvls = gather_pixel_size_observations(vis, ps, reso_lvl=1)
+    ok = ok and tuple(obs.shape) == (world, P) and lvls.tolist() == [1] * world
+    for r in range(world):
+        vr = torch.arange(P) % (r + 2) == 0
+        pr = torch.full((P,), float(r + 1)) + torch.arange(P) * 1e-3
+        ok = ok and bool(torch.equal(obs[r], torch.where(vr, pr, torch.full((P,), -1.0))))
+    # batched update == the documented formula == the sequential single-view update wherever ONE view saw the Gaussian
+    lvl = torch.ones(P, dtype=torch.long)
+    lvl[::7] = 0
+    mx, mn = torch.full((P,), 3.0), torch.full((P,), 1.2)
+    mn[::5] = -1.0
+    mx_b, mn_b = mx.clone(), mn.clone()
+    batched_pixel_size_update(mx_b, mn_b, lvl, obs, reso_lvl=1, reso_lvls=4)
+    nseen = (obs >= 0).sum(0)
+    one = (nseen == 1) & (lvl == 1)
+    o1 = obs.max(dim=0).values                              # the single observation where nseen == 1
+    seq_max = torch.maximum(mx * 0.95, o1)
+    grown = torch.clip(mn * 1.05, -1)
+    seq_min = torch.where(grown < 0, o1, torch.minimum(grown, o1))
+    ok = ok and bool(torch.equal(mx_b[one], seq_max[one])) and bool(torch.equal(mn_b[one], seq_min[one]))
+    untouched = (nseen == 0) | (lvl != 1)
+    ok = ok and bool(torch.equal(mx_b[untouched], mx[untouched])) and bool(torch.equal(mn_b[untouched], mn[untouched]))
+    two = (nseen == 2) & (lvl == 1)
+    ok = ok and bool(two.any()) and bool(torch.equal(mx_b[two], torch.maximum(mx * 0.95, obs.max(0).values)[two]))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factored_exchange_and_pixel_size_stats_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_factored_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)

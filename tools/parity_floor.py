@@ -9,8 +9,8 @@ For a BASELINE config (C2 / C3 / C5) this prints, per gradient tensor, the max-n
   * [CPU only, --floor] the float32 oracle and the SAME oracle source compiled with FMA contraction
     (g++ -ffp-contract=fast -mfma): the reference algorithm's own sensitivity to float32 rounding — nvcc
     contracts to FMA by default, so the real CUDA reference is the contracted flavour
-  * [--truth] each of them and the float64 evaluation of the same gradient formulas (oracle/msgs_oracle.cpp
-    msgs_oracle_backward_f64)
+  * [--truth] each of them and the float64 autograd evaluation of the same pipeline
+    (oracle/torch_oracle.py forward_backward_tiled)
 and the borderline-pixel / borderline-Gaussian fractions.
 
 usage: python tools/parity_floor.py C2 [--floor] [--truth] [--no-gpu] [--out file.md]
@@ -121,9 +121,12 @@ def main():
     grads["oracle_f32"] = leaf_grads_from_oracle(pc_raw, og)
     flagged = orc.borderline_gaussians.clone()
     bl_px = orc.borderline.float().mean().item()
+    truth_out = None
     if a.truth:
-        og64 = oc.backward_f64(orc, dL)
+        from oracle import torch_oracle as to
+        truth_out, og64 = to.forward_backward_tiled(seen, cam, st, bg, dL)
         grads["truth_f64"] = leaf_grads_from_oracle(pc_raw, og64)
+        flagged |= truth_out["radii"] != orc.radii
     if a.floor:
         so = build_fma_oracle()
 
@@ -145,6 +148,11 @@ def main():
         okpx = ~orc.borderline.bool()
         say(f"forward: HIP vs oracle max abs diff {d[:, okpx].max().item():.3e} on non-borderline pixels ({d.max().item():.3e} on all); "
             f"radii equal: {torch.equal(hip_out['radii'], orc.radii)}")
+    if truth_out is not None:
+        okpx = ~(orc.borderline.bool() | truth_out["borderline"])
+        say(f"forward vs float64 truth on non-borderline pixels: oracle_f32 {(orc.color.double() - truth_out['color']).abs()[:, okpx].max().item():.3e}"
+            + ("" if a.no_gpu else f", HIP {(hip_out['render'].double() - truth_out['color']).abs()[:, okpx].max().item():.3e}")
+            + f"; radii differ on {(truth_out['radii'] != orc.radii).sum().item()} Gaussians")
     ref = grads["truth_f64"] if a.truth else grads["oracle_f32"]
     pairs = []
     if not a.no_gpu:

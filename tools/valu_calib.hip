@@ -36,14 +36,16 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         lds[threadIdx.x] = v0; lds[threadIdx.x + 256] = v1; lds[threadIdx.x + 512] = v2; lds[threadIdx.x + 768] = v3; \
         __syncthreads();                                                                                            \
         const unsigned ldsaddr = ((threadIdx.x & 63) ^ 16) * 4u;                                                    \
+        const unsigned ldsuni = (threadIdx.x >> 6) * 256u;           /* wave-uniform LDS byte address */             \
         const unsigned long long mask = 0xAAAAAAAAAAAAAAAAull;                                                      \
         const unsigned long long t0 = __builtin_readcyclecounter();                                                 \
         for (int it = 0; it < ITER; ++it) {                                                                         \
             asm volatile(BODY BODY BODY BODY                                                                        \
                          : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7),          \
                            "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)                                                   \
-                         : "v"(a), "v"(b), "v"(pa), "v"(ldsaddr), "s"(mask)                                         \
-                         : "vcc", "s20", "s21", "s22", "s23", "memory");                                            \
+                         : "v"(a), "v"(b), "v"(pa), "v"(ldsaddr), "s"(mask), "v"(ldsuni)                            \
+                         : "vcc", "scc", "s20", "s21", "s22", "s23", "memory", "v40", "v41", "v42", "v43", "v44",   \
+                           "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");                                            \
         }                                                                                                           \
         const unsigned long long t1 = __builtin_readcyclecounter();                                                 \
         out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + d0.x + d0.y + d1.x +   \
@@ -107,6 +109,39 @@ STREAM_KERNEL(k_cmp_to_sgpr,
 STREAM_KERNEL(k_cmp_sand_cndmask,
     "v_cmp_lt_f32_e64 s[20:21], %0, %12\n s_and_b64 s[22:23], s[20:21], %16\n v_cndmask_b32_e64 %1, %1, %12, s[22:23]\n v_fma_f32 %2, %2, %12, %13\n"
     "v_cmp_lt_f32_e64 s[20:21], %3, %12\n s_and_b64 s[22:23], s[20:21], %16\n v_cndmask_b32_e64 %4, %4, %12, s[22:23]\n v_fma_f32 %5, %5, %12, %13\n")
+// LDS broadcast reads (every lane the same address), as the blend loops fetch one 48-byte record per entry
+STREAM_KERNEL(k_ds_read_b128_bcast,
+    "ds_read_b128 v[40:43], %17\n ds_read_b128 v[44:47], %17 offset:16\n ds_read_b128 v[48:51], %17 offset:32\n ds_read_b128 v[52:55], %17 offset:48\n"
+    "ds_read_b128 v[40:43], %17 offset:64\n ds_read_b128 v[44:47], %17 offset:80\n ds_read_b128 v[48:51], %17 offset:96\n ds_read_b128 v[52:55], %17 offset:112\n s_waitcnt lgkmcnt(0)\n")
+// the forward blend's per-entry shape: 3 broadcast record reads + 24 plain VALU + 1 exp  (28 instructions)
+STREAM_KERNEL(k_fwd_like,
+    "ds_read_b128 v[40:43], %17\n ds_read_b128 v[44:47], %17 offset:16\n ds_read_b128 v[48:51], %17 offset:32\n"
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_fma_f32 %0, %0, v40, v44\n v_fma_f32 %1, %1, v41, v45\n v_fma_f32 %2, %2, v42, v46\n v_fma_f32 %3, %3, v43, v47\n"
+    "v_fma_f32 %4, %4, v48, %13\n v_fma_f32 %5, %5, v49, %13\n v_fma_f32 %6, %6, v50, %13\n v_exp_f32 %7, %7\n"
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n")
+// the same VALU without the LDS reads
+STREAM_KERNEL(k_fwd_like_nolds,
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n"
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_exp_f32 %7, %7\n"
+    "v_fma_f32 %0, %0, %12, %13\n v_fma_f32 %1, %1, %12, %13\n v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n"
+    "v_fma_f32 %4, %4, %12, %13\n v_fma_f32 %5, %5, %12, %13\n v_fma_f32 %6, %6, %12, %13\n v_fma_f32 %7, %7, %12, %13\n")
+STREAM_KERNEL(k_cmp_vcc,
+    "v_cmp_lt_f32 vcc, %0, %12\n v_cmp_lt_f32 vcc, %1, %12\n v_cmp_lt_f32 vcc, %2, %12\n v_cmp_lt_f32 vcc, %3, %12\n"
+    "v_cmp_lt_f32 vcc, %4, %12\n v_cmp_lt_f32 vcc, %5, %12\n v_cmp_lt_f32 vcc, %6, %12\n v_cmp_lt_f32 vcc, %7, %12\n")
+STREAM_KERNEL(k_min_sub,
+    "v_min_f32 %0, %0, %12\n v_sub_f32 %1, %1, %12\n v_min_f32 %2, %2, %12\n v_sub_f32 %3, %3, %12\n"
+    "v_min_f32 %4, %4, %12\n v_sub_f32 %5, %5, %12\n v_min_f32 %6, %6, %12\n v_sub_f32 %7, %7, %12\n")
+STREAM_KERNEL(k_mov_dpp,
+    "v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %4, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    "v_mov_b32_dpp %6, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n")
 STREAM_KERNEL(k_ds_bpermute,
     "ds_bpermute_b32 %0, %15, %0\n ds_bpermute_b32 %1, %15, %1\n ds_bpermute_b32 %2, %15, %2\n ds_bpermute_b32 %3, %15, %3\n"
     "ds_bpermute_b32 %4, %15, %4\n ds_bpermute_b32 %5, %15, %5\n ds_bpermute_b32 %6, %15, %6\n ds_bpermute_b32 %7, %15, %7\n s_waitcnt lgkmcnt(0)\n")
@@ -137,6 +172,12 @@ int main(int argc, char** argv) {
         {"v_cmp_lt_f32 -> SGPR pair x8", k_cmp_to_sgpr, 8, ""},
         {"v_cmp -> s_and -> v_cndmask, + v_fma (x2)", k_cmp_sand_cndmask, 8, "6 VALU + 2 SALU per body"},
         {"ds_bpermute_b32 x8 + wait", k_ds_bpermute, 8, "LDS crossbar"},
+        {"v_cmp_lt_f32 -> vcc x8", k_cmp_vcc, 8, ""},
+        {"v_min_f32 / v_sub_f32 x8", k_min_sub, 8, ""},
+        {"v_mov_b32_dpp row_ror:8 x8", k_mov_dpp, 8, ""},
+        {"ds_read_b128 broadcast x8 + wait", k_ds_read_b128_bcast, 8, "16 B to all 64 lanes per instruction"},
+        {"fwd-like: 3 ds_read_b128 bcast + 24 fma + 1 exp", k_fwd_like, 28, "cycles per instruction of the 28 (25 VALU)"},
+        {"fwd-like without the LDS reads: 23 fma + 1 exp", k_fwd_like_nolds, 24, ""},
     };
     const int max_waves = cus * 4 * 8;
     float* out; unsigned long long* ticks;
@@ -145,6 +186,7 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> h(max_waves);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     printf("%-44s %5s %9s %9s %10s  %s\n", "stream", "w/SIMD", "cyc_tick", "cyc_wall", "Ginstr/s", "note");
     for (const Stream& st : streams) {
         for (int w : {1, 2, 4, 8}) {
@@ -170,6 +212,7 @@ int main(int argc, char** argv) {
             const double cyc_wall = best_ms * 1e-3 * clock_ghz * 1e9 / (w * instr_per_wave);
             const double ginstr = (double)blocks * 4 * instr_per_wave / (best_ms * 1e-3) * 1e-9;
             printf("%-44s %5d %9.2f %9.2f %10.1f  %s\n", st.name, w, cyc_tick, cyc_wall, ginstr, st.note);
+            fflush(stdout);
         }
     }
     // s_memtime tick vs wall: one long kernel, ticks / wall seconds
