@@ -44,6 +44,19 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def csrc_sha256():
+    """hash of the kernel sources this tree builds (same function in tools/summarize_rocprof.py, which stamps the
+    committed counter summaries with it)"""
+    import hashlib
+    root = os.path.join(ROOT, "ms-gs_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()
+
+
 def cpu_baseline(scenes, scene, settings, W, H, runs=2):
     """The CPU oracle (kind "port": there is no reference CPU path) on the SAME workload: the full scene
     rendered forward+backward at full resolution (i) on all host cores, best of `runs` (about 1-6 s per run), and
@@ -248,6 +261,23 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * (W * H / 1e6) / (elapsed / args.steps)
 
+    # SURVEY 8(d) form of the same measurement (N = 1): median of >= 50 steps, each bracketed by HIP events on the compute
+    # stream (the library launches on torch's current stream, so torch.cuda.Event sees its kernels)
+    median50 = None
+    if world == 1:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        dgr._C.set_timer(None)
+        for a_, b_ in evs:
+            a_.record()
+            step()
+            b_.record()
+        torch.cuda.synchronize()
+        ts_ = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        med = 0.5 * (ts_[24] + ts_[25])
+        median50 = {"ms_per_step": round(med, 4), "value": round(W * H / 1e6 / (med * 1e-3), 3), "unit": "Mpixels/s",
+                    "min_ms": round(ts_[0], 4), "p90_ms": round(ts_[44], 4),
+                    "how": "median of 50 steps, HIP events on the compute stream around each step"}
+
     # N > 1, informational ("with and without the all-reduce"), the same K steps with
     #   (a) the dense exchange serialised after each view: ONE flat all-reduce of the 59 floats / Gaussian
     #   (b) that dense all-reduce overlapped with the rendering of the NEXT view (two buckets; an optimizer step then
@@ -364,35 +394,39 @@ def main():
             dom = max(alg, key=lambda k: kernels.get(k, 0.0))
             achieved = alg[dom] / (kernels[dom] * 1e-3) / 1e9
             both = (alg["blend_fwd"] + alg["blend_bwd"]) / ((kernels["blend_fwd"] + kernels["blend_bwd"]) * 1e-3) / 1e9
-            # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
-            # separate passes, corrected per MI355X_MICROARCH.md §HBM); measured offline and committed under
-            # profiles/ because counters cannot be collected from inside the timed process
-            traffic = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r1.json")))["kernels"]
-                key = {"blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_tile_kernel"}[dom]
-                if (P, W, H) == (1_000_000, 1920, 1080) and key in tj:
-                    traffic = int(tj[key]["hbm_bytes"])
-            except Exception:
-                traffic = None
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in separate
+            # passes, corrected per MI355X_MICROARCH.md §HBM), collected offline by tools/profile_round.sh (counters cannot
+            # be read from inside the timed process) and committed under profiles/ together with the sha256 of the kernel
+            # sources they were measured on: reported only while that hash still matches this tree, null otherwise.
+            name_of = {"blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_tile"}[dom]
+            here = csrc_sha256()
+
+            def committed(fname):
+                try:
+                    j_ = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                    if j_.get("csrc_sha256") != here or (P, W, H) != (1_000_000, 1920, 1080) or world != 1:
+                        return None
+                    hits = [v for k, v in j_["kernels"].items() if k.startswith(name_of)]
+                    return max(hits, key=lambda v: v.get("launches", 1)) if hits else None
+                except Exception:
+                    return None
+            tr = committed("traffic_r2.json")
+            traffic = int(tr["hbm_bytes"]) if tr else None
             # what actually bounds the kernel: VALU issue.  Wave-instructions per launch from the committed
-            # PMC summary of this same command; issue model = instructions x 4.2 cycles / (1024 SIMDs x 2.4 GHz)
+            # PMC summary (same hash rule); cycles per wave64 instruction from the calibration of tools/valu_calib.hip
+            # (profiles/r2_valu_calibration.txt: plain fp32 2.2, v_cmp / v_cndmask / DPP 4.25, v_exp / v_rcp 8.1) weighted
+            # with the instruction mix of the kernel's inner loops (counted in the ISA: forward 18 plain + 3 compares +
+            # 1 exp per pair; backward 24 + 4 + 2 per quadrant step and 8 + 21 per reduction)
             valu = None
-            try:
-                import csv as _csv
-                rows = [r for r in _csv.reader(l for l in open(os.path.join(ROOT, "profiles", "r1j_pmc_sq_final.csv"))
-                                               if not l.startswith("#"))]
-                col = rows[0].index("SQ_INSTS_VALU")
-                key = {"blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_tile_kernel"}[dom]
-                for r in rows[1:]:
-                    if r[0].startswith(key) and (P, W, H) == (1_000_000, 1920, 1080):
-                        insts = float(r[col])
-                        model_ms = insts * 4.2 / (1024 * 2.4e9) * 1e3
-                        valu = {"wave_instructions": insts, "issue_model_ms": round(model_ms, 4),
-                                "frac_of_issue_rate": round(model_ms / kernels[dom], 4),
-                                "source": "profiles/r1j_pmc_sq_final.csv"}
-            except Exception:
-                valu = None
+            sq = committed("sq_r2.json")
+            if sq and "SQ_INSTS_VALU" in sq:
+                cyc = {"blend_fwd": (18 * 2.2 + 3 * 4.25 + 8.1) / 22.0,
+                       "blend_bwd": (63 * 2.2 + 30 * 4.25 + 4.6 * 8.1) / 97.6}[dom]
+                insts = float(sq["SQ_INSTS_VALU"])
+                floor_ms = insts * cyc / (1024 * 2.4e9) * 1e3
+                valu = {"wave_instructions": insts, "cycles_per_instruction_of_this_mix": round(cyc, 3),
+                        "issue_floor_ms": round(floor_ms, 4), "frac_of_issue_floor": round(floor_ms / kernels[dom], 4),
+                        "source": "profiles/sq_r2.json + profiles/r2_valu_calibration.txt"}
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom], "valu_issue": valu,
@@ -400,6 +434,7 @@ def main():
                                            "algorithmic_bytes": alg["blend_fwd"] + alg["blend_bwd"],
                                            "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
         result["roofline"] = roof
+        result["median_of_50"] = median50
         result["kernel_ms"] = kernels
         result["kernel_timing"] = (None if not timers else
                                    f"HIP events recorded by the library on {len(timers)} of the {args.steps} timed steps")

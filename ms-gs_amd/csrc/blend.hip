@@ -85,7 +85,7 @@ __device__ __forceinline__ int swizzled_tile(int bid, int num_tiles) {
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
-template <bool PREFETCH>
+template <bool PREFETCH, bool EXEC_BLEND>
 __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
@@ -159,11 +159,26 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             const uint64_t stopm = validm & m_stop;
             alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
             const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
-            const float wgt = blend ? alpha * T : 0.0f;
-            C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
-            adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
-            T = blend ? test_T : T;
-            last_off = blend ? off : last_off;
+            if (EXEC_BLEND) {
+                // the accumulation runs under the EXEC mask of the blending lanes instead of through selects:
+                // v_cndmask (like v_cmp and every DPP instruction) issues at HALF the rate of a plain fp32 VALU
+                // instruction on gfx950 (profiles/r2_valu_calibration.txt: 4.2 vs 2.2 cycles per wave64 instruction),
+                // so three selects cost more than the two moves + the scalar exec bookkeeping, and a record that no
+                // lane of the wave blends skips the block altogether.  Same values in the same order.
+                if (blend) {
+                    const float wgt = alpha * T;
+                    C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
+                    adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
+                    T = test_T;
+                    last_off = off;
+                }
+            } else {
+                const float wgt = blend ? alpha * T : 0.0f;
+                C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
+                adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
+                T = blend ? test_T : T;
+                last_off = blend ? off : last_off;
+            }
         };
         auto blend_entry = [&](uint32_t off) {
             float4 r0, r1, r2;
@@ -172,23 +187,31 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
         };
         const uint16_t* lp = s_list[w];
         if (PREFETCH) {
-            // software pipeline: the record of entry j+1 is fetched from LDS (list offset, then three 16-byte reads: two
-            // dependent LDS round trips) while entry j is evaluated — PMC showed the waves parked on s_waitcnt half of
-            // their time with the fetch in front of every evaluation (two register sets, ping-pong: no moves)
+            // software pipeline: while entry j is evaluated, the record of entry j+1 (three 16-byte LDS reads) AND the
+            // list offset of entry j+2 are in flight — PMC showed the waves parked on s_waitcnt half of their time with the
+            // dependent offset -> record fetch in front of every evaluation.  Two register sets, ping-pong (no moves).
+            // The explicit lgkmcnt(0) at the top of each half makes the hand-over point the same on every path, so the
+            // compiler's own waitcnt insertion does not make the evaluation wait for the loads just issued.
             if (cnt > 0) {
-                uint32_t offA = lp[0], offB = 0;
+                uint32_t offA = lp[0], offB = cnt > 1 ? lp[1] : 0u, offN = 0;
                 float4 a0, a1, a2, b0, b1, b2;
                 fetch(offA, a0, a1, a2);
                 for (int j = 0;; j += 2) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): set A and offB have landed
                     const bool hasB = j + 1 < cnt;
-                    if (hasB) { offB = lp[j + 1]; fetch(offB, b0, b1, b2); }
+                    if (hasB) fetch(offB, b0, b1, b2);
+                    if (j + 2 < cnt) offN = lp[j + 2];
                     if (alive == 0) break;
                     blend_rec(offA, a0, a1, a2);
                     if (!hasB) break;
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                  // set B and offN have landed
                     const bool hasA = j + 2 < cnt;
-                    if (hasA) { offA = lp[j + 2]; fetch(offA, a0, a1, a2); }
+                    offA = offN;
+                    if (hasA) fetch(offA, a0, a1, a2);
+                    const uint32_t offBcur = offB;
+                    if (j + 3 < cnt) offB = lp[j + 3];
                     if (alive == 0) break;
-                    blend_rec(offB, b0, b1, b2);
+                    blend_rec(offBcur, b0, b1, b2);
                     if (!hasA) break;
                 }
             }
@@ -897,6 +920,105 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     }
 }
 
+// Eight-waves-per-SIMD variant of blend_backward_tile_kernel: identical arithmetic; the next batch is NOT prefetched into
+// registers (13 VGPRs) and the register budget is capped at 64, so that 8 waves fit a SIMD: 1024 SIMDs x 8 = 8192 slots
+// hold all 8160 tiles of a 1080p frame at once.  With 80 registers (6 waves) the 8160 one-wave tiles run in two rounds of
+// latency-bound waves: PMC showed 3.5 waves resident per SIMD on average, each issuing one VALU instruction per 16 cycles.
+template <bool DET>
+__global__ __launch_bounds__(64, 8) void blend_backward_tile8_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                                 const uint32_t* __restrict__ ids,
+                                                                 const uint2* __restrict__ ranges,
+                                                                 const float* __restrict__ final_T,
+                                                                 const uint32_t* __restrict__ n_contrib,
+                                                                 const float* __restrict__ dL_dcolor,
+                                                                 float* __restrict__ grad_rec) {
+    __shared__ float4 s_r0[WB], s_r1[WB];
+    __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
+                                                           // address register serves every LDS read of an entry
+    const int num_tiles = vp.gx * vp.gy;
+    const int lane = threadIdx.x;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
+    const float bxf = (float)bx, byf = (float)by;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const size_t N = (size_t)vp.W * vp.H;
+
+    BwdQuad q0, q1, q2, q3;
+    uint32_t ql0, ql1, ql2, ql3;                           // wave-uniform: last blended position per quadrant
+    {
+        auto init = [&](BwdQuad& s, int qi) -> uint32_t {
+            const int px = bx + (qi & 1) * 8, py = by + (qi >> 1) * 8;
+            const bool inside = px < vp.W && py < vp.H;
+            const size_t pix = (size_t)py * vp.W + px;
+            const float Tf = inside ? final_T[pix] : 1.0f;
+            s.last = inside ? n_contrib[pix] : 0u;
+            s.dL0 = inside ? dL_dcolor[pix] : 0.f;
+            s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
+            s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
+            s.S = vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2;
+            s.T = Tf;
+            return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
+        };
+        ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
+    }
+    const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
+    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);         // the nine lanes that issue the per-entry atomics
+    const uint32_t aoff = row_reduce_component(lane);
+    const int xrow16 = (lane ^ 16) << 2, xrow32 = (lane ^ 32) << 2;     // ds_bpermute byte addresses of the partner lanes
+
+    const int nb = ((int)tile_last + WB - 1) / WB;
+    for (int b = nb - 1; b >= 0; --b) {
+        const int base = b * WB;
+        const int n = min(WB, (int)tile_last - base);
+        float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+        uint32_t nid = 0;
+        if (lane < n) { nid = ids[range.x + base + lane]; n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2; }
+        wave_fence();
+        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
+        // quadrant hit masks of the batch as four 64-bit ballots; a record beyond the last blended entry of a
+        // quadrant cannot matter to that quadrant
+        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
+        const uint32_t mypos = (uint32_t)(base + lane);
+        const uint64_t h0 = __ballot((mymask & 1u) && mypos < ql0), h1 = __ballot((mymask & 2u) && mypos < ql1),
+                       h2 = __ballot((mymask & 4u) && mypos < ql2), h3 = __ballot((mymask & 8u) && mypos < ql3);
+        wave_fence();
+        uint64_t todo = h0 | h1 | h2 | h3;
+        while (todo) {
+            const int e = 63 - __builtin_clzll(todo);     // back to front
+            const uint64_t bit = 1ull << e;
+            todo &= ~bit;
+            const uint32_t pos0 = (uint32_t)(base + e);   // 0-based position in the tile list
+            const float4 r0 = s_r0[e], r1 = s_r1[e];
+            const float cb = s_bi[e].x;
+            const float dx = r0.x - bxf, dy = r0.y - byf;
+            BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            uint64_t any = 0;
+            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
+            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
+            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
+            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
+            if (any == 0) continue;                        // no lane contributed: nothing to reduce
+            // ---- one 64-lane reduction per (tile, Gaussian): rows by DPP (row_reduce_scatter9), then the four rows
+            // through the LDS crossbar (ds_bpermute lane ^ 16, lane ^ 32: two adds on the VALU; v_permlane16/32_swap are
+            // multi-cycle there).  Lanes 0,1,4,5,8,9,12,13 then hold components 0..7 and lane 2 component 8: one atomic
+            // instruction; the record id is wave-uniform (scalar address arithmetic).
+            const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
+            if (DET) {
+                float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
+                if (alane) idst[aoff] = outv;
+            } else {
+                // (record id through v_readlane of a register copy and a scalar-base atomic — no 64-bit VALU multiply-add —
+                //  were measured: no difference, 357..382 us for all four combinations)
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
+                float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+                if (alane) unsafeAtomicAdd(gdst + aoff, outv);
+            }
+        }
+    }
+}
+
 // Software-pipelined variant of blend_backward_tile_kernel (same arithmetic, same sums, bit-identical values per
 // (tile, Gaussian); only WHEN things are issued differs).  PMC of the plain kernel: a wave issues one VALU instruction
 // per ~16 cycles (tools/valu_calib: one wave alone can issue every 5, the SIMD every 2) — its time is latency, not
@@ -1079,8 +1201,12 @@ static bool use_fine(int tiles, int max_tiles) {
 }
 // MSGS_FWD_PREFETCH=0 selects the forward without the LDS record prefetch (A/B measurements)
 static const bool g_fwd_prefetch = [] { const char* e = getenv("MSGS_FWD_PREFETCH"); return !(e && e[0] == '0'); }();
+// MSGS_FWD_EXEC=0: accumulation through selects instead of under the EXEC mask (A/B measurements)
+static const bool g_fwd_exec = [] { const char* e = getenv("MSGS_FWD_EXEC"); return !(e && e[0] == '0'); }();
+// MSGS_BWD_W8=1: the 64-register / 8-waves-per-SIMD one-wave-per-tile backward (A/B measurements)
+static const bool g_bwd_w8 = [] { const char* e = getenv("MSGS_BWD_W8"); return e && e[0] == '1'; }();
 // MSGS_BWD_PIPE=0 selects the un-pipelined one-wave-per-tile backward (A/B measurements)
-static const bool g_bwd_pipe = [] { const char* e = getenv("MSGS_BWD_PIPE"); return !(e && e[0] == '0'); }();
+static const bool g_bwd_pipe = [] { const char* e = getenv("MSGS_BWD_PIPE"); return e && e[0] == '1'; }();
 static bool bwd_v1(int tiles) {
     const int forced = g_bwd_gen.load();
     return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
@@ -1096,12 +1222,12 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
         hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
-    else if (fwd_gen == 1 && g_fwd_prefetch)
-        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib);
-    else if (fwd_gen == 1)
-        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib);
+    else if (fwd_gen == 1) {
+        auto k = g_fwd_prefetch ? (g_fwd_exec ? blend_forward_kernel<true, true> : blend_forward_kernel<true, false>)
+                                : (g_fwd_exec ? blend_forward_kernel<false, true> : blend_forward_kernel<false, false>);
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T,
+                           n_contrib);
+    }
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
                            out_ps, out_depth, final_T, n_contrib);
@@ -1117,6 +1243,9 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD)))
         hipLaunchKernelGGL(blend_backward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
+    else if (!bwd_v1(tiles) && g_bwd_w8)
+        hipLaunchKernelGGL(blend_backward_tile8_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
+                           final_T, n_contrib, dL_dcolor, grad_rec);
     else if (!bwd_v1(tiles) && g_bwd_pipe)
         hipLaunchKernelGGL(blend_backward_tile_pipe_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
                            final_T, n_contrib, dL_dcolor, grad_rec);

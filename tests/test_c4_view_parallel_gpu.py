@@ -13,7 +13,7 @@ from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_er
 
 pytestmark = pytest.mark.gpu
 LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
-FULL_RTOL = 1e-3        # tests/test_fullsize_gpu.py: the documented float32 floor at 1e5..1e6 Gaussians
+FULL_RTOL = 5e-4        # tests/test_fullsize_gpu.py, profiles/r2_parity_floor.md: 2x the largest value measured (3.4e-4, here)
 FULL_Q99 = 1e-4
 
 

@@ -2,15 +2,19 @@
 C3, plus size-independent properties (sortedness of every tile list, checksum of tile ranges, background
 and gradient linearity, determinism).
 
-Gradient tolerance at full size.  The max-norm criterion of the north star (1e-4 rel per tensor) is met on the
-small/medium cases of test_parity_gpu.py (measured 4e-6).  At 1e5-1e6 Gaussians it sits at the float32 noise
-floor of ANY float-atomic implementation: two runs of the same HIP binary differ by 4e-5 on dL/dscale (atomic
-order), and the oracle accumulates in double.  The conic -> covariance chain amplifies that by cancellation for a
-few Gaussians.  The full-size checks therefore assert (i) max-norm <= 1e-3 per tensor, and (ii) the 99th
-percentile of the per-Gaussian error relative to the Gaussian's own gradient <= 1e-4 (measured 8e-6), both on
-the Gaussians without a borderline alpha decision."""
-FULL_RTOL = 1e-3
+Gradient tolerance at full size (measured, profiles/r2_parity_floor.md).  Five of the seven gradient tensors (xyz, both SH
+tensors, opacity, means2D) meet the north star's 1e-4 max-norm at every size and are asserted at 1e-4 (TIGHT).  dL/dscaling
+and dL/drotation end the conic -> covariance chain, which amplifies any difference in the per-Gaussian sums by the squared
+aspect ratio of the footprint: HIP vs oracle is 0.7e-4 .. 2.5e-4 there (3.4e-4 on one C4 view), while the float32 reference
+algorithm itself moves by 3e-4 .. 1.2e-3 when the same oracle source is compiled with FMA contraction, and every float32
+evaluation (oracle, HIP) sits 3e-4 .. 1.7e-3 from the float64 truth.  The full-size checks assert (i) max-norm <= 5e-4 per
+tensor (FULL_RTOL, 2x the largest value measured), (ii) <= 1e-4 on the five tight tensors at C2 / C3, (iii) the 99th
+percentile of the per-Gaussian error relative to the Gaussian's own gradient <= 1e-4 (measured 8e-6) — all on the Gaussians
+without a borderline alpha decision, whose achieved fraction every test prints."""
+FULL_RTOL = 5e-4
 FULL_Q99 = 1e-4
+TIGHT = ("means3D", "features_dc", "features_rest", "opacity", "means2D")
+TIGHT_RTOL = 1e-4
 import ctypes as C
 
 import pytest
@@ -36,7 +40,57 @@ def test_config_c2_forward_backward_vs_oracle():
     out, pc, m2 = hip_render(sc, cam, st, bg, dL)
     orc, og = _oracle(pc.seen, cam, st, bg, dL)
     check_forward(out, orc, "C2")
-    check_backward(pc, m2, og, "C2", flagged=orc.borderline_gaussians, rtol=FULL_RTOL, q99_tol=FULL_Q99)
+    worst = check_backward(pc, m2, og, "C2", flagged=orc.borderline_gaussians, rtol=FULL_RTOL, q99_tol=FULL_Q99)
+    assert all(worst[k] <= TIGHT_RTOL for k in TIGHT), worst
+
+
+def test_config_c2_three_way_with_float64_truth():
+    """C2 against the float64 autograd evaluation of the same pipeline (oracle/torch_oracle.py forward_backward_tiled):
+    the HIP gradients are as close to the truth as the float32 reference algorithm is — the distance of BOTH from the
+    truth (3e-4 .. 1.7e-3 per tensor) is what makes 1e-4 between two float32 evaluations a statement about rounding
+    order, not about correctness.  Also the deterministic mode against the oracle, with the atomic mode's run-to-run noise
+    printed beside it."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import torch_oracle as to
+    from parity_utils import report
+    sc, cam, st = scenes.config("C2")
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 1)
+    out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+    _, pc_b, m2_b = hip_render(sc, cam, st, bg, dL)
+    prev = dgr.set_deterministic(True)
+    try:
+        _, pc_d, m2_d = hip_render(sc, cam, st, bg, dL)
+    finally:
+        dgr.set_deterministic(prev)
+    orc, og = _oracle(pc.seen, cam, st, bg, dL)
+    t_out, tg = to.forward_backward_tiled(pc.seen, cam, st, bg, dL)
+    flagged = orc.borderline_gaussians | (t_out["radii"] != orc.radii)
+    okpx = ~(orc.borderline.bool() | t_out["borderline"])
+    e_orc = (orc.color.double() - t_out["color"]).abs()[:, okpx].max().item()
+    e_hip = (out["render"].detach().cpu().double() - t_out["color"]).abs()[:, okpx].max().item()
+    report("C2", "forward, oracle_f32 vs float64 truth", e_orc)
+    report("C2", "forward, HIP vs float64 truth", e_hip)
+    assert e_hip <= 1.25 * e_orc + 1e-6
+    # gradients: HIP (atomic, deterministic) vs the float32 oracle, and everything vs the truth
+    w_det = check_backward(pc_d, m2_d, og, "C2 deterministic", flagged=flagged, rtol=FULL_RTOL)
+    assert all(w_det[k] <= TIGHT_RTOL for k in TIGHT), w_det
+    to_f32 = {k: v.float() for k, v in tg.items()}
+    w_hip_truth = check_backward(pc, m2, to_f32, "C2 HIP vs truth", flagged=flagged, rtol=1.0)
+    names = {"means3D": "_xyz", "features_dc": "_features_dc", "features_rest": "_features_rest", "opacity": "_opacity",
+             "scaling": "_scaling", "rotation": "_rotation"}
+    noise = {k: rel_err(getattr(pc_b, n).grad, getattr(pc, n).grad) for k, n in names.items()}
+    report("C2", "atomic run-to-run noise, worst tensor", max(noise.values()))
+    # the oracle's own distance from the truth (gradients w.r.t. the activated inputs, where both are defined)
+    w_orc_truth = {}
+    for k in ("means3D", "opacities", "scales", "rotations", "shs", "means2D"):
+        ref = tg[k].double()
+        scale = max(ref.abs().max().item(), 1e-30)
+        d = (og[k].double().reshape(ref.shape) - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values
+        w_orc_truth[k] = (d[~flagged].max() / scale).item()
+    report("C2", "oracle_f32 vs float64 truth, worst tensor (activated-input space)", max(w_orc_truth.values()))
+    report("C2", "HIP vs float64 truth, worst tensor (leaf space)", max(w_hip_truth.values()))
+    assert max(w_hip_truth.values()) <= 2.0 * max(w_orc_truth.values()) + 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +107,8 @@ def test_config_c3_forward_backward_vs_oracle(c3):
     out, pc, m2 = hip_render(sc, cam, st, bg, dL)
     orc, og = _oracle(pc.seen, cam, st, bg, dL)
     check_forward(out, orc, "C3")
-    check_backward(pc, m2, og, "C3", flagged=orc.borderline_gaussians, rtol=FULL_RTOL, q99_tol=FULL_Q99)
+    worst = check_backward(pc, m2, og, "C3", flagged=orc.borderline_gaussians, rtol=FULL_RTOL, q99_tol=FULL_Q99)
+    assert all(worst[k] <= TIGHT_RTOL for k in TIGHT), worst
     assert (out["radii"] > 0).sum().item() == (orc.radii > 0).sum().item()
 
 
