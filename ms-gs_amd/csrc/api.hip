@@ -99,7 +99,7 @@ size_t msgs_stage2_scratch_bytes(int64_t D, int32_t W, int32_t H) {
 }
 size_t msgs_image_bytes(int32_t W, int32_t H) { return ImageLayout(W, H).total; }
 size_t msgs_backward_scratch_bytes(int32_t P) {
-    return align256(sizeof(float) * GRAD_REC_FLOATS * (size_t)(P > 0 ? P : 1));
+    return align256(GRAD_REC_BYTES * (size_t)(P > 0 ? P : 1));
 }
 size_t msgs_backward_scratch_bytes_deterministic(int32_t P, int64_t D) { return DetScratch(P, D).total; }
 
@@ -331,9 +331,9 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     const BinningLayout BL(D, vp.gx * vp.gy);
     const ImageLayout IL(W, H);
     const Timer tm{timing, s};
-    float* grad_rec = (float*)scratch_v;
+    grad_acc_t* grad_rec = (grad_acc_t*)scratch_v;
 
-    HIP_TRY(launch_zero(grad_rec, sizeof(float) * GRAD_REC_FLOATS * (size_t)P, s));
+    HIP_TRY(launch_zero(grad_rec, GRAD_REC_BYTES * (size_t)P, s));
     tm.begin(MSGS_K_BLEND_BWD);
     if (det)      // grad_rec is the first region of the deterministic scratch layout
         HIP_TRY(launch_blend_backward_det(vp, P, geom, (const uint32_t*)(binning + BL.ids), D,

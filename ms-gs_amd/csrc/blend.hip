@@ -12,8 +12,9 @@
 // pixel of the quadrant is exactly what the per-pixel `continue` of the reference does, so results
 // are unchanged.
 //
-// Both kernels are VALU-issue bound (rocprofv3 PMC, profiles/), so the per-(pixel, Gaussian) math is
-// kept minimal: the record carries the conic pre-scaled into the log2 domain and log2(opacity), so
+// Both kernels are INSTRUCTION-ISSUE bound (a SIMD issues about one instruction of any kind per 2 cycles; compares, selects
+// and DPP at half rate, v_exp / v_rcp at a quarter: tools/valu_calib.hip), so the per-(pixel, Gaussian)
+// math is kept minimal: the record carries the conic pre-scaled into the log2 domain and log2(opacity), so
 //     alpha_raw = exp2( A' dx^2 + 2B' dx dy + C' dy^2 + log2 o )
 // is six FMA-class ops and one v_exp_f32; the three monomials double as the weights of the conic sums in
 // the backward, the mean gradient is accumulated as (sum q dx, sum q dy), the colour recurrence is one
@@ -24,8 +25,10 @@
 // Backward reduction: per (wave, record) the nine partial sums are reduced across the 64 lanes with a
 // hand-scheduled DPP reduce-scatter inside each 16-lane row (row_reduce_scatter9: 8 -> 4 -> 2 -> 1 values per
 // lane, the ninth riding on the duplicate lanes), one cross-row all-reduce of the single remaining value, and ONE
-// global_atomic_add_f32 instruction from nine lanes into the 48-byte per-Gaussian gradient record — one atomic per
-// (quadrant or tile, Gaussian, component) instead of the reference's one per (pixel, Gaussian, component).
+// global_atomic_add_f64 instruction from nine lanes into the 80-byte per-Gaussian gradient record of double accumulators
+// (the tiles' float32 sums add up exactly, so the default backward is reproducible whatever order the atomics arrive in:
+// DESIGN.md 4.2) — one atomic per (quadrant or tile, Gaussian, component) instead of the reference's one per (pixel,
+// Gaussian, component).
 // (An LDS accumulator committed once per batch was measured slower and removed, profiles/r1_notes.md.)
 //
 // Roofline: HBM-bound by contract (BASELINE.json); algorithmic bytes K6 = 48*D_trav + 28*N + 8*tiles,
@@ -33,6 +36,7 @@
 #include "msgs_internal.h"
 
 #include <atomic>
+#include <type_traits>
 
 #include <algorithm>
 
@@ -82,10 +86,73 @@ __device__ __forceinline__ int swizzled_tile(int bid, int num_tiles) {
     return (bid & 7) * per + (bid >> 3);
 }
 
+// Per-pixel forward state and the walk over one wave's compacted entry list — shared by the quadrant-per-wave kernel
+// and the fine-grained (4x4 sub-block per wave) kernel, so that both evaluate every pixel with the same instructions in
+// the same order (bit-identical images, test_blend_granularities_agree).
+struct FwdPix {
+    float T, C0, C1, C2, aps, adp;
+};
+// lp[0..cnt): BYTE offsets of the batch's 16-byte records this wave has to evaluate, in list order.  `alive` = lanes still
+// blending, as a SCALAR mask: every predicate is the ballot of one direct comparison combined with scalar logic (a ballot
+// of a derived bool costs two VALU instructions per use), and per-lane selects take their condition from the mask.
+// Returns the byte offset of the last entry blended in this batch (0xFFFFFFFF: none).
+__device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
+                                                 const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive) {
+    uint32_t last_off = 0xFFFFFFFFu;
+    // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
+    //  the LDS reads costs more than the two address instructions it saves)
+    auto blend_entry = [&](uint32_t off) {
+        const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
+        const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
+        const float4 r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
+        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+        const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
+        const float test_T = __fmaf_rn(-st.T, alpha, st.T);
+        const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
+        const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
+        const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
+        const uint64_t validm = alive & m_pow & m_alpha;
+        const uint64_t stopm = validm & m_stop;
+        alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
+        const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
+        const float wgt = blend ? alpha * st.T : 0.0f;
+        st.C0 = fmaf(r1.z, wgt, st.C0); st.C1 = fmaf(r1.w, wgt, st.C1); st.C2 = fmaf(r2.x, wgt, st.C2);
+        st.adp = fmaf(r2.y, wgt, st.adp); st.aps = fmaf(r2.z, wgt, st.aps);
+        st.T = blend ? test_T : st.T;
+        last_off = blend ? off : last_off;
+    };
+    int j = 0;
+    for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
+        if (alive == 0) break;
+        const uint32_t o0 = lp[j], o1 = lp[j + 1];
+        blend_entry(o0);
+        if (alive == 0) break;
+        blend_entry(o1);
+    }
+    if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
+    return last_off;
+}
+
+__device__ __forceinline__ void forward_store(const FwdPix& st, uint32_t last, bool inside, int px, int py,
+                                              const ViewParams& vp, float* out_color, float* out_ps, float* out_depth,
+                                              float* final_T, uint32_t* n_contrib) {
+    if (inside) {
+        const size_t N = (size_t)vp.W * vp.H;
+        const size_t pix = (size_t)py * vp.W + px;
+        out_color[pix] = st.C0 + st.T * vp.bg[0];
+        out_color[N + pix] = st.C1 + st.T * vp.bg[1];
+        out_color[2 * N + pix] = st.C2 + st.T * vp.bg[2];
+        out_ps[pix] = st.aps;
+        out_depth[pix] = st.adp;
+        final_T[pix] = st.T;
+        n_contrib[pix] = last;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
-template <bool PREFETCH, bool EXEC_BLEND>
 __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
@@ -111,7 +178,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
     const int len = (int)(range.y - range.x);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, aps = 0.f, adp = 0.f;
+    FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t last = 0;
     // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
     // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
@@ -139,106 +206,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
             cnt += __popcll(b);
         }
-        uint32_t last_off = 0xFFFFFFFFu;                     // byte offset of the last entry blended in THIS batch
-        // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
-        //  the LDS reads costs more than the two address instructions it saves)
-        auto fetch = [&](uint32_t off, float4& r0, float4& r1, float4& r2) {
-            r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
-            r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
-            r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
-        };
-        auto blend_rec = [&](uint32_t off, const float4& r0, const float4& r1, const float4& r2) {
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
-            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
-            const float test_T = __fmaf_rn(-T, alpha, T);
-            const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
-            const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
-            const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
-            const uint64_t validm = alive & m_pow & m_alpha;
-            const uint64_t stopm = validm & m_stop;
-            alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
-            const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
-            if (EXEC_BLEND) {
-                // the accumulation runs under the EXEC mask of the blending lanes instead of through selects:
-                // v_cndmask (like v_cmp and every DPP instruction) issues at HALF the rate of a plain fp32 VALU
-                // instruction on gfx950 (profiles/r2_valu_calibration.txt: 4.2 vs 2.2 cycles per wave64 instruction),
-                // so three selects cost more than the two moves + the scalar exec bookkeeping, and a record that no
-                // lane of the wave blends skips the block altogether.  Same values in the same order.
-                if (blend) {
-                    const float wgt = alpha * T;
-                    C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
-                    adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
-                    T = test_T;
-                    last_off = off;
-                }
-            } else {
-                const float wgt = blend ? alpha * T : 0.0f;
-                C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
-                adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
-                T = blend ? test_T : T;
-                last_off = blend ? off : last_off;
-            }
-        };
-        auto blend_entry = [&](uint32_t off) {
-            float4 r0, r1, r2;
-            fetch(off, r0, r1, r2);
-            blend_rec(off, r0, r1, r2);
-        };
-        const uint16_t* lp = s_list[w];
-        if (PREFETCH) {
-            // software pipeline: while entry j is evaluated, the record of entry j+1 (three 16-byte LDS reads) AND the
-            // list offset of entry j+2 are in flight — PMC showed the waves parked on s_waitcnt half of their time with the
-            // dependent offset -> record fetch in front of every evaluation.  Two register sets, ping-pong (no moves).
-            // The explicit lgkmcnt(0) at the top of each half makes the hand-over point the same on every path, so the
-            // compiler's own waitcnt insertion does not make the evaluation wait for the loads just issued.
-            if (cnt > 0) {
-                uint32_t offA = lp[0], offB = cnt > 1 ? lp[1] : 0u, offN = 0;
-                float4 a0, a1, a2, b0, b1, b2;
-                fetch(offA, a0, a1, a2);
-                for (int j = 0;; j += 2) {
-                    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): set A and offB have landed
-                    const bool hasB = j + 1 < cnt;
-                    if (hasB) fetch(offB, b0, b1, b2);
-                    if (j + 2 < cnt) offN = lp[j + 2];
-                    if (alive == 0) break;
-                    blend_rec(offA, a0, a1, a2);
-                    if (!hasB) break;
-                    __builtin_amdgcn_s_waitcnt(0xC07F);                  // set B and offN have landed
-                    const bool hasA = j + 2 < cnt;
-                    offA = offN;
-                    if (hasA) fetch(offA, a0, a1, a2);
-                    const uint32_t offBcur = offB;
-                    if (j + 3 < cnt) offB = lp[j + 3];
-                    if (alive == 0) break;
-                    blend_rec(offBcur, b0, b1, b2);
-                    if (!hasA) break;
-                }
-            }
-        } else {
-            int j = 0;
-            for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
-                if (alive == 0) break;
-                const uint32_t o0 = lp[j], o1 = lp[j + 1];
-                blend_entry(o0);
-                if (alive == 0) break;
-                blend_entry(o1);
-            }
-            if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
-        }
+        const uint32_t last_off = forward_walk(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
-    if (inside) {
-        const size_t N = (size_t)vp.W * vp.H;
-        const size_t pix = (size_t)py * vp.W + px;
-        out_color[pix] = C0 + T * vp.bg[0];
-        out_color[N + pix] = C1 + T * vp.bg[1];
-        out_color[2 * N + pix] = C2 + T * vp.bg[2];
-        out_ps[pix] = aps;
-        out_depth[pix] = adp;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-    }
+    forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
 }
 
 // Fine-grained variant for FEW tiles (low pyramid levels): sixteen wave64s per tile, each owning one 4x4 pixel sub-block
@@ -272,7 +243,7 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
     const int len = (int)(range.y - range.x);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, aps = 0.f, adp = 0.f;
+    FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t last = 0;
     // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
     // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
@@ -318,53 +289,10 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
             if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
             cnt += __popcll(b);
         }
-        uint32_t last_off = 0xFFFFFFFFu;                     // byte offset of the last entry blended in THIS batch
-        // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
-        //  the LDS reads costs more than the two address instructions it saves)
-        auto blend_entry = [&](uint32_t off) {
-            const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r0) + off);
-            const float4 r1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r1) + off);
-            const float4 r2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_r2) + off);
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
-            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
-            const float test_T = __fmaf_rn(-T, alpha, T);
-            const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
-            const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
-            const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
-            const uint64_t validm = alive & m_pow & m_alpha;
-            const uint64_t stopm = validm & m_stop;
-            alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
-            const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
-            const float wgt = blend ? alpha * T : 0.0f;
-            C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
-            adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
-            T = blend ? test_T : T;
-            last_off = blend ? off : last_off;
-        };
-        const uint16_t* lp = s_list[w];
-        int j = 0;
-        for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
-            if (alive == 0) break;
-            const uint32_t o0 = lp[j], o1 = lp[j + 1];
-            blend_entry(o0);
-            if (alive == 0) break;
-            blend_entry(o1);
-        }
-        if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
+        const uint32_t last_off = forward_walk(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
-    if (inside) {
-        const size_t N = (size_t)vp.W * vp.H;
-        const size_t pix = (size_t)py * vp.W + px;
-        out_color[pix] = C0 + T * vp.bg[0];
-        out_color[N + pix] = C1 + T * vp.bg[1];
-        out_color[2 * N + pix] = C2 + T * vp.bg[2];
-        out_ps[pix] = aps;
-        out_depth[pix] = adp;
-        final_T[pix] = T;
-        n_contrib[pix] = last;
-    }
+    forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,7 +310,8 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
 // the row total of component 8 when (l & 2) != 0.  The caller adds the four rows.
 // All hazards (VALU write -> DPP read needs two wait states) are resolved by the instruction order inside the block;
 // the leading s_nop covers whatever the compiler scheduled right before it.
-struct BwdSums { float v0, v1, v2, v3, v4, v5, v6, v7, v8; };
+template <class A> struct BwdSumsT { A v0, v1, v2, v3, v4, v5, v6, v7, v8; };
+using BwdSums = BwdSumsT<float>;
 __device__ __forceinline__ float row_reduce_scatter9(const BwdSums& v) {
     float a0, a1, a2, a3, b0, b1, t8, keep, send, c;
     const uint64_t odd = 0xAAAAAAAAAAAAAAAAull, bit1 = 0xCCCCCCCCCCCCCCCCull;
@@ -420,6 +349,51 @@ __device__ __forceinline__ float row_reduce_scatter9(const BwdSums& v) {
 __device__ __forceinline__ uint32_t row_reduce_component(int l) {
     return (l & 2) ? 8u : (uint32_t)(4 * ((l >> 3) & 1) + 2 * ((l >> 2) & 1) + (l & 1));
 }
+// Per-pixel backward state and the walk over one wave's compacted entry list (back to front) — shared by the
+// four-waves-per-tile kernel (CROSS_ROW: the pixels of an 8x8 quadrant fill the wave, the four 16-lane rows are added
+// with v_permlane16/32_swap) and the fine-grained kernel (the sixteen pixels of a 4x4 sub-block live in row 0: the row
+// reduction is the whole reduction).  Same arithmetic per pixel in the same order in both.
+struct BwdPix {
+    float T, S, dL0, dL1, dL2;
+    uint32_t last;
+};
+template <bool CROSS_ROW>
+__device__ __forceinline__ void backward_walk(const uint16_t* lp, int cnt, int base, const float4* s_r0, const float4* s_r1,
+                                              const float* s_b, const uint32_t* s_id, float pxf, float pyf, BwdPix& st,
+                                              bool alane, uint32_t aoff, grad_acc_t* __restrict__ grad_rec) {
+    for (int j = cnt - 1; j >= 0; --j) {
+        const int e = lp[j];
+        const float4 r0 = s_r0[e], r1 = s_r1[e];
+        const float cb = s_b[e];
+        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
+        const float a_raw = __builtin_amdgcn_exp2f(ev.p);
+        const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < st.last) &
+                                __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
+                                __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);   // <=> min(0.99, a_raw) >= 1/255
+        if (validm == 0) continue;
+        const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
+        const float a_m = valid ? a_raw : 0.0f;                // the one select: a masked lane is the identity below
+        const float alpha_m = fminf(0.99f, a_m);
+        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha_m);
+        const float Tn = st.T * inv;
+        st.T = Tn;
+        const float dch = alpha_m * Tn;
+        const float sm = fmaf(cb, st.dL2, fmaf(r1.w, st.dL1, r1.z * st.dL0)) - st.S;
+        const float dL_dalpha = sm * Tn;
+        st.S = fmaf(alpha_m, sm, st.S);
+        const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
+        const BwdSums v = {q * dx, q * dy, q * ev.dxx, q * ev.dxy, q * ev.dyy, q, dch * st.dL0, dch * st.dL1, dch * st.dL2};
+        // rows by DPP; the four rows with v_permlane16/32_swap (in this latency-bound regime they beat ds_bpermute,
+        // profiles/r1_notes.md); scalar record address, one atomic instruction from nine lanes
+        const float rowv = row_reduce_scatter9(v);
+        const float outv = CROSS_ROW ? cross_row_allreduce(rowv) : rowv;
+        const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
+        grad_acc_t* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
+        if (alane) unsafeAtomicAdd(gdst + aoff, (grad_acc_t)outv);
+    }
+}
+
 // Gradient record components accumulated here (scaled to dL/d{mean2D, conic, opacity} per Gaussian
 // in preprocess_backward_kernel):
 //   [0] sum q dx  [1] sum q dy  [2] sum q dx dx   [3] sum q dx dy   [4] sum q dy dy   [5] sum q
@@ -430,7 +404,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
                                                              const float* __restrict__ final_T,
                                                              const uint32_t* __restrict__ n_contrib,
                                                              const float* __restrict__ dL_dcolor,
-                                                             float* __restrict__ grad_rec) {
+                                                             grad_acc_t* __restrict__ grad_rec) {
     __shared__ float4 s_r0[BATCH], s_r1[BATCH];
     __shared__ float s_b[BATCH];
     __shared__ uint32_t s_id[BATCH];
@@ -452,22 +426,22 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     const size_t N = (size_t)vp.W * vp.H;
     const size_t pix = (size_t)py * vp.W + px;
 
-    const float T_final = inside ? final_T[pix] : 1.0f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
-    if (inside) { dL0 = dL_dcolor[pix]; dL1 = dL_dcolor[N + pix]; dL2 = dL_dcolor[2 * N + pix]; }
+    BwdPix st;
+    st.T = inside ? final_T[pix] : 1.0f;
+    st.last = inside ? n_contrib[pix] : 0u;
+    st.dL0 = st.dL1 = st.dL2 = 0.f;
+    if (inside) { st.dL0 = dL_dcolor[pix]; st.dL1 = dL_dcolor[N + pix]; st.dL2 = dL_dcolor[2 * N + pix]; }
 
-    const uint32_t wave_last = wave_max_u32(last);
+    const uint32_t wave_last = wave_max_u32(st.last);
     if (lane == 0) s_wmax[w] = wave_last;
     __syncthreads();
     const uint32_t tile_last = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
-    float T = T_final;
     // S = sum_c dL/dC_c * (colour composited BEHIND the current entry, background included, normalised by the
     // transmittance in front of it).  dL/dalpha_i = T_i (g_i - S_i) with g_i = sum_c dL/dC_c colour_i,c, and
     // S_{i-1} = S_i + alpha_i (g_i - S_i): the three per-channel recurrences of the textbook form collapse into one
     // scalar, and starting it at bg . dL/dC absorbs the separate background term (-T_final bg.dL / (1 - alpha_i)).
-    float S = vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2;
+    st.S = vp.bg[0] * st.dL0 + vp.bg[1] * st.dL1 + vp.bg[2] * st.dL2;
     const bool alane = lane < 16 && (!(lane & 2) || lane == 2);        // the nine lanes that issue the per-entry atomics
     const uint32_t aoff = row_reduce_component(lane);
 
@@ -493,36 +467,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             if (hit) s_list[w][cnt + __popcll(bal & lt_mask)] = (uint16_t)e;
             cnt += __popcll(bal);
         }
-        for (int j = cnt - 1; j >= 0; --j) {
-            const int e = s_list[w][j];
-            const float4 r0 = s_r0[e], r1 = s_r1[e];
-            const float cb = s_b[e];
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
-            const float a_raw = __builtin_amdgcn_exp2f(ev.p);
-            const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < last) &
-                                    __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
-                                    __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);   // <=> min(0.99, a_raw) >= 1/255
-            if (validm == 0) continue;
-            const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
-            const float a_m = valid ? a_raw : 0.0f;                // the one select: a masked lane is the identity below
-            const float alpha_m = fminf(0.99f, a_m);
-            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha_m);
-            const float Tn = T * inv;
-            T = Tn;
-            const float dch = alpha_m * Tn;
-            const float sm = fmaf(cb, dL2, fmaf(r1.w, dL1, r1.z * dL0)) - S;
-            const float dL_dalpha = sm * Tn;
-            S = fmaf(alpha_m, sm, S);
-            const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
-            const BwdSums v = {q * dx, q * dy, q * ev.dxx, q * ev.dxy, q * ev.dyy, q, dch * dL0, dch * dL1, dch * dL2};
-            // rows by DPP, the four rows with v_permlane16/32_swap (in this latency-bound regime they beat ds_bpermute,
-            // profiles/r1_notes.md); scalar record address, one atomic instruction from nine lanes
-            const float outv = cross_row_allreduce(row_reduce_scatter9(v));
-            const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
-            float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-            if (alane) unsafeAtomicAdd(gdst + aoff, outv);
-        }
+        backward_walk<true>(s_list[w], cnt, base, s_r0, s_r1, s_b, s_id, pxf, pyf, st, alane, aoff, grad_rec);
     }
 }
 
@@ -535,7 +480,7 @@ __global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp
                                                              const float* __restrict__ final_T,
                                                              const uint32_t* __restrict__ n_contrib,
                                                              const float* __restrict__ dL_dcolor,
-                                                             float* __restrict__ grad_rec) {
+                                                             grad_acc_t* __restrict__ grad_rec) {
     __shared__ float4 s_r0[BATCH], s_r1[BATCH];
     __shared__ float s_b[BATCH], s_tau[BATCH];
     __shared__ uint32_t s_id[BATCH];
@@ -557,24 +502,24 @@ __global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp
     const size_t N = (size_t)vp.W * vp.H;
     const size_t pix = (size_t)py * vp.W + px;
 
-    const float T_final = inside ? final_T[pix] : 1.0f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
-    if (inside) { dL0 = dL_dcolor[pix]; dL1 = dL_dcolor[N + pix]; dL2 = dL_dcolor[2 * N + pix]; }
+    BwdPix st;
+    st.T = inside ? final_T[pix] : 1.0f;
+    st.last = inside ? n_contrib[pix] : 0u;
+    st.dL0 = st.dL1 = st.dL2 = 0.f;
+    if (inside) { st.dL0 = dL_dcolor[pix]; st.dL1 = dL_dcolor[N + pix]; st.dL2 = dL_dcolor[2 * N + pix]; }
 
-    const uint32_t wave_last = wave_max_u32(last);
+    const uint32_t wave_last = wave_max_u32(st.last);
     if (lane == 0) s_wmax[w] = wave_last;
     __syncthreads();
     uint32_t tile_last = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tile_last = max(tile_last, s_wmax[k]);
 
-    float T = T_final;
     // S = sum_c dL/dC_c * (colour composited BEHIND the current entry, background included, normalised by the
     // transmittance in front of it).  dL/dalpha_i = T_i (g_i - S_i) with g_i = sum_c dL/dC_c colour_i,c, and
     // S_{i-1} = S_i + alpha_i (g_i - S_i): the three per-channel recurrences of the textbook form collapse into one
     // scalar, and starting it at bg . dL/dC absorbs the separate background term (-T_final bg.dL / (1 - alpha_i)).
-    float S = vp.bg[0] * dL0 + vp.bg[1] * dL1 + vp.bg[2] * dL2;
+    st.S = vp.bg[0] * st.dL0 + vp.bg[1] * st.dL1 + vp.bg[2] * st.dL2;
     const bool alane = lane < 16 && (!(lane & 2) || lane == 2);        // the nine lanes that issue the per-entry atomics
     const uint32_t aoff = row_reduce_component(lane);
 
@@ -619,35 +564,7 @@ __global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp
             if (hit) s_list[w][cnt + __popcll(bal & lt_mask)] = (uint16_t)e;
             cnt += __popcll(bal);
         }
-        for (int j = cnt - 1; j >= 0; --j) {
-            const int e = s_list[w][j];
-            const float4 r0 = s_r0[e], r1 = s_r1[e];
-            const float cb = s_b[e];
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
-            const float a_raw = __builtin_amdgcn_exp2f(ev.p);
-            const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < last) &
-                                    __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
-                                    __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);   // <=> min(0.99, a_raw) >= 1/255
-            if (validm == 0) continue;
-            const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
-            const float a_m = valid ? a_raw : 0.0f;                // the one select: a masked lane is the identity below
-            const float alpha_m = fminf(0.99f, a_m);
-            const float inv = __builtin_amdgcn_rcpf(1.0f - alpha_m);
-            const float Tn = T * inv;
-            T = Tn;
-            const float dch = alpha_m * Tn;
-            const float sm = fmaf(cb, dL2, fmaf(r1.w, dL1, r1.z * dL0)) - S;
-            const float dL_dalpha = sm * Tn;
-            S = fmaf(alpha_m, sm, S);
-            const float q = a_m * dL_dalpha;                       // Q6: gradient passes the 0.99 clamp
-            const BwdSums v = {q * dx, q * dy, q * ev.dxx, q * ev.dxy, q * ev.dyy, q, dch * dL0, dch * dL1, dch * dL2};
-            // the sixteen pixels live in row 0 of the wave: the row reduction is the whole reduction
-            const float outv = row_reduce_scatter9(v);
-            const uint32_t gid = __builtin_amdgcn_readfirstlane(s_id[e]);
-            float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-            if (alane) unsafeAtomicAdd(gdst + aoff, outv);
-        }
+        backward_walk<false>(s_list[w], cnt, base, s_r0, s_r1, s_b, s_id, pxf, pyf, st, alane, aoff, grad_rec);
     }
 }
 
@@ -779,6 +696,37 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
     fwd_quad_store(q3, bx + 8, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
 }
 
+// 64-lane all-reduce of a double (deterministic mode only): the same butterfly as wave_allreduce_sum, every move on the two
+// dwords of the value
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_mov_u<CTRL>((uint32_t)u), hi = dpp_mov_u<CTRL>((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_allreduce_sum_f64(double v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    v += dpp_mov_f64<0xB1>(v);            // xor 1
+    v += dpp_mov_f64<0x4E>(v);            // xor 2
+    v += dpp_mov_f64<0x124>(v);           // + quad (q-1)
+    v += dpp_mov_f64<0x128>(v);           // + quads (q-2, q-3): every lane = row sum
+    {
+        const uint64_t u = (uint64_t)__double_as_longlong(v);
+        const u2 lo = __builtin_amdgcn_permlane16_swap((uint32_t)u, (uint32_t)u, false, false);
+        const u2 hi = __builtin_amdgcn_permlane16_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+        v = __longlong_as_double((long long)(((uint64_t)hi.x << 32) | lo.x)) +
+            __longlong_as_double((long long)(((uint64_t)hi.y << 32) | lo.y));
+    }
+    {
+        const uint64_t u = (uint64_t)__double_as_longlong(v);
+        const u2 lo = __builtin_amdgcn_permlane32_swap((uint32_t)u, (uint32_t)u, false, false);
+        const u2 hi = __builtin_amdgcn_permlane32_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+        v = __longlong_as_double((long long)(((uint64_t)hi.x << 32) | lo.x)) +
+            __longlong_as_double((long long)(((uint64_t)hi.y << 32) | lo.y));
+    }
+    return v;
+}
+
 struct BwdQuad {
     float T, S, dL0, dL1, dL2;       // S: see blend_backward_kernel
     uint32_t last;
@@ -789,7 +737,8 @@ struct BwdQuad {
 // quadrant hit masks already removed the quadrants the record cannot touch)
 // (returns the lanes that contributed as a scalar mask: three ballots of direct comparisons and scalar ANDs — a ballot
 //  of a derived bool costs two VALU instructions, and the caller only needs "any lane?")
-__device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSums& v, const float4& r0, const float4& r1, float cb,
+template <class A>
+__device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSumsT<A>& v, const float4& r0, const float4& r1, float cb,
                                                   float dx, float dy, uint32_t pos0) {
     const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
     const float a_raw = __builtin_amdgcn_exp2f(ev.p);
@@ -809,10 +758,20 @@ __device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSums& v, const 
     const float dL_dalpha = sm * Tn;
     s.S = fmaf(alpha_m, sm, s.S);
     const float qq = a_m * dL_dalpha;                         // Q6: gradient passes the 0.99 clamp
-    v.v0 = fmaf(qq, dx, v.v0); v.v1 = fmaf(qq, dy, v.v1);
-    v.v2 = fmaf(qq, ev.dxx, v.v2); v.v3 = fmaf(qq, ev.dxy, v.v3); v.v4 = fmaf(qq, ev.dyy, v.v4);
-    v.v5 += qq;
-    v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
+    if constexpr (sizeof(A) == 4) {
+        v.v0 = fmaf(qq, dx, v.v0); v.v1 = fmaf(qq, dy, v.v1);
+        v.v2 = fmaf(qq, ev.dxx, v.v2); v.v3 = fmaf(qq, ev.dxy, v.v3); v.v4 = fmaf(qq, ev.dyy, v.v4);
+        v.v5 += qq;
+        v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
+    } else {
+        // deterministic (verification) mode: the float32 per-pixel factors enter DOUBLE sums — the structure of the CPU
+        // oracle (float32 terms, double accumulators)
+        const double qd = (double)qq, dd = (double)dch;
+        v.v0 = fma(qd, (double)dx, v.v0); v.v1 = fma(qd, (double)dy, v.v1);
+        v.v2 = fma(qd, (double)ev.dxx, v.v2); v.v3 = fma(qd, (double)ev.dxy, v.v3); v.v4 = fma(qd, (double)ev.dyy, v.v4);
+        v.v5 += qd;
+        v.v6 = fma(dd, (double)s.dL0, v.v6); v.v7 = fma(dd, (double)s.dL1, v.v7); v.v8 = fma(dd, (double)s.dL2, v.v8);
+    }
     return validm;
 }
 
@@ -825,7 +784,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                                                                  const float* __restrict__ final_T,
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
-                                                                 float* __restrict__ grad_rec) {
+                                                                 void* __restrict__ grad_out) {
     __shared__ float4 s_r0[WB], s_r1[WB];
     __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
                                                            // address register serves every LDS read of an entry
@@ -894,253 +853,41 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             const float4 r0 = s_r0[e], r1 = s_r1[e];
             const float cb = s_bi[e].x;
             const float dx = r0.x - bxf, dy = r0.y - byf;
-            BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            BwdSumsT<typename std::conditional<DET, double, float>::type> v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint64_t any = 0;
             if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
             if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
             if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
             if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
             if (any == 0) continue;                        // no lane contributed: nothing to reduce
+            if constexpr (DET) {
+                // deterministic (verification) mode: double sums over the 256 pixels, reduced in double in a fixed tree,
+                // stored per tile entry; det_reduce_kernel adds a Gaussian's entries in double in ascending tile order
+                const double t0 = wave_allreduce_sum_f64(v.v0), t1 = wave_allreduce_sum_f64(v.v1),
+                             t2 = wave_allreduce_sum_f64(v.v2), t3 = wave_allreduce_sum_f64(v.v3),
+                             t4 = wave_allreduce_sum_f64(v.v4), t5 = wave_allreduce_sum_f64(v.v5),
+                             t6 = wave_allreduce_sum_f64(v.v6), t7 = wave_allreduce_sum_f64(v.v7),
+                             t8 = wave_allreduce_sum_f64(v.v8);
+                if (lane == 0) {
+                    double* idst = (double*)grad_out + ((size_t)range.x + pos0) * DET_INST_FLOATS;
+                    idst[0] = t0; idst[1] = t1; idst[2] = t2; idst[3] = t3; idst[4] = t4; idst[5] = t5; idst[6] = t6;
+                    idst[7] = t7; idst[8] = t8;
+                }
+                continue;
+            }
             // ---- one 64-lane reduction per (tile, Gaussian): rows by DPP (row_reduce_scatter9), then the four rows
             // through the LDS crossbar (ds_bpermute lane ^ 16, lane ^ 32: two adds on the VALU; v_permlane16/32_swap are
             // multi-cycle there).  Lanes 0,1,4,5,8,9,12,13 then hold components 0..7 and lane 2 component 8: one atomic
             // instruction; the record id is wave-uniform (scalar address arithmetic).
-            const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
-            if (DET) {
-                float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
-                if (alane) idst[aoff] = outv;
-            } else {
+            if constexpr (!DET) {
+                const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
                 // (record id through v_readlane of a register copy and a scalar-base atomic — no 64-bit VALU multiply-add —
                 //  were measured: no difference, 357..382 us for all four combinations)
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
-                float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-                if (alane) unsafeAtomicAdd(gdst + aoff, outv);
+                grad_acc_t* gdst = (grad_acc_t*)grad_out + (size_t)gid * GRAD_REC_FLOATS;
+                if (alane) unsafeAtomicAdd(gdst + aoff, (grad_acc_t)outv);
             }
         }
-    }
-}
-
-// Eight-waves-per-SIMD variant of blend_backward_tile_kernel: identical arithmetic; the next batch is NOT prefetched into
-// registers (13 VGPRs) and the register budget is capped at 64, so that 8 waves fit a SIMD: 1024 SIMDs x 8 = 8192 slots
-// hold all 8160 tiles of a 1080p frame at once.  With 80 registers (6 waves) the 8160 one-wave tiles run in two rounds of
-// latency-bound waves: PMC showed 3.5 waves resident per SIMD on average, each issuing one VALU instruction per 16 cycles.
-template <bool DET>
-__global__ __launch_bounds__(64, 8) void blend_backward_tile8_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
-                                                                 const uint32_t* __restrict__ ids,
-                                                                 const uint2* __restrict__ ranges,
-                                                                 const float* __restrict__ final_T,
-                                                                 const uint32_t* __restrict__ n_contrib,
-                                                                 const float* __restrict__ dL_dcolor,
-                                                                 float* __restrict__ grad_rec) {
-    __shared__ float4 s_r0[WB], s_r1[WB];
-    __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
-                                                           // address register serves every LDS read of an entry
-    const int num_tiles = vp.gx * vp.gy;
-    const int lane = threadIdx.x;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
-    const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
-    const float bxf = (float)bx, byf = (float)by;
-    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
-    const uint2 range = ranges[tile];
-    const size_t N = (size_t)vp.W * vp.H;
-
-    BwdQuad q0, q1, q2, q3;
-    uint32_t ql0, ql1, ql2, ql3;                           // wave-uniform: last blended position per quadrant
-    {
-        auto init = [&](BwdQuad& s, int qi) -> uint32_t {
-            const int px = bx + (qi & 1) * 8, py = by + (qi >> 1) * 8;
-            const bool inside = px < vp.W && py < vp.H;
-            const size_t pix = (size_t)py * vp.W + px;
-            const float Tf = inside ? final_T[pix] : 1.0f;
-            s.last = inside ? n_contrib[pix] : 0u;
-            s.dL0 = inside ? dL_dcolor[pix] : 0.f;
-            s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
-            s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
-            s.S = vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2;
-            s.T = Tf;
-            return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
-        };
-        ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
-    }
-    const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
-    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);         // the nine lanes that issue the per-entry atomics
-    const uint32_t aoff = row_reduce_component(lane);
-    const int xrow16 = (lane ^ 16) << 2, xrow32 = (lane ^ 32) << 2;     // ds_bpermute byte addresses of the partner lanes
-
-    const int nb = ((int)tile_last + WB - 1) / WB;
-    for (int b = nb - 1; b >= 0; --b) {
-        const int base = b * WB;
-        const int n = min(WB, (int)tile_last - base);
-        float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-        uint32_t nid = 0;
-        if (lane < n) { nid = ids[range.x + base + lane]; n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2; }
-        wave_fence();
-        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
-        // quadrant hit masks of the batch as four 64-bit ballots; a record beyond the last blended entry of a
-        // quadrant cannot matter to that quadrant
-        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
-        const uint32_t mypos = (uint32_t)(base + lane);
-        const uint64_t h0 = __ballot((mymask & 1u) && mypos < ql0), h1 = __ballot((mymask & 2u) && mypos < ql1),
-                       h2 = __ballot((mymask & 4u) && mypos < ql2), h3 = __ballot((mymask & 8u) && mypos < ql3);
-        wave_fence();
-        uint64_t todo = h0 | h1 | h2 | h3;
-        while (todo) {
-            const int e = 63 - __builtin_clzll(todo);     // back to front
-            const uint64_t bit = 1ull << e;
-            todo &= ~bit;
-            const uint32_t pos0 = (uint32_t)(base + e);   // 0-based position in the tile list
-            const float4 r0 = s_r0[e], r1 = s_r1[e];
-            const float cb = s_bi[e].x;
-            const float dx = r0.x - bxf, dy = r0.y - byf;
-            BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            uint64_t any = 0;
-            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
-            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
-            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
-            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
-            if (any == 0) continue;                        // no lane contributed: nothing to reduce
-            // ---- one 64-lane reduction per (tile, Gaussian): rows by DPP (row_reduce_scatter9), then the four rows
-            // through the LDS crossbar (ds_bpermute lane ^ 16, lane ^ 32: two adds on the VALU; v_permlane16/32_swap are
-            // multi-cycle there).  Lanes 0,1,4,5,8,9,12,13 then hold components 0..7 and lane 2 component 8: one atomic
-            // instruction; the record id is wave-uniform (scalar address arithmetic).
-            const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
-            if (DET) {
-                float* idst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;     // grad_rec = inst_grad here
-                if (alane) idst[aoff] = outv;
-            } else {
-                // (record id through v_readlane of a register copy and a scalar-base atomic — no 64-bit VALU multiply-add —
-                //  were measured: no difference, 357..382 us for all four combinations)
-                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
-                float* gdst = grad_rec + (size_t)gid * GRAD_REC_FLOATS;
-                if (alane) unsafeAtomicAdd(gdst + aoff, outv);
-            }
-        }
-    }
-}
-
-// Software-pipelined variant of blend_backward_tile_kernel (same arithmetic, same sums, bit-identical values per
-// (tile, Gaussian); only WHEN things are issued differs).  PMC of the plain kernel: a wave issues one VALU instruction
-// per ~16 cycles (tools/valu_calib: one wave alone can issue every 5, the SIMD every 2) — its time is latency, not
-// issue: per entry the LDS record fetch, the two DEPENDENT ds_bpermute of the cross-row step and the atomics sit
-// exposed on the wave's in-order stream, and with ~3.5 resident waves per SIMD nothing covers them.  Here
-//   * the records of the NEXT entry are fetched from LDS before the current entry is evaluated, and
-//   * the cross-row reduction + atomic of entry k are deferred into entry k+1's evaluation: first ds_bpermute at the
-//     top, second one after two quadrant steps, atomic after the last — each LDS round trip is covered by ~70 VALU
-//     instructions of independent work.
-template <bool DET>
-__global__ __launch_bounds__(64) void blend_backward_tile_pipe_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
-                                                                      const uint32_t* __restrict__ ids,
-                                                                      const uint2* __restrict__ ranges,
-                                                                      const float* __restrict__ final_T,
-                                                                      const uint32_t* __restrict__ n_contrib,
-                                                                      const float* __restrict__ dL_dcolor,
-                                                                      float* __restrict__ grad_rec) {
-    __shared__ float4 s_r0[WB], s_r1[WB];
-    __shared__ float4 s_bi[WB];
-    const int num_tiles = vp.gx * vp.gy;
-    const int lane = threadIdx.x;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
-    const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
-    const float bxf = (float)bx, byf = (float)by;
-    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
-    const uint2 range = ranges[tile];
-    const size_t N = (size_t)vp.W * vp.H;
-
-    BwdQuad q0, q1, q2, q3;
-    uint32_t ql0, ql1, ql2, ql3;
-    {
-        auto init = [&](BwdQuad& s, int qi) -> uint32_t {
-            const int px = bx + (qi & 1) * 8, py = by + (qi >> 1) * 8;
-            const bool inside = px < vp.W && py < vp.H;
-            const size_t pix = (size_t)py * vp.W + px;
-            const float Tf = inside ? final_T[pix] : 1.0f;
-            s.last = inside ? n_contrib[pix] : 0u;
-            s.dL0 = inside ? dL_dcolor[pix] : 0.f;
-            s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
-            s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
-            s.S = vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2;
-            s.T = Tf;
-            return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
-        };
-        ql0 = init(q0, 0); ql1 = init(q1, 1); ql2 = init(q2, 2); ql3 = init(q3, 3);
-    }
-    const uint32_t tile_last = max(max(ql0, ql1), max(ql2, ql3));
-    const bool alane = lane < 16 && (!(lane & 2) || lane == 2);
-    const uint32_t aoff = row_reduce_component(lane);
-    const int xrow16 = (lane ^ 16) << 2, xrow32 = (lane ^ 32) << 2;
-
-    // deferred reduction of the previous contributing entry (wave-uniform control)
-    float pend = 0.f;
-    float* pend_dst = nullptr;                             // wave-uniform destination record; nullptr = nothing pending
-    auto finish1 = [&]() { return __int_as_float(__builtin_amdgcn_ds_bpermute(xrow16, __float_as_int(pend))); };
-    auto finish2 = [&]() { return __int_as_float(__builtin_amdgcn_ds_bpermute(xrow32, __float_as_int(pend))); };
-    auto commit = [&]() {
-        if (alane) {
-            if (DET) pend_dst[aoff] = pend; else unsafeAtomicAdd(pend_dst + aoff, pend);
-        }
-        pend_dst = nullptr;
-    };
-
-    const int nb = ((int)tile_last + WB - 1) / WB;
-    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-    uint32_t nid = 0;
-    if (nb > 0) {
-        const int i0 = (nb - 1) * WB + lane;
-        if (i0 < (int)tile_last) { nid = ids[range.x + i0]; n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2; }
-    }
-    for (int b = nb - 1; b >= 0; --b) {
-        const int base = b * WB;
-        const int n = min(WB, (int)tile_last - base);
-        wave_fence();
-        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
-        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
-        const uint32_t mypos = (uint32_t)(base + lane);
-        const uint64_t h0 = __ballot((mymask & 1u) && mypos < ql0), h1 = __ballot((mymask & 2u) && mypos < ql1),
-                       h2 = __ballot((mymask & 4u) && mypos < ql2), h3 = __ballot((mymask & 8u) && mypos < ql3);
-        wave_fence();
-        if (b > 0) {
-            nid = ids[range.x + base - WB + lane];
-            n0 = rec[nid].r0; n1 = rec[nid].r1; n2 = rec[nid].r2;
-        }
-        uint64_t todo = h0 | h1 | h2 | h3;
-        if (todo == 0) continue;
-        int e = 63 - __builtin_clzll(todo);
-        float4 pr0 = s_r0[e], pr1 = s_r1[e], pbi = s_bi[e];            // records of the first entry of the batch
-        while (todo) {
-            const uint64_t bit = 1ull << e;
-            todo &= ~bit;
-            const uint32_t pos0 = (uint32_t)(base + e);
-            const float4 r0 = pr0, r1 = pr1;
-            const float cb = pbi.x;
-            const uint32_t gid_v = __float_as_uint(pbi.y);
-            if (todo) {                                                // next entry's records: in flight during this one
-                e = 63 - __builtin_clzll(todo);
-                pr0 = s_r0[e]; pr1 = s_r1[e]; pbi = s_bi[e];
-            }
-            const float dx = r0.x - bxf, dy = r0.y - byf;
-            float b16 = 0.f;
-            if (pend_dst) b16 = finish1();
-            BwdSums v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            uint64_t any = 0;
-            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
-            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
-            float b32 = 0.f;
-            if (pend_dst) { pend += b16; b32 = finish2(); }
-            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
-            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
-            if (pend_dst) { pend += b32; commit(); }
-            if (any == 0) continue;
-            pend = row_reduce_scatter9(v);
-            if (DET) pend_dst = grad_rec + ((size_t)range.x + pos0) * DET_INST_FLOATS;
-            else pend_dst = grad_rec + (size_t)__builtin_amdgcn_readfirstlane(gid_v) * GRAD_REC_FLOATS;
-        }
-    }
-    if (pend_dst) {
-        pend += finish1();
-        pend += finish2();
-        commit();
     }
 }
 
@@ -1199,14 +946,6 @@ static bool use_fine(int tiles, int max_tiles) {
     const int g = g_granularity.load();
     return g == 2 || (g == 0 && tiles < max_tiles);
 }
-// MSGS_FWD_PREFETCH=0 selects the forward without the LDS record prefetch (A/B measurements)
-static const bool g_fwd_prefetch = [] { const char* e = getenv("MSGS_FWD_PREFETCH"); return !(e && e[0] == '0'); }();
-// MSGS_FWD_EXEC=0: accumulation through selects instead of under the EXEC mask (A/B measurements)
-static const bool g_fwd_exec = [] { const char* e = getenv("MSGS_FWD_EXEC"); return !(e && e[0] == '0'); }();
-// MSGS_BWD_W8=1: the 64-register / 8-waves-per-SIMD one-wave-per-tile backward (A/B measurements)
-static const bool g_bwd_w8 = [] { const char* e = getenv("MSGS_BWD_W8"); return e && e[0] == '1'; }();
-// MSGS_BWD_PIPE=0 selects the un-pipelined one-wave-per-tile backward (A/B measurements)
-static const bool g_bwd_pipe = [] { const char* e = getenv("MSGS_BWD_PIPE"); return e && e[0] == '1'; }();
 static bool bwd_v1(int tiles) {
     const int forced = g_bwd_gen.load();
     return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
@@ -1222,12 +961,9 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
         hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
-    else if (fwd_gen == 1) {
-        auto k = g_fwd_prefetch ? (g_fwd_exec ? blend_forward_kernel<true, true> : blend_forward_kernel<true, false>)
-                                : (g_fwd_exec ? blend_forward_kernel<false, true> : blend_forward_kernel<false, false>);
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T,
-                           n_contrib);
-    }
+    else if (fwd_gen == 1)
+        hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib);
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
                            out_ps, out_depth, final_T, n_contrib);
@@ -1236,19 +972,13 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
 
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 float* grad_rec, hipStream_t s) {
+                                 grad_acc_t* grad_rec, hipStream_t s) {
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
     if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD)))
         hipLaunchKernelGGL(blend_backward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
-    else if (!bwd_v1(tiles) && g_bwd_w8)
-        hipLaunchKernelGGL(blend_backward_tile8_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
-                           final_T, n_contrib, dL_dcolor, grad_rec);
-    else if (!bwd_v1(tiles) && g_bwd_pipe)
-        hipLaunchKernelGGL(blend_backward_tile_pipe_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
-                           final_T, n_contrib, dL_dcolor, grad_rec);
     else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
@@ -1266,34 +996,34 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
 namespace {
 __global__ __launch_bounds__(256) void det_reduce_kernel(const uint32_t* __restrict__ gid_sorted,
                                                          const uint32_t* __restrict__ entry_of, int64_t D,
-                                                         const float* __restrict__ inst_grad,
-                                                         float* __restrict__ grad_rec) {
+                                                         const double* __restrict__ inst_grad,
+                                                         grad_acc_t* __restrict__ grad_rec) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= D) return;
     const uint32_t g = gid_sorted[q];
     if (q > 0 && gid_sorted[q - 1] == g) return;               // not the head of its segment
-    // the per-tile sums of one Gaussian are added in DOUBLE: a Gaussian that covers hundreds of tiles otherwise loses
-    // ~1e-6 of its sums to float32 accumulation, which the conic -> covariance chain of K8 amplifies by the squared
-    // aspect ratio (measured at C2: dL/dscale 2.5e-4 from the oracle with float accumulation; profiles/r2_parity_floor.md)
+    // the per-tile sums of one Gaussian are added in DOUBLE (exact for any realistic tile count): the deterministic mode
+    // is the verification mode, and a Gaussian that covers hundreds of tiles otherwise loses ~1e-6 of its sums to float32
+    // accumulation, which the conic -> covariance chain of K8 amplifies by the squared aspect ratio
     double acc[DET_INST_FLOATS];
 #pragma unroll
     for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] = 0.0;
     for (int64_t k = q; k < D && gid_sorted[k] == g; ++k) {
-        const float* src = inst_grad + (size_t)entry_of[k] * DET_INST_FLOATS;
+        const double* src = inst_grad + (size_t)entry_of[k] * DET_INST_FLOATS;
 #pragma unroll
-        for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] += (double)src[c];
+        for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] += src[c];
     }
-    float* dst = grad_rec + (size_t)g * GRAD_REC_FLOATS;
+    grad_acc_t* dst = grad_rec + (size_t)g * GRAD_REC_FLOATS;
 #pragma unroll
-    for (int c = 0; c < DET_INST_FLOATS; ++c) dst[c] = (float)acc[c];
+    for (int c = 0; c < DET_INST_FLOATS; ++c) dst[c] = (grad_acc_t)acc[c];
 }
 }  // namespace
 
 DetScratch::DetScratch(int64_t P, int64_t D) {
     const int64_t n = D > 0 ? D : 1;
     size_t o = 0;
-    grad_rec = o;  o = align256(o + sizeof(float) * GRAD_REC_FLOATS * (size_t)(P > 0 ? P : 1));
-    inst_grad = o; o = align256(o + sizeof(float) * DET_INST_FLOATS * (size_t)n);
+    grad_rec = o;  o = align256(o + GRAD_REC_BYTES * (size_t)(P > 0 ? P : 1));
+    inst_grad = o; o = align256(o + sizeof(double) * DET_INST_FLOATS * (size_t)n);
     keys = o;      o = align256(o + 4 * (size_t)n);
     keys_s = o;    o = align256(o + 4 * (size_t)n);
     entry = o;     o = align256(o + 4 * (size_t)n);
@@ -1307,20 +1037,16 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0 || D <= 0) return hipSuccess;
     const DetScratch L(P, D);
-    float* grad_rec = (float*)(scratch + L.grad_rec);
-    float* inst = (float*)(scratch + L.inst_grad);
+    grad_acc_t* grad_rec = (grad_acc_t*)(scratch + L.grad_rec);
+    double* inst = (double*)(scratch + L.inst_grad);
     uint32_t* keys = (uint32_t*)(scratch + L.keys);
     uint32_t* keys_s = (uint32_t*)(scratch + L.keys_s);
     uint32_t* entry = (uint32_t*)(scratch + L.entry);
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    hipError_t e = launch_zero(inst, sizeof(float) * DET_INST_FLOATS * (size_t)D, s);
+    hipError_t e = launch_zero(inst, sizeof(double) * DET_INST_FLOATS * (size_t)D, s);
     if (e != hipSuccess) return e;
-    if (g_bwd_pipe)
-        hipLaunchKernelGGL(blend_backward_tile_pipe_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges,
-                           final_T, n_contrib, dL_dcolor, inst);
-    else
-        hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
-                           n_contrib, dL_dcolor, inst);
+    hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
+                       n_contrib, dL_dcolor, inst);
     e = hipMemcpyAsync(keys, ids, 4 * (size_t)D, hipMemcpyDeviceToDevice, s);      // the sort clobbers its input
     if (e != hipSuccess) return e;
     int bits = 1;

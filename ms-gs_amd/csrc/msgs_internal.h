@@ -28,12 +28,24 @@ struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2; };
 //   q0 = { px, py, k*conic.A, k*conic.B },  q1 = { k*conic.C, tau2, bits(minx | miny<<16), bits(maxx | maxy<<16) }
 struct __attribute__((aligned(32))) BinRec { float4 q0, q1; };
 
-// Per-Gaussian 2-D gradient record accumulated by the blend backward: 12 floats = 48 B.
+// Per-Gaussian 2-D gradient record accumulated by the blend backward: 10 accumulators.
 //   [0] sum q dx  [1] sum q dy  [2] sum q dx^2  [3] sum q dx dy  [4] sum q dy^2  [5] sum q  [6..8] dL/drgb
-//   [9..11] pad, with q = alpha_raw dL/dalpha; preprocess_backward_kernel turns [0..5] into
+//   [9] pad, with q = alpha_raw dL/dalpha; preprocess_backward_kernel turns [0..5] into
 //   dL/dmean2D (NDC-ish units), dL/dconic (A, B-half, C) and dL/dopacity with per-Gaussian factors.
-constexpr int GRAD_REC_FLOATS = 12;
-constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode: the nine K7 sums
+// The accumulators are DOUBLES (80-byte records, global_atomic_add_f64): the per-tile float32 sums of a Gaussian are
+// then added exactly, whatever the order the tiles' atomics arrive in — the default backward is reproducible to the
+// last float bit after the final rounding, like the CPU oracle (double accumulators, one cast), and the order noise of
+// float atomics (up to 1.5e-3 of the dL/dscale max-norm on a C4 view through K8's amplification) is gone.
+// -DMSGS_GRAD_REC_F32 builds the float32 variant (48-byte records) for A/B measurements.
+#if defined(MSGS_GRAD_REC_F32)
+typedef float grad_acc_t;
+constexpr int GRAD_REC_FLOATS = 12;     // accumulators per record (9 used)
+#else
+typedef double grad_acc_t;
+constexpr int GRAD_REC_FLOATS = 10;     // accumulators per record (9 used)
+#endif
+constexpr size_t GRAD_REC_BYTES = sizeof(grad_acc_t) * GRAD_REC_FLOATS;
+constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode: the nine K7 sums (DOUBLES)
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -300,7 +312,7 @@ struct ZeroJob { uint32_t* p0; size_t n0; uint32_t* p1; size_t n1; };
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
                              char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
-                                      const char* geom, const float* grad_rec, const msgs_grads_t& grads,
+                                      const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s);
 hipError_t launch_sh_grad_from_views(int P, int n_views, int deg, const float* means3D, const float* campos,
                                      int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
@@ -371,7 +383,7 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
                                 uint32_t* n_contrib, hipStream_t s);
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 float* grad_rec, hipStream_t s);
+                                 grad_acc_t* grad_rec, hipStream_t s);
 hipError_t launch_binning_stats(const ViewParams& vp, int P, const int32_t* radii, const uint32_t* n_contrib,
                                 unsigned long long* out2 /* device, zeroed inside */, hipStream_t s);
 

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp, msgs_gaussians_t g,
                                                                   const int32_t* __restrict__ radii,
                                                                   const char* __restrict__ geom,
-                                                                  const float* __restrict__ grad_rec,
+                                                                  const grad_acc_t* __restrict__ grad_rec,
                                                                   msgs_grads_t grads) {
     __shared__ float s_rows[4][64 * ROW_LDS];
     __shared__ uint8_t s_idx[4][64];
@@ -606,9 +606,22 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     if (rendered) {
         Cam cm;
         load_cam(vp, cm);
-        const float4 ga = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 0];
-        const float4 gb = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 1];
-        const float4 gc = reinterpret_cast<const float4*>(grad_rec)[3 * (size_t)i + 2];
+        // the nine sums, accumulated in grad_acc_t (double by default) and rounded to float ONCE here — the CPU oracle's
+        // structure (double accumulators, one cast)
+        float4 ga, gb, gc;
+        {
+            const grad_acc_t* gr = grad_rec + (size_t)i * GRAD_REC_FLOATS;
+            grad_acc_t t[GRAD_REC_FLOATS];
+            typedef grad_acc_t acc2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < GRAD_REC_FLOATS / 2; ++k) {
+                const acc2 v2 = reinterpret_cast<const acc2*>(gr)[k];
+                t[2 * k] = v2.x; t[2 * k + 1] = v2.y;
+            }
+            ga = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+            gb = make_float4((float)t[4], (float)t[5], (float)t[6], (float)t[7]);
+            gc = make_float4((float)t[8], 0.f, 0.f, 0.f);
+        }
         // blend_backward_kernel accumulates [sum q dx, sum q dy, sum q dx^2, sum q dx dy, sum q dy^2, sum q]
         // with q = alpha_raw dL/dalpha; the per-Gaussian constant factors are applied here (blend.hip).
         const float gA = -0.5f * ga.z, gBh = -0.5f * ga.w, gC = -0.5f * gb.x;
@@ -902,7 +915,7 @@ hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, in
 }
 
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
-                                      const char* geom, const float* grad_rec, const msgs_grads_t& grads,
+                                      const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s) {
     if (g.P == 0) return hipSuccess;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,

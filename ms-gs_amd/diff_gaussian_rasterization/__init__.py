@@ -283,6 +283,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             outs = (color, torch.zeros(H, W, device=dev), torch.zeros(H, W, device=dev),
                     torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, device=dev))
             ctx.mark_non_differentiable(*outs[1:])
+            ctx.set_materialize_grads(False)
             return outs
         ctx.empty = False
         call = _Call(raster_settings, means3D, _opt(sh), _opt(colors_precomp), opacities, _opt(scales),
@@ -295,6 +296,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.shapes = (means2D.shape, opacities.shape)
         _save_inputs(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the four non-differentiable outputs
         return color, acc_ps, depth, radii, pixel_sizes
 
     @staticmethod
@@ -303,6 +305,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             return tuple(torch.zeros(s, device=ctx.dev) for s in ctx.in_shapes) + (None,) * 6
         _check_saved(ctx)
         call = ctx.call
+        if grad_color is None:
+            grad_color = torch.zeros(3, call.H, call.W, dtype=torch.float32, device=call.device)
         geom, binning, image, D = ctx.state
         dev, P, K = call.device, call.P, call.K
         lib = _C.lib
@@ -408,12 +412,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                                      rotation_raw))
         _save_inputs(ctx, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the four non-differentiable outputs
         return color, acc_ps, depth, radii, pixel_sizes
 
     @staticmethod
     def backward(ctx, grad_color, grad_acc_ps, grad_depth, grad_radii, grad_pixel_sizes):
         _check_saved(ctx)
         call = ctx.call
+        if grad_color is None:
+            grad_color = torch.zeros(3, call.H, call.W, dtype=torch.float32, device=call.device)
         geom, binning, image, D = ctx.state
         dev, P = call.device, call.P
         lib = _C.lib
@@ -463,6 +470,7 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
         _save_inputs(ctx, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw, shs, opacities,
                      scales, rotations)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the four non-differentiable outputs
         return color, acc_ps, depth, radii, pixel_sizes
 
     @staticmethod

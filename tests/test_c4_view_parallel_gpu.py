@@ -13,7 +13,10 @@ from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_er
 
 pytestmark = pytest.mark.gpu
 LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
-FULL_RTOL = 5e-4        # tests/test_fullsize_gpu.py, profiles/r2_parity_floor.md: 2x the largest value measured (3.4e-4, here)
+# tests/test_fullsize_gpu.py, profiles/r2_parity_floor.md: 1e-4 on xyz / SH / opacity / means2D; dL/dscaling and dL/drotation
+# (K8's amplification of chance-sized float32 differences) at 2e-3 in the default mode (measured 9.9e-4 on view 3) and 5e-4 in
+# the deterministic mode (measured 3.8e-4)
+TIGHT_RTOL, LOOSE, LOOSE_DET = 1e-4, 2e-3, 5e-4
 FULL_Q99 = 1e-4
 
 
@@ -37,19 +40,26 @@ def rccl_single_rank():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("v", [0, 3, 6])
-def test_c4_ring_views_vs_oracle(c4, v):
+@pytest.mark.parametrize("v,det", [(0, False), (3, False), (3, True), (6, False)])
+def test_c4_ring_views_vs_oracle(c4, v, det):
     """full size: 1 M Gaussians in the ball of radius 4, camera v of 8 on the ring of radius 8, 1920x1080"""
+    import diff_gaussian_rasterization as dgr
     from oracle import oracle_ctypes as oc
     sc, cams, st = c4
     cam = cams[v]
     bg = torch.zeros(3)
     dL = scenes.grad_seed(cam.image_width, cam.image_height, 40 + v)
-    out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+    prev = dgr.set_deterministic(det)
+    try:
+        out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+    finally:
+        dgr.set_deterministic(prev)
     orc = oc.rasterize(pc.seen, cam, st, bg)
     og = oc.backward(orc, dL)
     check_forward(out, orc, f"C4 view {v}")
-    worst = check_backward(pc, m2, og, f"C4 view {v}", flagged=orc.borderline_gaussians, rtol=FULL_RTOL, q99_tol=FULL_Q99)
+    loose = LOOSE_DET if det else LOOSE
+    worst = check_backward(pc, m2, og, f"C4 view {v}" + (" deterministic" if det else ""), flagged=orc.borderline_gaussians,
+                           rtol=TIGHT_RTOL, rtol_by_key={"scaling": loose, "rotation": loose}, q99_tol=FULL_Q99)
     V = int((orc.radii > 0).sum())
     print(f"C4 view {v}: V={V} D_ref={orc.num_instances} borderline px {orc.borderline.float().mean().item():.5%} "
           f"borderline Gaussians {orc.borderline_gaussians.float().mean().item():.4%} worst {max(worst.values()):.2e}")

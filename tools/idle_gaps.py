@@ -2,9 +2,10 @@
 import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
-idx = [i for i, e in enumerate(ev) if 'blend_forward_kernel' in e[2]]
-n = 10
-seg = ev[idx[8]:idx[8 + n] + 1]
+idx = [i for i, e in enumerate(ev) if 'blend_forward' in e[2]]
+n = min(10, len(idx) - 4)
+first = min(8, len(idx) - n - 1)
+seg = ev[idx[first]:idx[first + n] + 1]
 span = seg[-1][0] - seg[0][0]
 busy = sum(e[1] - e[0] for e in seg[:-1])
 print("per step: span %.1f us, busy %.1f us, idle %.1f us" % (span / n / 1e3, busy / n / 1e3, (span - busy) / n / 1e3))

@@ -142,6 +142,38 @@ STREAM_KERNEL(k_mov_dpp,
     "v_mov_b32_dpp %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
     "v_mov_b32_dpp %4, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n"
     "v_mov_b32_dpp %6, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n")
+// scalar-unit streams: the blend loops carry ~1 scalar instruction (mask logic, loop control, branches) per VALU instruction
+STREAM_KERNEL(k_salu,
+    "s_and_b64 s[20:21], s[22:23], %16\n s_or_b64 s[22:23], s[20:21], %16\n s_and_b64 s[20:21], s[22:23], %16\n s_or_b64 s[22:23], s[20:21], %16\n"
+    "s_and_b64 s[20:21], s[22:23], %16\n s_or_b64 s[22:23], s[20:21], %16\n s_and_b64 s[20:21], s[22:23], %16\n s_or_b64 s[22:23], s[20:21], %16\n")
+STREAM_KERNEL(k_valu_salu_1to1,
+    "v_fma_f32 %0, %0, %12, %13\n s_and_b64 s[20:21], s[22:23], %16\n v_fma_f32 %1, %1, %12, %13\n s_or_b64 s[22:23], s[20:21], %16\n"
+    "v_fma_f32 %2, %2, %12, %13\n s_and_b64 s[20:21], s[22:23], %16\n v_fma_f32 %3, %3, %12, %13\n s_or_b64 s[22:23], s[20:21], %16\n")
+STREAM_KERNEL(k_valu_salu_1to2,
+    "v_fma_f32 %0, %0, %12, %13\n s_and_b64 s[20:21], s[22:23], %16\n s_or_b64 s[22:23], s[20:21], %16\n v_fma_f32 %1, %1, %12, %13\n"
+    "s_and_b64 s[20:21], s[22:23], %16\n s_or_b64 s[22:23], s[20:21], %16\n v_fma_f32 %2, %2, %12, %13\n s_and_b64 s[20:21], s[22:23], %16\n")
+// branches that are not taken / taken (to the next instruction), with the compare that feeds them
+STREAM_KERNEL(k_valu_branch_nottaken,
+    "v_fma_f32 %0, %0, %12, %13\n s_cmp_eq_u32 s20, s20\n s_cbranch_scc0 1f\n 1:\n v_fma_f32 %1, %1, %12, %13\n s_cmp_eq_u32 s20, s20\n s_cbranch_scc0 2f\n 2:\n"
+    "v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n")
+STREAM_KERNEL(k_valu_branch_taken,
+    "v_fma_f32 %0, %0, %12, %13\n s_cmp_eq_u32 s20, s20\n s_cbranch_scc1 1f\n s_nop 0\n 1:\n v_fma_f32 %1, %1, %12, %13\n s_cmp_eq_u32 s20, s20\n s_cbranch_scc1 2f\n s_nop 0\n 2:\n"
+    "v_fma_f32 %2, %2, %12, %13\n v_fma_f32 %3, %3, %12, %13\n")
+// the forward blend's real per-entry shape as compiled: 22 VALU (3 compares, 1 exp), ~20 scalar (mask logic + loop control
+// + 5 branches), 4 LDS reads
+STREAM_KERNEL(k_fwd_real_shape,
+    "ds_read_b128 v[40:43], %17\n ds_read_b128 v[44:47], %17 offset:16\n ds_read_b96 v[48:50], %17 offset:32\n ds_read_u16 v51, %17 offset:48\n"
+    "s_cmp_lt_u32 s20, s21\n s_cselect_b64 s[22:23], -1, 0\n s_cmp_ge_u32 s20, s21\n s_cbranch_scc0 1f\n 1:\n"
+    "s_cmp_eq_u64 s[22:23], 0\n s_cbranch_scc0 2f\n 2:\n s_waitcnt lgkmcnt(0)\n"
+    "v_sub_f32 %0, v40, %12\n v_sub_f32 %1, v41, %13\n v_mul_f32 %2, %0, %0\n v_mul_f32 %3, %1, %0\n v_mul_f32 %4, %1, %1\n"
+    "v_fma_f32 %5, v44, %4, v45\n v_fmac_f32 %5, v43, %3\n v_fmac_f32 %5, v42, %2\n v_exp_f32 %6, %5\n"
+    "v_cmp_le_f32 vcc, %5, v45\n v_min_f32 %7, 0x3f7d70a4, %6\n v_cmp_le_f32_e64 s[20:21], %12, %7\n v_fma_f32 %6, -%0, %7, %0\n"
+    "s_and_b64 s[20:21], vcc, s[20:21]\n v_cmp_gt_f32_e64 s[22:23], %13, %6\n s_and_b64 s[20:21], s[20:21], %16\n s_and_b64 s[22:23], s[20:21], s[22:23]\n"
+    "s_xor_b64 s[22:23], s[22:23], s[20:21]\n s_and_saveexec_b64 s[20:21], s[22:23]\n"
+    "v_mul_f32 %1, %0, %7\n v_fmac_f32 %2, v46, %1\n v_fmac_f32 %3, v47, %1\n v_fmac_f32 %4, v48, %1\n v_fmac_f32 %5, v49, %1\n v_fmac_f32 %6, v50, %1\n"
+    "v_mov_b32 %0, %6\n v_mov_b32 %7, v51\n"
+    "s_or_b64 exec, exec, s[20:21]\n s_xor_b64 s[22:23], s[22:23], %16\n s_andn2_b64 vcc, exec, s[22:23]\n s_cbranch_vccz 3f\n 3:\n"
+    "s_add_i32 s20, s20, 2\n s_cmp_lt_u32 s20, s21\n s_cbranch_scc0 4f\n 4:\n")
 STREAM_KERNEL(k_ds_bpermute,
     "ds_bpermute_b32 %0, %15, %0\n ds_bpermute_b32 %1, %15, %1\n ds_bpermute_b32 %2, %15, %2\n ds_bpermute_b32 %3, %15, %3\n"
     "ds_bpermute_b32 %4, %15, %4\n ds_bpermute_b32 %5, %15, %5\n ds_bpermute_b32 %6, %15, %6\n ds_bpermute_b32 %7, %15, %7\n s_waitcnt lgkmcnt(0)\n")
@@ -171,6 +203,12 @@ int main(int argc, char** argv) {
         {"v_cndmask_b32 (SGPR mask) x8", k_cndmask_sgpr, 8, ""},
         {"v_cmp_lt_f32 -> SGPR pair x8", k_cmp_to_sgpr, 8, ""},
         {"v_cmp -> s_and -> v_cndmask, + v_fma (x2)", k_cmp_sand_cndmask, 8, "6 VALU + 2 SALU per body"},
+        {"s_and_b64 / s_or_b64 x8 (scalar only)", k_salu, 8, "SALU"},
+        {"v_fma_f32 : SALU 1:1 (4 + 4)", k_valu_salu_1to1, 8, "per instruction of the 8"},
+        {"v_fma_f32 : SALU 1:2 (3 + 5)", k_valu_salu_1to2, 8, "per instruction of the 8"},
+        {"4 v_fma + 2 (s_cmp + branch not taken)", k_valu_branch_nottaken, 8, "per instruction of the 8"},
+        {"4 v_fma + 2 (s_cmp + branch taken)", k_valu_branch_taken, 8, "per instruction of the 8 (+2 skipped s_nop)"},
+        {"forward blend, real per-entry shape", k_fwd_real_shape, 53, "22 VALU + 27 scalar/branch/wait + 4 LDS; x53 = cycles per entry"},
         {"ds_bpermute_b32 x8 + wait", k_ds_bpermute, 8, "LDS crossbar"},
         {"v_cmp_lt_f32 -> vcc x8", k_cmp_vcc, 8, ""},
         {"v_min_f32 / v_sub_f32 x8", k_min_sub, 8, ""},
