@@ -219,11 +219,14 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
-/* Deterministic mode (process-wide switch; initial value from the environment variable MSGS_DETERMINISTIC=1).
- * The forward is always bitwise reproducible.  The backward normally accumulates per-Gaussian sums with float
- * atomics (order varies run to run, ~1e-5 relative noise); with the switch on, msgs_backward stores the sums of
- * every tile entry, groups them by Gaussian with a stable sort and adds them in a fixed order: bitwise reproducible,
- * about 0.4 ms slower at C3, and the scratch buffer must hold msgs_backward_scratch_bytes_deterministic(P, D) bytes.
+/* Deterministic (verification) mode (process-wide switch; initial value from the environment variable
+ * MSGS_DETERMINISTIC=1).  The forward is always bitwise reproducible.  The default backward adds the float32 sum each
+ * tile delivers for a Gaussian into DOUBLE accumulators with float64 atomics: the sums are exact, so the result does not
+ * depend on the order the atomics arrive in (reproducible in practice: a double total can move by 1e-16, which changes the
+ * rounded float about once in 1e9 values).  With the switch on, msgs_backward accumulates the per-pixel float32 factors in
+ * double inside the tile as well, stores the nine sums of every tile entry, groups them by Gaussian with a stable sort and
+ * adds them in ascending tile order: reproducible by construction and the accumulation structure of the CPU oracle; about
+ * 1.4 ms slower at C3, and the scratch buffer must hold msgs_backward_scratch_bytes_deterministic(P, D) bytes.
  * msgs_set_deterministic returns the previous value. */
 int msgs_set_deterministic(int32_t on);
 int msgs_get_deterministic(void);

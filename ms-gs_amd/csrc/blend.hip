@@ -97,7 +97,11 @@ struct FwdPix {
 // of a derived bool costs two VALU instructions per use), and per-lane selects take their condition from the mask.
 // Returns the byte offset of the last entry blended in this batch (0xFFFFFFFF: none).
 __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
-                                                 const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive) {
+                                                 const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io) {
+    // the state lives in LOCAL scalars while the list is walked (through the struct reference the compiler turned the
+    // two selects of the update into EXEC-masked moves with duplicated loop-carried copies: +14 % VALU instructions)
+    float T = st.T, C0 = st.C0, C1 = st.C1, C2 = st.C2, aps = st.aps, adp = st.adp;
+    uint64_t alive = alive_io;
     uint32_t last_off = 0xFFFFFFFFu;
     // (a scalar entry index via readfirstlane was measured: 221 -> 257 us — the VALU->SALU->VALU hop in front of
     //  the LDS reads costs more than the two address instructions it saves)
@@ -108,7 +112,7 @@ __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, co
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
         const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
-        const float test_T = __fmaf_rn(-st.T, alpha, st.T);
+        const float test_T = __fmaf_rn(-T, alpha, T);
         const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
         const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
         const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
@@ -116,10 +120,10 @@ __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, co
         const uint64_t stopm = validm & m_stop;
         alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
         const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
-        const float wgt = blend ? alpha * st.T : 0.0f;
-        st.C0 = fmaf(r1.z, wgt, st.C0); st.C1 = fmaf(r1.w, wgt, st.C1); st.C2 = fmaf(r2.x, wgt, st.C2);
-        st.adp = fmaf(r2.y, wgt, st.adp); st.aps = fmaf(r2.z, wgt, st.aps);
-        st.T = blend ? test_T : st.T;
+        const float wgt = blend ? alpha * T : 0.0f;
+        C0 = fmaf(r1.z, wgt, C0); C1 = fmaf(r1.w, wgt, C1); C2 = fmaf(r2.x, wgt, C2);
+        adp = fmaf(r2.y, wgt, adp); aps = fmaf(r2.z, wgt, aps);
+        T = blend ? test_T : T;
         last_off = blend ? off : last_off;
     };
     int j = 0;
@@ -131,6 +135,8 @@ __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, co
         blend_entry(o1);
     }
     if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
+    st.T = T; st.C0 = C0; st.C1 = C1; st.C2 = C2; st.aps = aps; st.adp = adp;
+    alive_io = alive;
     return last_off;
 }
 
