@@ -124,6 +124,9 @@ typedef struct msgs_grads {
     float* dL_dcov3D;          /* [P,6]   when cov3D_precomp was given                               */
     float* dL_dfeatures_dc;    /* [P,1,3]  raw mode only                                                     */
     float* dL_dfeatures_rest;  /* [P,15,3] raw mode only                                                     */
+    void* factors_ready;       /* optional hipEvent_t, factored SH gradient only: dL_dcolors is written by a kernel of its
+                                * own BEFORE the per-Gaussian backward and this event is recorded right behind it, so that
+                                * the caller can start the all-gather of the factors while the rest of msgs_backward runs */
 } msgs_grads_t;
 
 /* Optional per-kernel timing (bench.py's roofline leg).  The caller owns the events; the library

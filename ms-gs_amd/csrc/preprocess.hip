@@ -830,13 +830,34 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     if (grads.dL_dmeans3D) { grads.dL_dmeans3D[3 * i] = dmean[0]; grads.dL_dmeans3D[3 * i + 1] = dmean[1]; grads.dL_dmeans3D[3 * i + 2] = dmean[2]; }
     if (grads.dL_dmeans2D) { grads.dL_dmeans2D[3 * i] = g2x; grads.dL_dmeans2D[3 * i + 1] = g2y; grads.dL_dmeans2D[3 * i + 2] = 0.f; }
     if (grads.dL_dopacities) grads.dL_dopacities[i] = dopac;
-    if (grads.dL_dcolors) { grads.dL_dcolors[3 * i] = dcolr[0]; grads.dL_dcolors[3 * i + 1] = dcolr[1]; grads.dL_dcolors[3 * i + 2] = dcolr[2]; }
+    if (grads.dL_dcolors && !factored_sh) { grads.dL_dcolors[3 * i] = dcolr[0]; grads.dL_dcolors[3 * i + 1] = dcolr[1]; grads.dL_dcolors[3 * i + 2] = dcolr[2]; }
     if (grads.dL_dscales) { grads.dL_dscales[3 * i] = dscale[0]; grads.dL_dscales[3 * i + 1] = dscale[1]; grads.dL_dscales[3 * i + 2] = dscale[2]; }
     if (grads.dL_drotations) reinterpret_cast<float4*>(grads.dL_drotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
     if (grads.dL_dcov3D) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) grads.dL_dcov3D[6 * i + k] = dcov[k];
     }
+}
+
+// The factors themselves: dL/drgb of one view (the three colour sums of the gradient record, zero where the colour was
+// clamped, Q8, and for Gaussians that were not rendered) — a kernel of its own in front of K9, so that the exchange of
+// the factors can overlap with K9 (msgs_grads_t::factors_ready).
+__global__ __launch_bounds__(256) void sh_factor_kernel(int P, const int32_t* __restrict__ radii,
+                                                        const char* __restrict__ geom,
+                                                        const grad_acc_t* __restrict__ grad_rec,
+                                                        float* __restrict__ dL_dcolors) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (radii[i] > 0) {
+        const GeomLayout L(P);
+        const uint32_t fl = reinterpret_cast<const uint32_t*>(geom + L.flags)[i];
+        const grad_acc_t* gr = grad_rec + (size_t)i * GRAD_REC_FLOATS;
+        c0 = (fl & 1u) ? 0.f : (float)gr[6];
+        c1 = (fl & 2u) ? 0.f : (float)gr[7];
+        c2 = (fl & 4u) ? 0.f : (float)gr[8];
+    }
+    dL_dcolors[3 * (size_t)i] = c0; dL_dcolors[3 * (size_t)i + 1] = c1; dL_dcolors[3 * (size_t)i + 2] = c2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -918,6 +939,16 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s) {
     if (g.P == 0) return hipSuccess;
+    if (g.raw_params != 0 && grads.dL_dfeatures_dc == nullptr) {          // factored SH gradient: the factors first
+        hipLaunchKernelGGL(sh_factor_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, g.P, radii, geom, grad_rec,
+                           grads.dL_dcolors);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (grads.factors_ready) {
+            e = hipEventRecord((hipEvent_t)grads.factors_ready, s);
+            if (e != hipSuccess) return e;
+        }
+    }
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
                        grad_rec, grads);
     return hipGetLastError();

@@ -323,7 +323,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_cov = torch.empty(P, 6, dtype=torch.float32, device=dev) if call.cov is not None else None
             scratch = _backward_scratch(P, D, dev)
             grads = _C.Grads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
-                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, None)
+                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, None, None)
             _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
@@ -344,10 +344,6 @@ class _RasterizeGaussians(torch.autograd.Function):
 _grad_sinks = {}
 
 
-def _sink_key(t):
-    return id(t)
-
-
 def _save_inputs(ctx, *tensors):
     """Everything the backward re-reads goes through save_for_backward, so that an in-place edit between forward and
     backward (optimizer step, reset_opacity-style edit) raises autograd's version-counter error instead of yielding
@@ -360,21 +356,25 @@ def _check_saved(ctx):
         ctx.saved_tensors              # raises "modified by an inplace operation" when a version changed
 
 
-_sh_factor_sink = [None]
+_sh_factor_sink = [None, None]          # [destination tensor, optional torch.cuda.Event recorded once the factors are written]
 
 
-def set_grad_sinks(mapping, sh_factor=None):
+def set_grad_sinks(mapping, sh_factor=None, factors_ready=None):
     """mapping: {leaf parameter: destination tensor (float32, contiguous, same numel)} or None to clear.
     sh_factor: optional [P,3] float32 destination.  When given, the backward of the raw / chained entries does NOT form
     the 48-float SH gradient rows: it writes this view's clamp-masked dL/drgb there (the SH gradient is the outer product
     basis(direction) x dL/drgb, rebuilt by sh_grad_from_views after the ranks have exchanged the factors) and returns
-    None for features_dc / features_rest."""
+    None for features_dc / features_rest.  factors_ready: optional torch.cuda.Event (created BEFORE the call so that its
+    handle exists); the library records it on the backward's stream right behind the kernel that writes the factors, ahead
+    of the per-Gaussian backward — a side stream that waits on it can start exchanging the factors while that kernel runs."""
     _grad_sinks.clear()
     _sh_factor_sink[0] = None
+    _sh_factor_sink[1] = None
     if sh_factor is not None:
         if sh_factor.dtype != torch.float32 or not sh_factor.is_contiguous() or sh_factor.dim() != 2 or sh_factor.shape[1] != 3:
             raise ValueError("sh_factor sink must be a contiguous float32 [P,3] tensor")
         _sh_factor_sink[0] = sh_factor
+        _sh_factor_sink[1] = factors_ready
     if mapping:
         for leaf, dest in mapping.items():
             if dest.dtype != torch.float32 or not dest.is_contiguous() or dest.numel() != leaf.numel():
@@ -384,8 +384,14 @@ def set_grad_sinks(mapping, sh_factor=None):
             _grad_sinks[id(leaf)] = (weakref.ref(leaf), dest)
 
 
-def _grad_out(key, shape, dev):
-    hit = _grad_sinks.get(key)
+def _snapshot_sinks(ctx, leaves):
+    """Called in forward (the caller's thread): the sinks registered for THIS call travel on its ctx, so that the
+    backward — which runs on autograd's worker thread — never reads module state another thread may be changing."""
+    ctx.sinks = tuple(_grad_sinks.get(id(t)) for t in leaves)
+    ctx.sh_factor = (_sh_factor_sink[0], _sh_factor_sink[1])
+
+
+def _grad_out(hit, shape, dev):
     if hit is not None and hit[0]() is not None and hit[1].device == dev:
         return hit[1].view(shape)                   # a NEW alias: autograd may adopt it as param.grad
     return torch.empty(shape, dtype=torch.float32, device=dev)
@@ -408,8 +414,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
-        ctx.leaf_keys = tuple(_sink_key(t) for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
-                                                     rotation_raw))
+        _snapshot_sinks(ctx, (xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw))
         _save_inputs(ctx, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the four non-differentiable outputs
@@ -428,9 +433,9 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         with _on_device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             dL = _f32c(grad_color)
-            kx, kdc, krest, kop, ksc, krot = ctx.leaf_keys
+            kx, kdc, krest, kop, ksc, krot = ctx.sinks
             g_m2 = torch.empty(P, 3, dtype=torch.float32, device=dev)
-            factor = _sh_factor_sink[0]
+            factor, ready = ctx.sh_factor
             if factor is not None and (factor.device != dev or factor.shape[0] != P):
                 raise ValueError("sh_factor sink does not match this model (device / number of Gaussians)")
             g_xyz = _grad_out(kx, (P, 3), dev)
@@ -440,7 +445,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_opac, g_scal, g_rot = _grad_out(kop, op_shape, dev), _grad_out(ksc, (P, 3), dev), _grad_out(krot, (P, 4), dev)
             scratch = _backward_scratch(P, D, dev)
             grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, _ptr(factor), _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
-                             _ptr(g_dc), _ptr(g_rest))
+                             _ptr(g_dc), _ptr(g_rest),
+                             C.c_void_p(ready.cuda_event) if (factor is not None and ready is not None) else None)
             _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
@@ -465,8 +471,7 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
         color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
-        ctx.leaf_keys = tuple(_sink_key(t) for t in (xyz, features_dc, features_rest, opacity_raw, scaling_raw,
-                                                     rotation_raw))
+        _snapshot_sinks(ctx, (xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw))
         _save_inputs(ctx, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw, shs, opacities,
                      scales, rotations)
         ctx.mark_non_differentiable(acc_ps, depth, radii, pixel_sizes)
@@ -485,6 +490,9 @@ chain_reference_getters = os.environ.get("MSGS_NO_GETTER_CHAIN", "0") != "1"
 # the chained kernels read the SH rows from the concatenated tensor the reference built (aligned rows, visible ones
 # only: K1 111 -> 89 us, K9 141 -> 126 us at C3) at the price of keeping that [P,16,3] tensor alive until backward
 _chain_reads_cat = os.environ.get("MSGS_CHAIN_SPLIT_READS", "0") != "1"
+
+
+_warned_chain = [False]
 
 
 def _leaf(fn):
@@ -643,6 +651,15 @@ class GaussianRasterizer(nn.Module):
         if chain_reference_getters and torch.is_grad_enabled() and shs is not None and cov3D_precomp is None \
                 and means3D.shape[0] > 0 and means3D.device.type == "cuda":
             leaves = _match_reference_getters(means3D, shs, opacities, scales, rotations)
+            if leaves is None and not _warned_chain[0] and all(
+                    t is not None and t.grad_fn is not None for t in (shs, opacities, scales, rotations)):
+                # all four inputs carry an autograd history but it is not the reference's getters (or PyTorch renamed
+                # its autograd nodes): correct results through the plain path, but say so once — the chained backward
+                # is ~15 % of the step at 1 M Gaussians
+                _warned_chain[0] = True
+                import warnings
+                warnings.warn("diff_gaussian_rasterization: inputs were not recognised as the reference's getters "
+                              "(cat / sigmoid / exp / normalize of leaf parameters); their backward runs in autograd")
             if leaves is not None:
                 o = lambda t: t if t is not None else empty
                 return _RasterizeGaussiansChained.apply(

@@ -158,8 +158,10 @@ class FactoredGradExchange:
       * the remaining 11 floats (xyz 3, opacity 1, scaling 3, rotation 4) go through one flat all-reduce (ncclAvg).
 
     Per GPU and step at 1 M Gaussians and 8 ranks: 7 x 12 MB received by the all-gather + 2 x 7/8 x 44 MB for the
-    all-reduce = 161 MB, against 413 MB for the dense bucket; both collectives run concurrently on RCCL's stream.
-    Exact: no quantisation, the same float32 terms in a different (fixed) summation order.
+    all-reduce = 161 MB, against 413 MB for the dense bucket.  The all-gather starts as soon as the factors are written
+    — the library emits them with a kernel of its own in front of the per-Gaussian backward and signals an event
+    (msgs_grads_t::factors_ready) — and so overlaps that kernel; the SH rows are rebuilt while the all-reduce of the
+    small bucket is still in flight.  Exact: no quantisation, the same float32 terms in a different (fixed) summation order.
 
         ex = FactoredGradExchange(model, world)
         ex.begin_view(); loss.backward(); ex.end_view(camera_center); ex.finish()     # then optimizer.step()
@@ -197,9 +199,17 @@ class FactoredGradExchange:
                 self.avg_op = dist.ReduceOp.AVG
             except Exception:
                 self.avg_op = None
+        # overlap of the factor all-gather with the per-Gaussian backward (K9): the library writes the factors with a
+        # kernel of its own in front of K9 and records `ready` behind it; the all-gather is issued from a side stream that
+        # only waits for that event (HIP path only: the injected test doubles have no event)
+        self.side = self.ready = None
         if reconstruct is None or set_sinks is None:
             import diff_gaussian_rasterization as dgr
             reconstruct = reconstruct or dgr.sh_grad_from_views
+            if set_sinks is None and dev.type == "cuda":
+                self.side = torch.cuda.Stream(device=dev)
+                self.ready = torch.cuda.Event()
+                self.ready.record(torch.cuda.current_stream(dev))       # creates the native handle
             set_sinks = set_sinks or dgr.set_grad_sinks
         self._reconstruct, self._set_sinks = reconstruct, set_sinks
 
@@ -207,7 +217,10 @@ class FactoredGradExchange:
         for n in ("_features_dc", "_features_rest"):
             getattr(self.model, n).grad = None
         self.small.detach_grads()
-        self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3))
+        if self.ready is not None:
+            self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3), factors_ready=self.ready)
+        else:
+            self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3))
 
     def end_view(self, camera_center):
         """after backward(): issue both collectives (asynchronously; they run on the communicator's stream)"""
@@ -217,22 +230,42 @@ class FactoredGradExchange:
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 raise RuntimeError("FactoredGradExchange: a gradient did not land in the bucket (the rasterizer was "
                                    "not called through its raw / chained entry)")
-        self.send[3 * self.P:3 * self.P + 3] = camera_center.to(self.send.device, torch.float32).reshape(3)
         if self.active:
             op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
-            self.pending = [dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True),
-                            dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)]
+            cc = camera_center.to(self.send.device, torch.float32).reshape(3)
+            if self.side is not None:
+                # the factors are final once `ready` has fired (before K9 ends): gather them from the side stream,
+                # concurrently with K9; the small bucket's all-reduce follows K9 on the main stream
+                main = torch.cuda.current_stream(self.send.device)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self.ready)
+                    self.send[3 * self.P:3 * self.P + 3] = cc
+                    ag = dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True)
+                self.send.record_stream(self.side)
+                self.gathered.record_stream(self.side)
+                ar = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+                self.pending = [ag, ar]
+                self._main = main
+            else:
+                self.send[3 * self.P:3 * self.P + 3] = cc
+                self.pending = [dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True),
+                                dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)]
+        else:
+            self.send[3 * self.P:3 * self.P + 3] = camera_center.to(self.send.device, torch.float32).reshape(3)
 
     def finish(self):
         """wait for the exchange (stream-level for NCCL) and rebuild the SH gradient; afterwards every leaf's .grad
         holds the gradient averaged over the `world` views of this step"""
-        for w in self.pending:
+        if self.pending:
+            self.pending[0].wait()                 # the factors of every rank have arrived (stream-level wait for NCCL)
+        # the SH rows are rebuilt while the small bucket's all-reduce is still in flight
+        self._reconstruct(self.model._xyz.detach(), self.gathered, self.n_rows, int(self.model.active_sh_degree),
+                          1.0 / self.world, self.g_dc, self.g_rest)
+        for w in self.pending[1:]:
             w.wait()
         self.pending = []
         if self.world > 1 and (not self.active or self.avg_op is None):
             self.small.flat.div_(self.world)
-        self._reconstruct(self.model._xyz.detach(), self.gathered, self.n_rows, int(self.model.active_sh_degree),
-                          1.0 / self.world, self.g_dc, self.g_rest)
         self.model._features_dc.grad = self.g_dc
         self.model._features_rest.grad = self.g_rest
 

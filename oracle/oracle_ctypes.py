@@ -41,7 +41,7 @@ class Grads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p)]
+                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p)]
 
 
 def build(force=False):
@@ -203,7 +203,7 @@ def backward(r, dL_dcolor, num_threads=0):
         out["cov3D_precomp"] = torch.zeros(P, 6)
     gr = Grads(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out.get("shs")), _ptr(out.get("colors_precomp")),
                _ptr(out["opacities"]), _ptr(out.get("scales")), _ptr(out.get("rotations")),
-               _ptr(out.get("cov3D_precomp")), None, None)
+               _ptr(out.get("cov3D_precomp")), None, None, None)
     rc = L.msgs_oracle_backward(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), int(num_threads))
     if rc != 0:
         raise RuntimeError(f"msgs_oracle_backward failed: {rc}")
