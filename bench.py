@@ -375,6 +375,15 @@ def main():
                                                 C.c_void_p(scratch.data_ptr()), scratch.numel(), o,
                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stats")
             stats = {"D": int(D), "D_trav": int(o[0]), "V": int(o[1])}
+            # lane efficiency of the blend forward, measured by a counting replica of the kernel on this state
+            o3 = (C.c_int64 * 3)()
+            dgr._C.check(lib.msgs_blend_lane_stats(C.byref(ctx.call.view), C.c_void_p(geom.data_ptr()), geom.numel(), P, int(D),
+                                                   C.c_void_p(binning.data_ptr()), binning.numel(),
+                                                   C.c_void_p(scratch.data_ptr()), scratch.numel(), o3,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lane stats")
+            stats["blend_fwd_lanes"] = {"wave_entry_evaluations": int(o3[0]), "evaluated_lanes": 64 * int(o3[0]),
+                                        "lanes_still_blending": int(o3[1]), "lanes_blended": int(o3[2]),
+                                        "lane_efficiency": round(int(o3[2]) / max(64 * int(o3[0]), 1), 4)}
         except Exception as e:  # statistics are informative; never fail the bench line on them
             stats = {"error": repr(e)}
         kernels = None

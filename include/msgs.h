@@ -222,6 +222,14 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
+/* Diagnostic: lane efficiency of the blend forward.  Replays the quadrant-per-wave forward kernel on the state a forward left
+ * behind (geom / binning of msgs_forward; nothing is written to them or to any image) with scalar counters:
+ * out_host[0] = (wave, entry) evaluations — each evaluates 64 lanes; out_host[1] = lanes still blending summed over them;
+ * out_host[2] = lanes that blended (alpha >= 1/255, power <= 0, before termination).  Synchronises `stream`. */
+int msgs_blend_lane_stats(const msgs_view_t* view, const void* geom, size_t geom_bytes, int32_t P, int64_t D,
+                          const void* binning, size_t binning_bytes, void* scratch, size_t scratch_bytes,
+                          int64_t* out_host, void* stream);
+
 /* Deterministic (verification) mode (process-wide switch; initial value from the environment variable
  * MSGS_DETERMINISTIC=1).  The forward is always bitwise reproducible.  The default backward adds the float32 sum each
  * tile delivers for a Gaussian into DOUBLE accumulators with float64 atomics: the sums are exact, so the result does not

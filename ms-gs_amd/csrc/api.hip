@@ -390,6 +390,26 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
     return MSGS_OK;
 }
 
+int msgs_blend_lane_stats(const msgs_view_t* view, const void* geom, size_t geom_bytes, int32_t P, int64_t D,
+                          const void* binning_v, size_t binning_bytes, void* scratch, size_t scratch_bytes,
+                          int64_t* out_host, void* stream) {
+    if (!view || !geom || !binning_v || !scratch || !out_host || scratch_bytes < 24 || P < 0) return MSGS_ERR_INVALID_ARG;
+    const int W = view->image_width, H = view->image_height;
+    if (geom_bytes < msgs_geom_bytes(P) || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    const ViewParams vp = make_view_params(view);
+    const BinningLayout BL(D, vp.gx * vp.gy);
+    const char* binning = (const char*)binning_v;
+    unsigned long long* dev = (unsigned long long*)scratch;
+    HIP_TRY(launch_blend_lane_stats(vp, (const char*)geom, (const uint32_t*)(binning + BL.ids),
+                                    (const uint2*)(binning + BL.ranges), dev, s));
+    unsigned long long host[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(host, dev, 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 3; ++k) out_host[k] = (int64_t)host[k];
+    return MSGS_OK;
+}
+
 int msgs_adam_step(const msgs_adam_tensor_t* tensors, int32_t n_tensors, int64_t step, double beta1, double beta2,
                    double eps, void* stream) {
     if (n_tensors < 0 || n_tensors > MSGS_ADAM_MAX_TENSORS || step < 1 || (n_tensors && !tensors))

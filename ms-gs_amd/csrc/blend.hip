@@ -96,8 +96,13 @@ struct FwdPix {
 // blending, as a SCALAR mask: every predicate is the ballot of one direct comparison combined with scalar logic (a ballot
 // of a derived bool costs two VALU instructions per use), and per-lane selects take their condition from the mask.
 // Returns the byte offset of the last entry blended in this batch (0xFFFFFFFF: none).
+// COUNT (diagnostic replica, msgs_blend_lane_stats): also counts, per wave, the entry evaluations (x 64 = evaluated lanes), the
+// lanes still blending at each of them and the lanes that blended — scalar popcounts, no effect on the arithmetic.
+struct LaneStats { uint32_t steps, alive, blended; };
+template <bool COUNT = false>
 __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
-                                                 const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io) {
+                                                 const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io,
+                                                 LaneStats* stats = nullptr) {
     // the state lives in LOCAL scalars while the list is walked (through the struct reference the compiler turned the
     // two selects of the update into EXEC-masked moves with duplicated loop-carried copies: +14 % VALU instructions)
     float T = st.T, C0 = st.C0, C1 = st.C1, C2 = st.C2, aps = st.aps, adp = st.adp;
@@ -118,6 +123,9 @@ __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, co
         const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
         const uint64_t validm = alive & m_pow & m_alpha;
         const uint64_t stopm = validm & m_stop;
+        if (COUNT) {
+            stats->steps += 1u; stats->alive += (uint32_t)__popcll(alive); stats->blended += (uint32_t)__popcll(validm & ~stopm);
+        }
         alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
         const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
         const float wgt = blend ? alpha * T : 0.0f;
@@ -159,6 +167,7 @@ __device__ __forceinline__ void forward_store(const FwdPix& st, uint32_t last, b
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
+template <bool COUNT>
 __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
@@ -166,7 +175,8 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
                                                             float* __restrict__ out_ps,
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ final_T,
-                                                            uint32_t* __restrict__ n_contrib) {
+                                                            uint32_t* __restrict__ n_contrib,
+                                                            unsigned long long* __restrict__ lane_stats) {
     __shared__ float4 s_r0[BATCH], s_r1[BATCH], s_r2[BATCH];
     __shared__ uint32_t s_mask[BATCH];
     __shared__ uint16_t s_list[4][BATCH];
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    LaneStats ls = {0u, 0u, 0u};
     uint32_t last = 0;
     // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
     // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
@@ -212,10 +223,18 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
             cnt += __popcll(b);
         }
-        const uint32_t last_off = forward_walk(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive);
+        const uint32_t last_off = forward_walk<COUNT>(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, &ls);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
-    forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    if (COUNT) {
+        if (lane == 0) {
+            atomicAdd(&lane_stats[0], (unsigned long long)ls.steps);
+            atomicAdd(&lane_stats[1], (unsigned long long)ls.alive);
+            atomicAdd(&lane_stats[2], (unsigned long long)ls.blended);
+        }
+    } else {
+        forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    }
 }
 
 // Fine-grained variant for FEW tiles (low pyramid levels): sixteen wave64s per tile, each owning one 4x4 pixel sub-block
@@ -968,8 +987,8 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
         hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib);
     else if (fwd_gen == 1)
-        hipLaunchKernelGGL(blend_forward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib);
+        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr);
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
                            out_ps, out_depth, final_T, n_contrib);
@@ -1061,6 +1080,19 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys_s, entry, D, inst,
                        grad_rec);
+    return hipGetLastError();
+}
+
+// diagnostic: the quadrant-per-wave forward replayed with lane counters (no outputs written)
+hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
+                                   unsigned long long* out3, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out3, 0, 24, s);
+    if (e != hipSuccess) return e;
+    const int tiles = vp.gx * vp.gy;
+    if (tiles)
+        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, reinterpret_cast<const GaussRec*>(geom),
+                           ids, ranges, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (uint32_t*)nullptr, out3);
     return hipGetLastError();
 }
 

@@ -384,6 +384,8 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  grad_acc_t* grad_rec, hipStream_t s);
+hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
+                                   unsigned long long* out3 /* device, zeroed inside */, hipStream_t s);
 hipError_t launch_binning_stats(const ViewParams& vp, int P, const int32_t* radii, const uint32_t* n_contrib,
                                 unsigned long long* out2 /* device, zeroed inside */, hipStream_t s);
 

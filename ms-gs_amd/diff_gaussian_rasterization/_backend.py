@@ -121,6 +121,9 @@ def _load():
     lib.msgs_binning_stats.restype = C.c_int
     lib.msgs_binning_stats.argtypes = [C.POINTER(View), C.c_int32, vp, vp, sz, vp, sz, vp, sz,
                                        C.POINTER(C.c_int64), vp]
+    lib.msgs_blend_lane_stats.restype = C.c_int
+    lib.msgs_blend_lane_stats.argtypes = [C.POINTER(View), vp, sz, C.c_int32, C.c_int64, vp, sz, vp, sz,
+                                          C.POINTER(C.c_int64), vp]
     lib.msgs_voxel_pool_scratch_bytes.restype = sz
     lib.msgs_voxel_pool_scratch_bytes.argtypes = [C.c_int64]
     lib.msgs_voxel_pool_build.restype = C.c_int
@@ -166,7 +169,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_ssim_window", "msgs_preprocess_only", "msgs_knn_scratch_bytes",
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
-           "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views")
+           "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
+           "msgs_blend_lane_stats")
 
 
 def check(rc, where):

@@ -338,3 +338,42 @@ def test_kernel_variants_agree_on_random_shapes():
     finally:
         dgr._C.lib.msgs_set_backward_generation(prev_gen)
         dgr._C.lib.msgs_set_blend_granularity(prev_gran)
+
+
+def test_lane_stats_diagnostic_matches_the_oracle_pair_count():
+    """msgs_blend_lane_stats: the counting replica of the forward kernel blends exactly the (pixel, Gaussian) pairs the
+    oracle counts as valid, minus one terminating entry per saturated pixel; it writes nothing."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    W, H = 160, 128
+    sc, cam = small_scene(6000, W, H, 61)
+    bg = torch.zeros(3)
+    pc = SyntheticGaussians(sc, "cuda")
+    out = render(cam.to("cuda"), pc, PIPE, bg.cuda(), **ST0)
+    ctx = out["render"].grad_fn
+    geom, binning, image, D = ctx.state
+    before = out["render"].clone()
+    scratch = torch.empty(256, dtype=torch.uint8, device="cuda")
+    o3 = (C.c_int64 * 3)()
+    dgr._C.check(dgr._C.lib.msgs_blend_lane_stats(C.byref(ctx.call.view), C.c_void_p(geom.data_ptr()), geom.numel(), sc.P, int(D),
+                                                  C.c_void_p(binning.data_ptr()), binning.numel(),
+                                                  C.c_void_p(scratch.data_ptr()), scratch.numel(), o3,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lane stats")
+    steps, alive, blended = int(o3[0]), int(o3[1]), int(o3[2])
+    assert torch.equal(out["render"], before)
+    assert 0 < blended <= alive <= 64 * steps
+    from oracle import oracle_ctypes as oc
+    import copy
+    seen = copy.copy(sc)
+    with torch.no_grad():
+        seen.scales = pc.get_scaling.detach().cpu().contiguous()
+        seen.rotations = pc.get_rotation.detach().cpu().contiguous()
+        seen.opacities = pc.get_opacity.detach().cpu().contiguous()
+        seen.shs = pc.get_features.detach().cpu().contiguous()
+        seen.means3D = pc.get_xyz.detach().cpu().contiguous()
+    orc = oc.rasterize(seen, cam, ST0, bg)
+    # valid_pairs counts the terminating entry of a saturated pixel too; at most one per pixel
+    assert orc.valid_pairs - W * H <= blended <= orc.valid_pairs + 64
+    assert abs(blended - orc.valid_pairs) <= W * H
