@@ -7,9 +7,11 @@ Parity status:
     present in this image, and tests/test_epilogue_cpu.py checks this numpy restatement against torch.optim.Adam on
     CPU (exp_avg / exp_avg_sq bit-for-bit, parameters within 1 ulp: ATen's CPU sqrt is not correctly rounded), and the GPU tests additionally compare the HIP kernel with
     torch.optim.Adam running on the same GPU.
-  * training_stats: PARITY UNPINNED.  The reference's methods live in scene/gaussian_model.py, which cannot be
-    imported here (it imports simple_knn._C and open3d, both absent); the indexing semantics of
-    gaussian_model.py:663-704 and train.py:239-250 are restated with numpy masks.
+  * training_stats: PINNED.  tests/golden/stats_*.npz hold inputs and outputs of the reference's OWN
+    update_base_gaussian_mask / update_pixel_sizes / add_densification_stats (scene/gaussian_model.py:663-704, loaded by
+    file path in the build container with empty placeholders for the third-party modules its import block names:
+    tests/golden/make_stats_golden.py) plus train.py:249; tests/test_epilogue_cpu.py requires this numpy restatement to
+    reproduce them bit for bit (the accumulated gradient norm to one ulp: torch.norm vs sqrt(x*x + y*y)).
 """
 import numpy as np
 

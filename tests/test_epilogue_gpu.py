@@ -173,3 +173,31 @@ def test_epilogue_argument_errors():
     assert _C.lib.msgs_densify_stats(C.byref(d), None) == -1
     d.reso_lvl = 0
     assert _C.lib.msgs_densify_stats(C.byref(d), None) == -1          # NULL radii
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
+def test_training_stats_kernel_vs_reference_golden(case):
+    """msgs_densify_stats against the outputs of the REFERENCE's own statistics methods (tests/golden/stats_*.npz,
+    generated by make_stats_golden.py from /root/reference/scene/gaussian_model.py:663-704 + train.py:249): bit-exact."""
+    import os
+    import numpy as np
+    from train_epilogue import update_training_stats
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"stats_{case}.npz"))
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    m = types.SimpleNamespace(reso_lvls=int(z["reso_lvls"]), xyz_gradient_accum=t(z["in_xyz_gradient_accum"]),
+                              denom=t(z["in_denom"]), max_radii2D=t(z["in_max_radii2D"]),
+                              max_pixel_sizes=t(z["in_max_pixel_sizes"]), min_pixel_sizes=t(z["in_min_pixel_sizes"]),
+                              base_gaussian_mask=t(z["in_base_mask"]), target_reso_lvl=t(z["target_reso_lvl"]))
+    vsp = types.SimpleNamespace(grad=t(z["grad2d"]))
+    update_training_stats(m, vsp, t(z["radii"]), t(z["pixel_sizes"]), int(z["reso_lvl"]), base_mask=bool(z["do_base_mask"]),
+                          update_pixel_sizes=True, densify=True)
+    torch.cuda.synchronize()
+    for k, attr in (("xyz_gradient_accum", "xyz_gradient_accum"), ("denom", "denom"), ("max_radii2D", "max_radii2D"),
+                    ("max_pixel_sizes", "max_pixel_sizes"), ("min_pixel_sizes", "min_pixel_sizes"),
+                    ("base_mask", "base_gaussian_mask")):
+        got = getattr(m, attr).cpu().numpy()
+        if k == "xyz_gradient_accum":     # one ulp of the gradient norm on ~1e-4 of the entries (torch.norm's CPU kernel)
+            assert np.allclose(got, z["out_" + k], rtol=2e-7, atol=0) and (got != z["out_" + k]).mean() < 1e-3, f"{case}: {k}"
+        else:
+            assert np.array_equal(got, z["out_" + k]), f"{case}: {k}"
