@@ -106,5 +106,7 @@ for sub, name in (("pmc_sq", "pmc_sq.csv"), ("pmc_sq2", "pmc_sq2.csv")):
     if sub == "pmc_sq":       # machine-readable twin for bench.py's informational VALU field
         json.dump({"source": "rocprofv3 --pmc " + " ".join(names) + " -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing; mean per launch",
                    "csrc_sha256": csrc_sha256(),
-                   "kernels": {re.sub(r"<.*$", "", k): {c: a[k][c] / len(d[k]) for c in names} for k in order[:24]}},
+                   # template variants share a key: keep the one launched most often (the hot one)
+                   "kernels": {kk: vv for kk, vv in reversed([(re.sub(r"<.*$", "", k), {c: a[k][c] / len(d[k]) for c in names})
+                                                              for k in sorted(order[:24], key=lambda k: -len(d[k]))])}},
                   open(os.path.join(dst, "sq.json"), "w"), indent=1)
