@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profile of bench.py on the GPU box: kernel trace + stats, and the PMC passes (each in its own run, no trace
 # domains with --pmc).  Usage (through gpurun): bash tools/profile_round.sh <tag>   -> gpurun_out/prof_<tag>/summary/*.csv
-# Copy the summaries you want judged into profiles/.
+# Copy the summaries you want judged into profiles/ (rNN_kernel_stats.csv, rNN_pmc_*.csv, rNN_idle.txt) and summary/traffic.json,
+# summary/sq.json to profiles/traffic_rNN.json, profiles/sq_rNN.json: bench.py reads those two while their csrc hash matches.
 tag=${1:-x}
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
