@@ -275,8 +275,8 @@ def test_forward_capacity_guess_paths_give_identical_results():
 
 def test_blend_granularities_agree():
     """The fine-grained kernels (sixteen waves per tile, 4x4 sub-blocks) evaluate every pixel with the same arithmetic in
-    the same order as the quadrant-per-wave kernels: forward outputs bit-identical, gradients equal up to the order of
-    the float atomics.  Ragged image (W, H not multiples of 16 or 4), multi-scale filters on, non-zero background."""
+    the same order as the quadrant-per-wave kernels: forward outputs bit-identical, gradients equal up to the float32 partial sums the
+    waves form over their pixels (the cross-tile accumulation is exact).  Ragged image (W, H not multiples of 16 or 4), multi-scale filters on, non-zero background."""
     import diff_gaussian_rasterization as dgr
     W, H = 203, 117
     sc, cam = small_scene(6000, W, H, 57, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.2)
@@ -295,17 +295,25 @@ def test_blend_granularities_agree():
     for k in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
         assert torch.equal(a[k], b[k]), k
     assert a["render"].abs().max().item() > 0
+    from parity_utils import report
+    worst = {}
     for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
-        tol = 1e-3 if n in ("_scaling", "_rotation") else 3e-4      # float-atomic order (tests/test_deterministic_gpu.py)
-        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= tol, n
-    assert rel_err(mb, ma) <= 3e-4
+        worst[n] = rel_err(getattr(pb, n).grad, getattr(pa, n).grad)
+    worst["means2D"] = rel_err(mb, ma)
+    report("granularities", "worst gradient difference between the 8x8 and 4x4 kernels", max(worst.values()))
+    # the cross-tile accumulation is exact (double accumulators): what differs is the float32 partial sum a wave forms
+    # over its 64 resp. 16 pixels before it is added
+    # (measured 2e-6 .. 6e-6 on scaling / rotation, 4e-7 elsewhere; with float32 atomics this test needed 1e-3 / 3e-4)
+    for n, v in worst.items():
+        tol = 5e-5 if n in ("_scaling", "_rotation") else 1e-5
+        assert v <= tol, (n, worst)
 
 
 def test_kernel_variants_agree_on_random_shapes():
     """Differential stress of the blend kernel variants (quadrant-per-wave forward with the four-waves and one-wave
     backward, fine-grained forward + backward) over random image shapes, densities and footprint sizes, including
     images smaller than one tile / one 4x4 sub-block and footprints of many tiles: forward outputs bit-identical,
-    gradients equal up to float-atomic order."""
+    gradients equal up to the in-tile float32 partial sums (the cross-tile accumulation is exact)."""
     import random
     import diff_gaussian_rasterization as dgr
     rnd = random.Random(20261002)
@@ -313,6 +321,7 @@ def test_kernel_variants_agree_on_random_shapes():
     shapes += [(rnd.randint(20, 260), rnd.randint(20, 200)) for _ in range(6)]
     prev_gen = dgr._C.lib.msgs_set_backward_generation(0)
     prev_gran = dgr._C.lib.msgs_set_blend_granularity(0)
+    worst_all = {}
     try:
         for n, (W, H) in enumerate(shapes):
             P = rnd.choice([50, 800, 5000])
@@ -332,12 +341,15 @@ def test_kernel_variants_agree_on_random_shapes():
                 for key in ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes"):
                     assert torch.equal(a[key], b[key]), (key, W, H, P)
                 for nm in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
-                    tol = 2e-3 if nm in ("_scaling", "_rotation") else 5e-4
-                    assert rel_err(getattr(pb, nm).grad, getattr(pa, nm).grad) <= tol, (nm, W, H, P)
-                assert rel_err(mb, ma) <= 5e-4, (W, H, P)
+                    tol = 5e-5 if nm in ("_scaling", "_rotation") else 1e-5      # measured 5.4e-6 / 3.8e-7 (in-tile float32 sums only)
+                    e = rel_err(getattr(pb, nm).grad, getattr(pa, nm).grad)
+                    worst_all[nm] = max(worst_all.get(nm, 0.0), e)
+                    assert e <= tol, (nm, W, H, P)
+                assert rel_err(mb, ma) <= 1e-5, (W, H, P)
     finally:
         dgr._C.lib.msgs_set_backward_generation(prev_gen)
         dgr._C.lib.msgs_set_blend_granularity(prev_gran)
+    print("[parity] kernel variants, worst gradient difference per tensor:", {k: f"{v:.2e}" for k, v in worst_all.items()})
 
 
 def test_lane_stats_diagnostic_matches_the_oracle_pair_count():
