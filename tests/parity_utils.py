@@ -75,6 +75,13 @@ def report(name, what, value):
     print(f"[parity] {name}: {what} = {value:.3e}")
 
 
+def rel_err_reported(name, what, a, ref, rows=None):
+    """rel_err() that also prints / records the achieved value (pytest -s), so asserted tolerances can be read against it"""
+    e = rel_err(a, ref, rows)
+    report(name, what, e)
+    return e
+
+
 def check_forward(out, orc, name=""):
     ok = ~orc.borderline.bool()
     frac_bl = 1.0 - ok.float().mean().item()

@@ -121,4 +121,6 @@ def test_direct_gradient_sinks_with_odd_gaussian_count():
     for p, q, v in zip(pc.parameters(), ref.parameters(), b.views):
         assert p.grad.data_ptr() == v.data_ptr()
         scale = q.grad.abs().max().clamp_min(1e-30)
-        assert ((p.grad - q.grad).abs().max() / scale).item() <= 3e-4        # two float-atomic runs
+        err = ((p.grad - q.grad).abs().max() / scale).item()
+        print(f"[parity] direct sinks: {err:.3e}")
+        assert err == 0.0         # same kernels, reproducible sums: the sink receives exactly what autograd would

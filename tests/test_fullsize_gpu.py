@@ -16,6 +16,8 @@ per-Gaussian error relative to the Gaussian's own gradient <= 1e-4 (measured 8e-
 borderline alpha decision, whose achieved fraction every test prints."""
 TIGHT_RTOL = 1e-4
 LOOSE, LOOSE_DET = 2e-3, 5e-4
+LINEARITY_RTOL = {"_scaling": 1e-3, "_rotation": 3e-4}       # measured 2.5e-4 / 5.9e-5; the other tensors <= 1.5e-6
+LINEARITY_RTOL_DEFAULT = 1e-5
 FULL_Q99 = 1e-4
 FULL_TOL = {"scaling": LOOSE, "rotation": LOOSE}
 FULL_TOL_DET = {"scaling": LOOSE_DET, "rotation": LOOSE_DET}
@@ -25,7 +27,7 @@ import pytest
 import torch
 
 import scenes
-from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_err
+from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_err, rel_err_reported
 
 pytestmark = pytest.mark.gpu
 
@@ -178,12 +180,12 @@ def test_c3_backward_is_linear_in_dL(c3):
     _, p1, m1 = hip_render(sc, cam, st, bg, d1)
     _, p2, m2 = hip_render(sc, cam, st, bg, d2)
     _, p3, m3 = hip_render(sc, cam, st, bg, 2.0 * d1 - 0.5 * d2)
-    # three independent float-atomic runs are combined here; one run differs from its own repetition by 4e-5 on
-    # dL/dscale (atomic order + cancellation in the conic -> covariance chain), hence 5e-4 rather than 1e-4
+    # every run is reproducible, so what is left is float32 rounding inside one pixel's chain (linear up to rounding) and K8's
+    # amplification of it on dL/dscale, dL/drotation (the conic -> covariance cancellation, profiles/r2_parity_floor.md)
     for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
         want = 2.0 * getattr(p1, n).grad - 0.5 * getattr(p2, n).grad
-        assert rel_err(getattr(p3, n).grad, want) <= 5e-4, n
-    assert rel_err(m3, 2.0 * m1 - 0.5 * m2) <= 5e-4
+        assert rel_err_reported("C3 linearity", n, getattr(p3, n).grad, want) <= LINEARITY_RTOL.get(n, LINEARITY_RTOL_DEFAULT), n
+    assert rel_err_reported("C3 linearity", "means2D", m3, 2.0 * m1 - 0.5 * m2) <= LINEARITY_RTOL_DEFAULT
 
 
 def test_c3_multiscale_pyramid_levels(c3):

@@ -5,11 +5,17 @@ import pytest
 import torch
 
 import scenes
-from parity_utils import PIPE, check_forward, rel_err, small_scene
+from parity_utils import PIPE, check_forward, rel_err, rel_err_reported, small_scene
 
 pytestmark = pytest.mark.gpu
 
-HIP_VS_HIP_RTOL = 3e-4
+# render_fused evaluates exp / sigmoid / normalize inside the kernels; torch evaluates them 1 ulp differently, and K8 (conic ->
+# covariance -> scale, rotation) amplifies that: measured <= 4.5e-5 on scaling / rotation, <= 1.3e-6 elsewhere at the small
+# sizes.  At C3 a one-ulp radius change moves up to 2 Gaussians in or out of a tile, which changes every gradient that shares
+# their pixels: measured 1e-4 .. 5.3e-4 in max norm there.
+HIP_VS_HIP_RTOL = {"_scaling": 2e-4, "_rotation": 2e-4}
+HIP_VS_HIP_RTOL_DEFAULT = 5e-6
+C3_RTOL = 1e-3
 LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 
 
@@ -40,11 +46,8 @@ def test_fused_matches_reference_api_path(P, W, H, seed, deg, ms):
     assert (a["acc_pixel_size"] - b["acc_pixel_size"]).abs().max().item() <= 1e-4
     assert torch.allclose(a["pixel_sizes"], b["pixel_sizes"], rtol=1e-5, atol=1e-6)
     for n in LEAVES:
-        # two HIP runs, each carrying float-atomic summation noise that the scale / rotation chain amplifies to the
-        # 1e-4 level in the worst tensor (the same path run twice differs by up to 1.4e-4 there; the deterministic
-        # mode removes it: tests/test_deterministic_gpu.py) -> 3e-4 here, 1e-4 against the oracle elsewhere
-        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= HIP_VS_HIP_RTOL, n
-    assert rel_err(b["viewspace_points"].grad, a["viewspace_points"].grad) <= HIP_VS_HIP_RTOL
+        assert rel_err_reported(f"fused P={P}", n, getattr(pb, n).grad, getattr(pa, n).grad) <= HIP_VS_HIP_RTOL.get(n, HIP_VS_HIP_RTOL_DEFAULT), n
+    assert rel_err_reported(f"fused P={P}", "means2D", b["viewspace_points"].grad, a["viewspace_points"].grad) <= HIP_VS_HIP_RTOL_DEFAULT
     assert pb._features_rest.grad.shape == pb._features_rest.shape and pb._opacity.grad.shape == pb._opacity.shape
 
 
@@ -81,8 +84,8 @@ def test_fused_c3_fullsize_matches_reference_api_path():
     assert (a["radii"] != b["radii"]).sum().item() <= 2            # normalize() may differ from torch by 1 ulp
     frac_bad = ((a["render"] - b["render"]).abs() > 1e-5).float().mean().item()
     assert frac_bad < 1e-4
-    for n in LEAVES:                                               # float-atomic noise floor at this size
-        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= 1e-3, n
+    for n in LEAVES:
+        assert rel_err_reported("fused C3", n, getattr(pb, n).grad, getattr(pa, n).grad) <= C3_RTOL, n
 
 
 def test_fused_argument_errors():

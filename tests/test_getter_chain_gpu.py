@@ -4,11 +4,15 @@ import pytest
 import torch
 
 import scenes
-from parity_utils import PIPE, rel_err, small_scene
+from parity_utils import PIPE, rel_err, rel_err_reported, small_scene
 
 pytestmark = pytest.mark.gpu
 LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
-HIP_VS_HIP_RTOL = 3e-4          # two runs with float atomics (tests/test_fused_gpu.py)
+# The rasterizer's gradient sums are exact across tiles (double accumulators), so the chained and the plain path differ only
+# in the getter backward itself (sigmoid / normalize in the kernel vs in autograd): measured 0 on xyz / SH / scaling,
+# <= 2.3e-7 on opacity / rotation, at every size including C3.
+HIP_VS_HIP_RTOL = 2e-6
+C3_RTOL = 2e-6
 
 
 def _run(sc, cam, st, bg, dL, chain, pipe=PIPE):
@@ -45,8 +49,8 @@ def test_chained_equals_autograd_through_the_getters(P, W, H, seed, deg, ms):
     for n in LEAVES:
         ga, gb = getattr(pa, n).grad, getattr(pb, n).grad
         assert gb.shape == ga.shape and gb.is_contiguous()
-        assert rel_err(gb, ga) <= HIP_VS_HIP_RTOL, n
-    assert rel_err(b["viewspace_points"].grad, a["viewspace_points"].grad) <= HIP_VS_HIP_RTOL
+        assert rel_err_reported(f"chain P={P}", n, gb, ga) <= HIP_VS_HIP_RTOL, n
+    assert rel_err_reported(f"chain P={P}", "means2D", b["viewspace_points"].grad, a["viewspace_points"].grad) <= HIP_VS_HIP_RTOL
 
 
 def test_patterns_that_must_not_be_chained_take_the_plain_path():
@@ -85,7 +89,7 @@ def test_c3_fullsize_chained_vs_plain():
     assert ub == "_RasterizeGaussiansChainedBackward"
     assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
     for n in LEAVES:
-        assert rel_err(getattr(pb, n).grad, getattr(pa, n).grad) <= 1e-3, n      # float-atomic noise floor at this size
+        assert rel_err_reported("chain C3", n, getattr(pb, n).grad, getattr(pa, n).grad) <= C3_RTOL, n
 
 
 def test_gradient_sinks_deliver_into_the_exchange_bucket():
@@ -116,7 +120,8 @@ def test_gradient_sinks_deliver_into_the_exchange_bucket():
         assert not dgr._grad_sinks
         for n in LEAVES:
             got, want = getattr(pc, n).grad, getattr(ref, n).grad / 2
-            assert rel_err(got, want) <= HIP_VS_HIP_RTOL, (fn.__name__, n)
+            # render_fused evaluates the activations in the kernels, 1 ulp from torch's (tests/test_fused_gpu.py)
+            assert rel_err(got, want) <= (2e-4 if fn is render_fused else HIP_VS_HIP_RTOL), (fn.__name__, n)
     # the plain path cannot deliver into the bucket: loud failure instead of silently missing gradients
     pc = SyntheticGaussians(sc, "cuda")
     ex = PipelinedGradExchange(pc.parameters(), world=2, direct=True)

@@ -128,7 +128,9 @@ def test_python_side_cov_and_colors():
         # the Python-side activations differentiate through torch: end-to-end grads must agree with the
         # in-op path up to float32 rounding of two different formula orderings
         for n in ("_xyz", "_opacity", "_scaling", "_rotation", "_features_dc", "_features_rest"):
-            assert rel_err(getattr(pc, n).grad, getattr(ref_pc, n).grad) <= 5e-4, n
+            e = rel_err(getattr(pc, n).grad, getattr(ref_pc, n).grad)
+            print(f"[parity] python-side cov/colors {n}: {e:.3e}")
+            assert e <= (1e-4 if n in ("_scaling", "_rotation") else 5e-6), n     # measured 2.2e-5 / 3e-6 / <= 5.2e-7
 
 
 def test_precomputed_inputs_vs_oracle():

@@ -66,13 +66,17 @@ def test_first_iteration_matches_the_reference_composition():
     for k in ("max_pixel_sizes", "min_pixel_sizes"):       # pixel sizes: in-kernel expf vs torch.exp, 1 ulp apart
         assert torch.allclose(getattr(a, k), getattr(b, k), rtol=1e-5, atol=0), k
     ref = b.xyz_gradient_accum
-    assert (a.xyz_gradient_accum - ref).abs().max().item() <= 3e-4 * ref.abs().max().item()
+    e = (a.xyz_gradient_accum - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[parity] train step xyz_gradient_accum: {e:.3e}")
+    assert e <= 5e-6                 # measured 4.1e-7
     # first Adam step = -lr * g / (|g| + eps): +-lr wherever the gradient is not ~0.  Compare the moments (linear in
     # the gradient) for every Gaussian, and the parameters where the gradient is well above the float-atomic noise.
     for (n, ga_, gb_) in zip(a.LEAVES, ga, gb):
         p, q = ga_["params"][0], gb_["params"][0]
         ma, mb = oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]
-        assert (ma - mb).abs().max().item() <= 3e-4 * mb.abs().max().item(), n      # two HIP runs: float-atomic noise twice
+        e = (ma - mb).abs().max().item() / mb.abs().max().item()
+        print(f"[parity] train step exp_avg {n}: {e:.3e}")
+        assert e <= (5e-5 if n in ("_scaling", "_rotation") else 5e-6), n      # measured 4.5e-6 / 2.3e-6 / <= 4.1e-7
         sure = mb.abs() > 1e-3 * mb.abs().max()
         assert sure.any()
         step_a, step_b = (p - before[n])[sure], (q - before[n])[sure]
