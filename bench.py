@@ -37,6 +37,10 @@ for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd",
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the hosts of this pool only support dmabuf IPC: without this RCCL's buffer exchange between the ranks fails in
+# hipIpcGetMemHandle (already exported on the driver's boxes; kept here for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
