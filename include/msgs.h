@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 4
+#define MSGS_ABI_VERSION 5
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -127,6 +127,9 @@ typedef struct msgs_grads {
     void* factors_ready;       /* optional hipEvent_t, factored SH gradient only: dL_dcolors is written by a kernel of its
                                 * own BEFORE the per-Gaussian backward and this event is recorded right behind it, so that
                                 * the caller can start the all-gather of the factors while the rest of msgs_backward runs */
+    int32_t scratch_is_clear;  /* non-zero: the first msgs_backward_scratch_bytes(P) bytes of `scratch` were handed to the
+                                * forward of THIS view as grad_records (it cleared them during the blend) and nothing has
+                                * written them since: msgs_backward skips its own fill launch.  0: msgs_backward clears them */
 } msgs_grads_t;
 
 /* Optional per-kernel timing (bench.py's roofline leg).  The caller owns the events; the library
@@ -179,7 +182,12 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g,
                         void* scratch, size_t scratch_bytes,
                         void* image_state, size_t image_bytes,
                         float* out_color, float* out_acc_pixel_size, float* out_depth,
+                        void* grad_records, size_t grad_records_bytes,
                         const msgs_timing_t* timing, void* stream);
+/* grad_records (optional, NULL = none): the buffer the caller will pass to msgs_backward as `scratch`
+ * (>= msgs_backward_scratch_bytes(P)).  The per-Gaussian gradient records in it have to start from zero; the blend
+ * kernel of the forward clears them on the side (it is instruction-bound, the stores are free there), and a
+ * msgs_backward called with msgs_grads_t.scratch_is_clear = 1 saves the fill launch. */
 
 /* ---- backward -------------------------------------------------------------------------------- */
 /* dL_dcolor is [3,H,W].  acc_pixel_size / depth / pixel_sizes carry no gradient (they never
@@ -266,8 +274,9 @@ int msgs_set_blend_granularity(int32_t mode);
 int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int32_t* radii, float* pixel_sizes,
                  void* geom, size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning,
                  size_t binning_bytes, void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes,
-                 float* out_color, float* out_acc_pixel_size, float* out_depth, int64_t* num_instances_host,
-                 int32_t* stage2_done, const msgs_timing_t* timing, void* stream);
+                 float* out_color, float* out_acc_pixel_size, float* out_depth, void* grad_records,
+                 size_t grad_records_bytes, int64_t* num_instances_host, int32_t* stage2_done,
+                 const msgs_timing_t* timing, void* stream);
 
 /* msgs_preprocess_only: the per-Gaussian stage alone (frustum cull, multi-scale filters, projection) — radii and
  * pixel_sizes exactly as msgs_forward_stage1 writes them, without sorting, binning or blending.  For the camera

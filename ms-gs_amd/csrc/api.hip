@@ -216,8 +216,8 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
 int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes, void* geom,
                  size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
                  void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
-                 float* out_acc_ps, float* out_depth, int64_t* num_instances_host, int32_t* stage2_done,
-                 const msgs_timing_t* timing, void* stream) {
+                 float* out_acc_ps, float* out_depth, void* grad_records, size_t grad_records_bytes,
+                 int64_t* num_instances_host, int32_t* stage2_done, const msgs_timing_t* timing, void* stream) {
     if (!stage2_done) return MSGS_ERR_INVALID_ARG;
     *stage2_done = 0;
     int rc = msgs_forward_stage1(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes,
@@ -228,7 +228,8 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
     if (!binning || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_OK;
     if (D > 0 && (!scratch2 || scratch2_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_OK;
     rc = msgs_forward_stage2(view, g, geom, geom_bytes, D, binning, binning_bytes, scratch2, scratch2_bytes, image,
-                             image_bytes, out_color, out_acc_ps, out_depth, timing, stream);
+                             image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, timing,
+                             stream);
     if (rc) return rc;
     *stage2_done = 1;
     return MSGS_OK;
@@ -250,7 +251,7 @@ int msgs_preprocess_only(const msgs_view_t* view, const msgs_gaussians_t* g, int
 int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes,
                         int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
                         void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
-                        const msgs_timing_t* timing, void* stream) {
+                        void* grad_records, size_t grad_records_bytes, const msgs_timing_t* timing, void* stream) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (D < 0 || D > 0xFFFFFFFFll) return MSGS_ERR_TOO_MANY;
@@ -259,6 +260,7 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
     if (P > 0 && (!geom_v || geom_bytes < msgs_geom_bytes(P))) return MSGS_ERR_CAPACITY;
     if (binning_bytes < msgs_binning_bytes(D, W, H) || image_bytes < msgs_image_bytes(W, H)) return MSGS_ERR_CAPACITY;
     if (D > 0 && (!scratch_v || scratch_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_ERR_CAPACITY;
+    if (grad_records && grad_records_bytes < msgs_backward_scratch_bytes(P)) return MSGS_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
     const char* geom = (const char*)geom_v;
     char* binning = (char*)binning_v;
@@ -299,7 +301,8 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
 
     tm.begin(MSGS_K_BLEND_FWD);
     HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth,
-                                 (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib), s));
+                                 (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib),
+                                 grad_records, grad_records ? GRAD_REC_BYTES * (size_t)P : 0, s));
     tm.end(MSGS_K_BLEND_FWD);
     return debug_sync(view, s);
 }
@@ -333,7 +336,8 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     const Timer tm{timing, s};
     grad_acc_t* grad_rec = (grad_acc_t*)scratch_v;
 
-    HIP_TRY(launch_zero(grad_rec, GRAD_REC_BYTES * (size_t)P, s));
+    if (!grads->scratch_is_clear)           // (else: cleared by the blend kernel of this view's forward, msgs.h)
+        HIP_TRY(launch_zero(grad_rec, GRAD_REC_BYTES * (size_t)P, s));
     tm.begin(MSGS_K_BLEND_BWD);
     if (det)      // grad_rec is the first region of the deterministic scratch layout
         HIP_TRY(launch_blend_backward_det(vp, P, geom, (const uint32_t*)(binning + BL.ids), D,

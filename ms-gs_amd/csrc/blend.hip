@@ -86,6 +86,19 @@ __device__ __forceinline__ int swizzled_tile(int bid, int num_tiles) {
     return (bid & 7) * per + (bid >> 3);
 }
 
+// Side job of the forward blend kernels: clear the backward's per-Gaussian gradient records (msgs.h, grad_records).  They
+// have to start from zero; done here the 80 bytes per Gaussian cost nothing — the kernels are instruction-issue bound with
+// the memory pipe mostly idle, the stores are fire-and-forget and nothing in this kernel reads them — and the backward saves a
+// fill launch.  Workgroup b clears slice b of the buffer (n16 sixteen-byte words in total).
+constexpr int CLEAR_INLINE_MIN_TILES = 2048;
+__device__ __forceinline__ void clear_slice(uint4* __restrict__ p, size_t n16) {
+    if (p == nullptr) return;
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x;
+    const size_t hi = lo + per < n16 ? lo + per : n16;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Per-pixel forward state and the walk over one wave's compacted entry list — shared by the quadrant-per-wave kernel
 // and the fine-grained (4x4 sub-block per wave) kernel, so that both evaluate every pixel with the same instructions in
 // the same order (bit-identical images, test_blend_granularities_agree).
@@ -176,10 +189,12 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
-                                                            unsigned long long* __restrict__ lane_stats) {
+                                                            unsigned long long* __restrict__ lane_stats,
+                                                            uint4* __restrict__ clear_ptr, size_t clear_n16) {
     __shared__ float4 s_r0[BATCH], s_r1[BATCH], s_r2[BATCH];
     __shared__ uint32_t s_mask[BATCH];
     __shared__ uint16_t s_list[4][BATCH];
+    clear_slice(clear_ptr, clear_n16);
 
     const int num_tiles = vp.gx * vp.gy;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -250,10 +265,12 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
                                                             float* __restrict__ out_ps,
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ final_T,
-                                                            uint32_t* __restrict__ n_contrib) {
+                                                            uint32_t* __restrict__ n_contrib,
+                                                            uint4* __restrict__ clear_ptr, size_t clear_n16) {
     __shared__ float4 s_r0[BATCH], s_r1[BATCH], s_r2[BATCH];
     __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
     __shared__ uint16_t s_list[16][BATCH];
+    clear_slice(clear_ptr, clear_n16);
 
     const int num_tiles = vp.gx * vp.gy;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -659,8 +676,10 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
                                                                 float* __restrict__ out_ps,
                                                                 float* __restrict__ out_depth,
                                                                 float* __restrict__ final_T,
-                                                                uint32_t* __restrict__ n_contrib) {
+                                                                uint32_t* __restrict__ n_contrib,
+                                                                uint4* __restrict__ clear_ptr, size_t clear_n16) {
     __shared__ float4 s_r0[WB], s_r1[WB], s_r2[WB];
+    clear_slice(clear_ptr, clear_n16);
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -978,20 +997,31 @@ static bool bwd_v1(int tiles) {
 
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                uint32_t* n_contrib, hipStream_t s) {
+                                uint32_t* n_contrib, void* clear_ptr, size_t clear_bytes, hipStream_t s) {
     const int tiles = vp.gx * vp.gy;
-    if (tiles == 0) return hipSuccess;
+    if (tiles == 0) return clear_ptr && clear_bytes ? launch_zero(clear_ptr, clear_bytes, s) : hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
     static const int fwd_gen = env_gen("MSGS_FWD_GEN", 1);
+    // the gradient records are cleared by the blend kernel itself when it has enough workgroups to spread the stores over the
+    // chip; with few tiles (low pyramid levels: 2 .. 500 workgroups, measured 150 -> 410 us at 2 tiles for 80 MB) a fill
+    // kernel in front of it is faster
+    static_assert(GRAD_REC_BYTES % 16 == 0, "the forward clears the gradient records in 16-byte words");
+    const bool inline_clear = clear_ptr && clear_bytes && tiles >= CLEAR_INLINE_MIN_TILES;
+    if (clear_ptr && clear_bytes && !inline_clear) {
+        hipError_t e = launch_zero(clear_ptr, clear_bytes, s);
+        if (e != hipSuccess) return e;
+    }
+    uint4* const cp = inline_clear ? reinterpret_cast<uint4*>(clear_ptr) : nullptr;
+    const size_t cn = inline_clear ? clear_bytes / 16 : 0;
     if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
         hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib);
+                           out_depth, final_T, n_contrib, cp, cn);
     else if (fwd_gen == 1)
         hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr);
+                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn);
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
-                           out_ps, out_depth, final_T, n_contrib);
+                           out_ps, out_depth, final_T, n_contrib, cp, cn);
     return hipGetLastError();
 }
 
@@ -1092,7 +1122,7 @@ hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const
     if (tiles)
         hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, reinterpret_cast<const GaussRec*>(geom),
                            ids, ranges, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (uint32_t*)nullptr, out3);
+                           (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0);
     return hipGetLastError();
 }
 

@@ -380,7 +380,7 @@ hipError_t voxel_pool_average(const float* features, int F, const uint32_t* orde
 // blend.hip
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                uint32_t* n_contrib, hipStream_t s);
+                                uint32_t* n_contrib, void* clear_ptr, size_t clear_bytes, hipStream_t s);
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  grad_acc_t* grad_rec, hipStream_t s);

@@ -211,6 +211,27 @@ def _backward_scratch(P, D, dev):
     return _bytes(lib.msgs_backward_scratch_bytes(P), dev)
 
 
+def _alloc_grad_records(ctx, P, dev):
+    """The backward's per-Gaussian gradient records have to start from zero.  When a backward can follow, the buffer is
+    allocated HERE and handed to the forward, whose blend kernel clears it on the side (include/msgs.h, grad_records: the
+    kernel is instruction-bound, the stores are free) — the backward then skips its fill launch.  Not in the verification
+    mode, whose scratch is sized by the instance count."""
+    ctx.grad_rec = None
+    if P > 0 and any(ctx.needs_input_grad) and not _C.lib.msgs_get_deterministic():
+        ctx.grad_rec = _bytes(_C.lib.msgs_backward_scratch_bytes(P), dev)
+    return ctx.grad_rec
+
+
+def _take_backward_scratch(ctx, P, D, dev):
+    """(scratch, is_clear): the buffer the forward cleared, once; any later backward through the same graph
+    (retain_graph) gets a fresh one that msgs_backward clears itself"""
+    rec = getattr(ctx, "grad_rec", None)
+    ctx.grad_rec = None
+    if rec is not None and not _C.lib.msgs_get_deterministic():
+        return rec, 1
+    return _backward_scratch(P, D, dev), 0
+
+
 def set_deterministic(on=True):
     """Process-wide switch: bitwise-reproducible backward (no float atomics; ~0.4 ms slower at 1M Gaussians / 1080p).
     Returns the previous setting.  The forward is always reproducible.  Also: MSGS_DETERMINISTIC=1 in the environment."""
@@ -222,7 +243,7 @@ def set_deterministic(on=True):
 _last_instances = {}
 
 
-def _forward_impl(call):
+def _forward_impl(call, grad_rec=None):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
     key = (dev.index, P, W, H)
@@ -248,6 +269,7 @@ def _forward_impl(call):
                                   _ptr(binning), binning.numel() if binning is not None else 0,
                                   _ptr(scratch2), scratch2.numel() if scratch2 is not None else 0,
                                   _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                  _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
         # views of one scene differ in D: remember a slowly decaying maximum rather than the last value
@@ -259,6 +281,7 @@ def _forward_impl(call):
             _C.check(lib.msgs_forward_stage2(C.byref(call.view), C.byref(call.g), _ptr(geom), geom.numel(), D,
                                              _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
                                              _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                             _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
                                              _C.timer_ptr(), stream), "msgs_forward_stage2")
     return color, acc_ps, depth, radii, pixel_sizes, (geom, binning, image, D)
 
@@ -289,7 +312,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         call = _Call(raster_settings, means3D, _opt(sh), _opt(colors_precomp), opacities, _opt(scales),
                      _opt(rotations), _opt(cov3Ds_precomp), _opt(max_pixel_sizes), _opt(min_pixel_sizes),
                      _opt(occ_multiplier), _opt(dc_delta), _opt(base_mask))
-        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device))
         ctx.call = call
         ctx.state = state
         ctx.radii = radii
@@ -321,9 +344,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_scales = torch.empty(P, 3, dtype=torch.float32, device=dev) if call.scales is not None else None
             g_rot = torch.empty(P, 4, dtype=torch.float32, device=dev) if call.rot is not None else None
             g_cov = torch.empty(P, 6, dtype=torch.float32, device=dev) if call.cov is not None else None
-            scratch = _backward_scratch(P, D, dev)
+            scratch, is_clear = _take_backward_scratch(ctx, P, D, dev)
             grads = _C.Grads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
-                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, None, None)
+                             _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, None, None, is_clear)
             _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
@@ -411,7 +434,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         call = _Call(raster_settings, xyz, None, None, opacity_raw, scaling_raw, rotation_raw, None,
                      _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
                      _opt(base_mask), raw_features=(features_dc, features_rest))
-        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device))
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
         _snapshot_sinks(ctx, (xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw))
@@ -443,10 +466,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             if factor is None:
                 g_dc, g_rest = _grad_out(kdc, dc_shape, dev), _grad_out(krest, rest_shape, dev)
             g_opac, g_scal, g_rot = _grad_out(kop, op_shape, dev), _grad_out(ksc, (P, 3), dev), _grad_out(krot, (P, 4), dev)
-            scratch = _backward_scratch(P, D, dev)
+            scratch, is_clear = _take_backward_scratch(ctx, P, D, dev)
             grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, _ptr(factor), _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
                              _ptr(g_dc), _ptr(g_rest),
-                             C.c_void_p(ready.cuda_event) if (factor is not None and ready is not None) else None)
+                             C.c_void_p(ready.cuda_event) if (factor is not None and ready is not None) else None,
+                             is_clear)
             _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
@@ -468,7 +492,7 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
         call = _Call(raster_settings, xyz, _opt(shs), None, opacities, scales, rotations, None,
                      _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
                      _opt(base_mask), raw_features=(features_dc, features_rest), rotations_raw=rotation_raw)
-        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call)
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device))
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
         _snapshot_sinks(ctx, (xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw))

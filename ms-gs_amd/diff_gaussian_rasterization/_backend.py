@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -46,7 +46,8 @@ class Grads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p)]
+                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p),
+                ("scratch_is_clear", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -104,12 +105,12 @@ def _load():
     lib.msgs_set_blend_granularity.argtypes = [C.c_int32]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
-                                 vp, vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
+                                 vp, vp, vp, vp, sz, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
     lib.msgs_preprocess_only.restype = C.c_int
     lib.msgs_preprocess_only.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp]
     lib.msgs_forward_stage2.restype = C.c_int
     lib.msgs_forward_stage2.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, sz, C.c_int64, vp, sz, vp, sz,
-                                        vp, sz, vp, vp, vp, C.POINTER(Timing), vp]
+                                        vp, sz, vp, vp, vp, vp, sz, C.POINTER(Timing), vp]
     lib.msgs_backward.restype = C.c_int
     lib.msgs_backward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, sz, C.c_int64, vp, sz, vp, sz,
                                   vp, vp, sz, C.POINTER(Grads), C.POINTER(Timing), vp]

@@ -41,7 +41,8 @@ class Grads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p)]
+                ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p),
+                ("scratch_is_clear", C.c_int32)]
 
 
 def build(force=False):

@@ -124,3 +124,73 @@ def test_direct_gradient_sinks_with_odd_gaussian_count():
         err = ((p.grad - q.grad).abs().max() / scale).item()
         print(f"[parity] direct sinks: {err:.3e}")
         assert err == 0.0         # same kernels, reproducible sums: the sink receives exactly what autograd would
+
+
+@pytest.mark.parametrize("P,W,H,granularity", [(1003, 96, 64, 0), (1, 640, 480, 0), (2500, 80, 48, 2), (7, 16, 16, 0)])
+def test_gradient_records_cleared_by_the_forward(P, W, H, granularity):
+    """msgs.h grad_records: the forward's blend kernel clears the backward's per-Gaussian gradient records.  The buffer is
+    poisoned beforehand (the caching allocator hands the freed block back), the first backward runs on the buffer the
+    forward cleared, the second one (retain_graph) on a fresh buffer msgs_backward clears itself: identical bits, and both
+    equal to a run without any pre-clearing (no_grad forward cannot be used for that, so: a poisoned second forward)."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import PIPE, render
+    from synthetic_model import SyntheticGaussians
+    sc, cam = small_scene(P, W, H, 21)
+    st = dict(filter_small=False, filter_large=False, fade_size=1.0)
+    dL = scenes.grad_seed(W, H, 21).cuda()
+    bg = torch.zeros(3, device="cuda")
+    nbytes = dgr._C.lib.msgs_backward_scratch_bytes(P)
+    prev = dgr._C.lib.msgs_set_blend_granularity(granularity)
+    try:
+        grads = []
+        for rep in range(2):
+            poison = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda")      # NaN patterns in every record
+            ptr = poison.data_ptr()
+            del poison
+            pc = SyntheticGaussians(sc, "cuda")
+            out = render(cam.to("cuda"), pc, PIPE, bg, **st)
+            ctx = out["render"].grad_fn
+            assert ctx.grad_rec is not None and ctx.grad_rec.numel() == nbytes
+            reused = ctx.grad_rec.data_ptr() == ptr
+            out["render"].backward(dL, retain_graph=True)
+            assert ctx.grad_rec is None                              # handed over once
+            first = [p.grad.clone() for p in pc.parameters()]
+            for p in pc.parameters():
+                p.grad = None
+            out["render"].backward(dL)                               # fresh scratch, cleared by msgs_backward
+            second = [p.grad.clone() for p in pc.parameters()]
+            for a, b in zip(first, second):
+                assert torch.isfinite(a).all() and torch.equal(a, b)
+            grads.append(first)
+            print(f"[parity] grad_records P={P}: poisoned block reused by the forward: {reused}")
+        for a, b in zip(*grads):
+            assert torch.equal(a, b)
+        # no backward can follow: nothing is allocated or cleared
+        with torch.no_grad():
+            pc = SyntheticGaussians(sc, "cuda")
+            out = render(cam.to("cuda"), pc, PIPE, bg, **st)
+            assert out["render"].grad_fn is None
+    finally:
+        dgr._C.lib.msgs_set_blend_granularity(prev)
+
+
+@pytest.mark.parametrize("P,W,H", [(500, 64, 48), (333, 1024, 768), (3, 1920, 1080)])
+def test_gradient_records_are_zero_after_the_forward_and_capacity_is_checked(P, W, H):
+    """both clearing routes (a fill launch below 2048 tiles, the blend kernel's own stores above) leave every byte of the
+    records zero, and only those bytes are written"""
+    import diff_gaussian_rasterization as dgr
+    kw, cam = _inputs(P, W, H)
+    call = dgr._Call(_settings(cam, torch.zeros(3, device="cuda")), kw["means3D"], kw["shs"], None, kw["opacities"],
+                     kw["scales"], kw["rotations"], None, kw["max_pixel_sizes"], kw["min_pixel_sizes"], None, None, None)
+    nbytes = dgr._C.lib.msgs_backward_scratch_bytes(P)
+    assert nbytes >= 80 * P
+    buf = torch.full((nbytes + 256,), 0xFF, dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                           # first frame (two library calls) and steady state (one)
+        buf.fill_(0xFF)
+        dgr._forward_impl(call, buf[:nbytes])
+        torch.cuda.synchronize()
+        assert int(buf[:80 * P].max()) == 0
+        assert int(buf[nbytes:].min()) == 0xFF                   # nothing behind the buffer was touched
+    small = torch.empty(64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="smaller"):
+        dgr._forward_impl(call, small)
