@@ -112,8 +112,30 @@ struct FwdPix {
 // COUNT (diagnostic replica, msgs_blend_lane_stats): also counts, per wave, the entry evaluations (x 64 = evaluated lanes), the
 // lanes still blending at each of them and the lanes that blended — scalar popcounts, no effect on the arithmetic.
 struct LaneStats { uint32_t steps, alive, blended; };
+// Entry lists of the forward kernels: BYTE offsets of the 16-byte records, four bytes each so that ONE 16-byte LDS read
+// fetches four of them, and padded to a multiple of four with the offset of a SENTINEL record (slot BATCH of the record
+// arrays: zero conic, log2-opacity -1e30 -> alpha = exp2(-1e30) = 0 < 1/255, never valid, every product with it is an exact
+// zero).  The walk then takes four entries per trip with one list read, one "any pixel left?" test and one counter update for
+// the four — 36 instead of 45 instructions per entry; a padded or post-termination evaluation changes no pixel.
+// Measured at C3 (blend_forward_kernel incl. the clearing of the gradient records): two entries per trip 187 us; four per trip
+// 216 us when the compiler is free to hoist all thirteen LDS reads of a trip (97 VGPRs -> 4 waves per SIMD) and 182 us
+// when it is held to 64 VGPRs / 8 waves per SIMD (amdgpu_waves_per_eu below): issue-bound code wants the waves, not the
+// hoisting.  (Folding the two selects of the update into one — alpha_b = blend ? alpha : 0, T = fma(-T, alpha_b, T) —
+// measured the same time and was not kept.)
+constexpr int LIST_PAD = 4;
+constexpr uint32_t SENTINEL_OFF = (uint32_t)BATCH << 4;
+__device__ __forceinline__ void write_sentinel_record(float4* s_r0, float4* s_r1, float4* s_r2) {
+    s_r0[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_r1[BATCH] = make_float4(0.f, -1.0e30f, 0.f, 0.f);
+    s_r2[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// after the compaction: lanes 0..2 of the wave pad its list (cnt entries) up to the next multiple of four
+__device__ __forceinline__ void pad_list(uint32_t* lp, int cnt, int lane) {
+    if (lane < LIST_PAD - 1) lp[cnt + lane] = SENTINEL_OFF;
+}
+
 template <bool COUNT = false>
-__device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
+__device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
                                                  const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io,
                                                  LaneStats* stats = nullptr) {
     // the state lives in LOCAL scalars while the list is walked (through the struct reference the compiler turned the
@@ -137,7 +159,9 @@ __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, co
         const uint64_t validm = alive & m_pow & m_alpha;
         const uint64_t stopm = validm & m_stop;
         if (COUNT) {
-            stats->steps += 1u; stats->alive += (uint32_t)__popcll(alive); stats->blended += (uint32_t)__popcll(validm & ~stopm);
+            if (__builtin_amdgcn_readfirstlane(off) != SENTINEL_OFF) {
+                stats->steps += 1u; stats->alive += (uint32_t)__popcll(alive); stats->blended += (uint32_t)__popcll(validm & ~stopm);
+            }
         }
         alive &= ~stopm;                                                            // terminated: NOT blended (Q7)
         const bool blend = __builtin_amdgcn_inverse_ballot_w64(validm & ~stopm);
@@ -147,15 +171,11 @@ __device__ __forceinline__ uint32_t forward_walk(const uint16_t* lp, int cnt, co
         T = blend ? test_T : T;
         last_off = blend ? off : last_off;
     };
-    int j = 0;
-    for (; j + 1 < cnt; j += 2) {                         // two entries per trip: one list-pointer update for both
+    for (int j = 0; j < cnt; j += LIST_PAD) {              // the list is padded to a multiple of four
         if (alive == 0) break;
-        const uint32_t o0 = lp[j], o1 = lp[j + 1];
-        blend_entry(o0);
-        if (alive == 0) break;
-        blend_entry(o1);
+        const uint4 o = *reinterpret_cast<const uint4*>(lp + j);
+        blend_entry(o.x); blend_entry(o.y); blend_entry(o.z); blend_entry(o.w);
     }
-    if (j < cnt && j + 1 >= cnt && alive != 0) blend_entry(lp[j]);
     st.T = T; st.C0 = C0; st.C1 = C1; st.C2 = C2; st.aps = aps; st.adp = adp;
     alive_io = alive;
     return last_off;
@@ -181,7 +201,7 @@ __device__ __forceinline__ void forward_store(const FwdPix& st, uint32_t last, b
 // K6
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
                                                             float* __restrict__ out_color,
@@ -191,10 +211,11 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
                                                             uint32_t* __restrict__ n_contrib,
                                                             unsigned long long* __restrict__ lane_stats,
                                                             uint4* __restrict__ clear_ptr, size_t clear_n16) {
-    __shared__ float4 s_r0[BATCH], s_r1[BATCH], s_r2[BATCH];
+    __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ uint32_t s_mask[BATCH];
-    __shared__ uint16_t s_list[4][BATCH];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
+    if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
 
     const int num_tiles = vp.gx * vp.gy;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -235,9 +256,10 @@ __global__ __launch_bounds__(256) void blend_forward_kernel(ViewParams vp, const
             const int e = c * 64 + lane;
             const bool hit = e < n && ((s_mask[e] >> w) & 1u);
             const uint64_t b = __ballot(hit);
-            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
+            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint32_t)(e << 4);
             cnt += __popcll(b);
         }
+        pad_list(s_list[w], cnt, lane);
         const uint32_t last_off = forward_walk<COUNT>(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, &ls);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
@@ -267,10 +289,11 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
                                                             uint4* __restrict__ clear_ptr, size_t clear_n16) {
-    __shared__ float4 s_r0[BATCH], s_r1[BATCH], s_r2[BATCH];
+    __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
-    __shared__ uint16_t s_list[16][BATCH];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[16][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
+    if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
 
     const int num_tiles = vp.gx * vp.gy;
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -328,9 +351,10 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
             const int e = c * 64 + lane;
             const bool hit = e < n && ((s_mask[w >> 2][e] >> (w & 3)) & 1u);
             const uint64_t b = __ballot(hit);
-            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint16_t)(e << 4);
+            if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint32_t)(e << 4);
             cnt += __popcll(b);
         }
+        pad_list(s_list[w], cnt, lane);
         const uint32_t last_off = forward_walk(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
