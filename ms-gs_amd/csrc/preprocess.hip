@@ -198,12 +198,13 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 constexpr int ROW_F = 48;          // floats per SH row in HBM (K = 16)
 constexpr int ROW_LDS = 49;        // floats per row in LDS
+constexpr int K9_STAGE_ROWS = 32;  // Gaussians of a wave whose SH rows are in LDS at a time (preprocess_backward_kernel)
 
 __device__ __forceinline__ int sh_row_float4s(int deg) { return deg == 0 ? 1 : deg == 1 ? 3 : deg == 2 ? 7 : 12; }
 
-// rows listed in idx[0..nrow) (lane numbers inside the wave) are loaded from g_rows + lane*48
+// rows listed in idx[0..nrow) (lane numbers inside the wave) are loaded from g_rows + lane*48 into LDS row (lane - row0)
 __device__ __forceinline__ void coop_load_rows(float* lds_rows, const float* g_rows, const uint8_t* idx, int nrow,
-                                               int n4, int lane) {
+                                               int n4, int lane, int row0 = 0) {
     const int rpi = 64 / n4;
     const int sub = lane / n4, c = lane - sub * n4;
     for (int it = 0; it * rpi < nrow; ++it) {
@@ -211,7 +212,7 @@ __device__ __forceinline__ void coop_load_rows(float* lds_rows, const float* g_r
         if (sub < rpi && slot < nrow) {
             const int sl = idx[slot];
             const float4 v = *reinterpret_cast<const float4*>(g_rows + (size_t)sl * ROW_F + 4 * c);
-            float* d = lds_rows + sl * ROW_LDS + 4 * c;
+            float* d = lds_rows + (sl - row0) * ROW_LDS + 4 * c;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     }
@@ -289,11 +290,13 @@ __device__ __forceinline__ float act_rotation(const msgs_gaussians_t& g, int i, 
 // SH rows of one wave from the split dc / rest parameters into LDS rows [dc(3) | rest(45)] (= the torch.cat of
 // gaussian_model.py:144-149): the rest rows of 64 consecutive Gaussians are ONE contiguous, 16-byte aligned run of
 // 64*45 floats, moved with full-width float4 loads.
+// (lrow: the LDS row of THIS lane's Gaussian i — its lane number, or lane & 31 when 32 Gaussians are staged at a time;
+//  wave_first / nrow then describe the staged run)
 __device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const float* dc, const float* rest, int i,
-                                                     bool in_range, int wave_first, int nrow, int lane) {
+                                                     bool in_range, int wave_first, int nrow, int lane, int lrow) {
     if (in_range) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) lds_rows[lane * ROW_LDS + c] = dc[3 * (size_t)i + c];
+        for (int c = 0; c < 3; ++c) lds_rows[lrow * ROW_LDS + c] = dc[3 * (size_t)i + c];
     }
     const float* src = rest + (size_t)wave_first * REST_F;
     const int nflat = nrow * REST_F;
@@ -319,11 +322,11 @@ __device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const floa
 // coefficients beyond the active degree)
 __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, float* d_dc, float* d_rest, int i,
                                                       bool in_range, int wave_first, int nrow, uint64_t live,
-                                                      int nfloat, int lane) {
+                                                      int nfloat, int lane, int lrow) {
     if (in_range) {
-        const bool on = (live >> lane) & 1ull;
+        const bool on = (live >> lrow) & 1ull;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = on ? lds_rows[lane * ROW_LDS + c] : 0.f;
+        for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = on ? lds_rows[lrow * ROW_LDS + c] : 0.f;
     }
     float* dst = d_rest + (size_t)wave_first * REST_F;
     const int nflat = nrow * REST_F;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         const int wave_first = blockIdx.x * blockDim.x + wv * 64;
         const int nrow = min(64, P - wave_first);
         if (nrow > 0 && __ballot(alive) != 0)
-            coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane);
+            coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane, lane);
         wave_lds_fence();
         if (alive) {
             const float* sh = (const float*)&s_rows[wv][lane * ROW_LDS];
@@ -553,12 +556,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 // ---------------------------------------------------------------------------------------------
 // K8 + K9
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp, msgs_gaussians_t g,
+// (held to 96 registers = 5 waves per SIMD: measured 116 us with the compiler's 102 registers / 4 waves, 112 us with 5 waves and
+//  one spilled register, 125 us with 6 waves and 22 spills; 121 us before the rows were staged in two runs)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void preprocess_backward_kernel(ViewParams vp, msgs_gaussians_t g,
                                                                   const int32_t* __restrict__ radii,
                                                                   const char* __restrict__ geom,
                                                                   const grad_acc_t* __restrict__ grad_rec,
                                                                   msgs_grads_t grads) {
-    __shared__ float s_rows[4][64 * ROW_LDS];
+    // 32 rows per wave: the SH rows of a wave's 64 Gaussians pass through LDS in two runs of 32 (below).  25 KB per workgroup
+    // instead of 50: the kernel is latency-bound and its time follows the occupancy (measured at C3 with 1 / 2 / 3 workgroups
+    // per CU: 252 / 147 / 121 us)
+    __shared__ float s_rows[4][K9_STAGE_ROWS * ROW_LDS];
     __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,22 +594,11 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
     const bool factored_sh = raw && grads.dL_dfeatures_dc == nullptr;
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
-    if (split_in) {
-        const int nrow = min(64, P - wave_first);
-        if (nrow > 0 && live != 0)
-            coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane);
-        wave_lds_fence();
-    } else if (staged_sh) {
+    if (staged_sh && !split_in) {            // list of the rendered lanes, ascending: the rows to fetch from the concatenated tensor
         if (rendered) s_idx[wv][__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        wave_lds_fence();
-        coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(live),
-                       sh_row_float4s(deg), lane);
-        wave_lds_fence();
     }
-    float* dsh = factored_sh ? nullptr
-                 : staged_sh ? &s_rows[wv][lane * ROW_LDS]
-                             : (grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr);
-    // (raw mode: the LDS row receives the gradient of the concatenated [dc | rest] coefficients)
+    uint32_t fl = 0;
+    float p[3] = {0.f, 0.f, 0.f};
 
     if (rendered) {
         Cam cm;
@@ -629,8 +626,8 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
         dopac = o_in > 0.f ? gb.y / o_in : 0.f;                         // (q / (o w)) * w, SPEC M4
         if (raw) dopac = dopac * (o_in * (1.0f - o_in));                // through the sigmoid
         dcolr[0] = gb.z; dcolr[1] = gb.w; dcolr[2] = gc.x;
-        const uint32_t fl = flags[i];
-        const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
+        fl = flags[i];
+        p[0] = g.means3D[3 * i]; p[1] = g.means3D[3 * i + 1]; p[2] = g.means3D[3 * i + 2];
 
         float cov3D[6];
         float R[3][3], S[3] = {0.f, 0.f, 0.f};
@@ -721,13 +718,52 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
                 dmean[j] += (cm.M[4 * j + 0] * m_w - cm.M[4 * j + 3] * mul1) * g2x +
                             (cm.M[4 * j + 1] * m_w - cm.M[4 * j + 3] * mul2) * g2y;
         }
-        // ---- colour backward ----
-        if (!g.colors_precomp) {
+        // ---- 3-D covariance backward ----
+        if (!g.cov3D_precomp) {
+            const float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dM[3][3], dR[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc += Gm[a][k] * (R[k][b] * S[b]);
+                    dM[a][b] = 2.f * acc;
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float ds = dM[0][j] * R[0][j] + dM[1][j] * R[1][j] + dM[2][j] * R[2][j];
+                dscale[j] = vp.scale_modifier * ds;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dR[a][j] = dM[a][j] * S[j];
+            }
+            const float r = qr, x = qx, y = qy, z = qz;
+            dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+            if (raw) {
+                // through exp: d/d(log s) = s * d/ds;  through normalize: (g - q (q.g)) / ||raw||
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dscale[j] = dscale[j] * sact[j];
+                const float dotq = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+                dq[0] = (dq[0] - r * dotq) / qnorm; dq[1] = (dq[1] - x * dotq) / qnorm;
+                dq[2] = (dq[2] - y * dotq) / qnorm; dq[3] = (dq[3] - z * dotq) / qnorm;
+            }
+        }
+    }
+    // ---- colour backward (the last contribution to dL/dmean) ----
+    // sh: this Gaussian's 48 (or 3K) coefficients, dsh: where their gradient goes (the same LDS row when staged; nullptr = the
+    // factored path, rows not formed)
+    auto colour_backward = [&](const float* sh, float* dsh) {
+        {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 if (fl & (1u << c)) dcolr[c] = 0.f;                                // Q8
-            const float* sh = staged_sh ? (const float*)&s_rows[wv][lane * ROW_LDS] : g.shs + (size_t)3 * K * i;
-            const float dox = p[0] - cm.cam[0], doy = p[1] - cm.cam[1], doz = p[2] - cm.cam[2];
+            const float dox = p[0] - vp.campos[0], doy = p[1] - vp.campos[1], doz = p[2] - vp.campos[2];
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
             const float x = dox / len, y = doy / len, z = doz / len;
             float ddir[3] = {0.f, 0.f, 0.f};
@@ -773,57 +809,47 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(ViewParams vp,
             dmean[1] += (ddir[1] - y * dotv) / len;
             dmean[2] += (ddir[2] - z * dotv) / len;
         }
-        // ---- 3-D covariance backward ----
-        if (!g.cov3D_precomp) {
-            const float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
-                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
-                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-            float dM[3][3], dR[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc += Gm[a][k] * (R[k][b] * S[b]);
-                    dM[a][b] = 2.f * acc;
-                }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float ds = dM[0][j] * R[0][j] + dM[1][j] * R[1][j] + dM[2][j] * R[2][j];
-                dscale[j] = vp.scale_modifier * ds;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) dR[a][j] = dM[a][j] * S[j];
+    };
+    const bool do_colour = !g.colors_precomp;                 // wave-uniform
+    if (do_colour && staged_sh) {
+        // the wave's SH rows in two runs of K9_STAGE_ROWS = 32 Gaussians: load (cooperative, coalesced) -> the lanes of that
+        // run work on their LDS row in place -> store (cooperative, coalesced)
+        const int nfloat = 3 * (deg + 1) * (deg + 1);
+#pragma unroll 1
+        for (int h = 0; h < 64 / K9_STAGE_ROWS; ++h) {
+            const int row0 = h * K9_STAGE_ROWS;
+            const int first = wave_first + row0;
+            const int nrow = min(K9_STAGE_ROWS, P - first);
+            if (nrow <= 0) break;                                          // wave-uniform
+            const uint64_t live_h = (live >> row0) & ((1ull << K9_STAGE_ROWS) - 1ull);
+            const bool mine = (lane / K9_STAGE_ROWS) == h;
+            const int lrow = lane - row0;
+            wave_lds_fence();                                              // s_idx visible / previous run stored
+            if (split_in) {
+                if (live_h != 0)
+                    coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range && mine, first, nrow, lane, lrow);
+            } else {
+                coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F,
+                               s_idx[wv] + __popcll(live & ((1ull << row0) - 1ull)), __popcll(live_h), sh_row_float4s(deg),
+                               lane, row0);
             }
-            const float r = qr, x = qx, y = qy, z = qz;
-            dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
-            dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
-            dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
-            dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
-            if (raw) {
-                // through exp: d/d(log s) = s * d/ds;  through normalize: (g - q (q.g)) / ||raw||
-#pragma unroll
-                for (int j = 0; j < 3; ++j) dscale[j] = dscale[j] * sact[j];
-                const float dotq = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
-                dq[0] = (dq[0] - r * dotq) / qnorm; dq[1] = (dq[1] - x * dotq) / qnorm;
-                dq[2] = (dq[2] - y * dotq) / qnorm; dq[3] = (dq[3] - z * dotq) / qnorm;
+            wave_lds_fence();
+            if (rendered && mine) {
+                float* row = &s_rows[wv][lrow * ROW_LDS];
+                colour_backward(row, factored_sh ? nullptr : row);
             }
+            if (factored_sh) continue;
+            wave_lds_fence();
+            if (raw)
+                coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range && mine, first,
+                                      nrow, live_h, nfloat, lane, lrow);
+            else
+                coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)first * ROW_F, nrow, live_h, nfloat, lane);
         }
-    } else if (dsh && !staged_sh) {
-        for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
-    }
-    if (raw && !factored_sh) {
-        wave_lds_fence();
-        const int nrow = min(64, P - wave_first);
-        if (nrow > 0)
-            coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range, wave_first,
-                                  nrow, live, 3 * (deg + 1) * (deg + 1), lane);
-    } else if (staged_sh && !raw) {
-        wave_lds_fence();
-        const int nrow = min(64, P - wave_first);
-        if (nrow > 0)
-            coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)wave_first * ROW_F, nrow, live,
-                            3 * (deg + 1) * (deg + 1), lane);
+    } else if (do_colour) {
+        float* dsh = grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr;
+        if (rendered) colour_backward(g.shs + (size_t)3 * K * i, dsh);
+        else if (dsh) for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
     }
     if (!in_range) return;
 
@@ -907,7 +933,7 @@ __global__ __launch_bounds__(256) void sh_grad_from_views_kernel(int P, int n_vi
     wave_lds_fence();
     const int nrow = min(64, P - wave_first);
     if (nrow > 0)
-        coop_store_split_rows(s_rows[wv], d_dc, d_rest, i, in_range, wave_first, nrow, ~0ull, 48, lane);
+        coop_store_split_rows(s_rows[wv], d_dc, d_rest, i, in_range, wave_first, nrow, ~0ull, 48, lane, lane);
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ V,
