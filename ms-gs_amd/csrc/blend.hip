@@ -121,7 +121,7 @@ struct LaneStats { uint32_t steps, alive, blended; };
 // 216 us when the compiler is free to hoist all thirteen LDS reads of a trip (97 VGPRs -> 4 waves per SIMD) and 182 us
 // when it is held to 64 VGPRs / 8 waves per SIMD (amdgpu_waves_per_eu below): issue-bound code wants the waves, not the
 // hoisting.  (Folding the two selects of the update into one — alpha_b = blend ? alpha : 0, T = fma(-T, alpha_b, T) —
-// measured the same time and was not kept.)
+// measured the same time and was not kept; eight entries per trip: 184 us, no gain.)
 constexpr int LIST_PAD = 4;
 constexpr uint32_t SENTINEL_OFF = (uint32_t)BATCH << 4;
 __device__ __forceinline__ void write_sentinel_record(float4* s_r0, float4* s_r1, float4* s_r2) {

@@ -211,13 +211,18 @@ def _backward_scratch(P, D, dev):
     return _bytes(lib.msgs_backward_scratch_bytes(P), dev)
 
 
+# MSGS_NO_FORWARD_CLEAR=1: allocate the records in backward as before (a trainer that keeps MANY forward graphs alive before
+# running their backwards would otherwise hold 80 bytes per Gaussian per graph)
+_forward_clear = os.environ.get("MSGS_NO_FORWARD_CLEAR", "0") != "1"
+
+
 def _alloc_grad_records(ctx, P, dev):
     """The backward's per-Gaussian gradient records have to start from zero.  When a backward can follow, the buffer is
     allocated HERE and handed to the forward, whose blend kernel clears it on the side (include/msgs.h, grad_records: the
     kernel is instruction-bound, the stores are free) — the backward then skips its fill launch.  Not in the verification
     mode, whose scratch is sized by the instance count."""
     ctx.grad_rec = None
-    if P > 0 and any(ctx.needs_input_grad) and not _C.lib.msgs_get_deterministic():
+    if _forward_clear and P > 0 and any(ctx.needs_input_grad) and not _C.lib.msgs_get_deterministic():
         ctx.grad_rec = _bytes(_C.lib.msgs_backward_scratch_bytes(P), dev)
     return ctx.grad_rec
 
