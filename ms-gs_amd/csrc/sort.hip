@@ -213,6 +213,29 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     }
 }
 
+// Large inputs (SCANNED_MIN_BLOCKS): one small block turns the group sums into the scatter's bases in place —
+// gsum[g][d] := (keys with a smaller digit) + (digit d in groups before g) — so that a scatter block reads ONE row of this
+// table plus the histograms of the earlier blocks of its own group, instead of every group's sums (with 13 400 blocks that
+// was 112 + 60 rows = 176 KB per block, more bytes than the keys the block moves).  A kernel of its own: folding it into the
+// histogram kernel's last-arriving block needs a device-scope release fence in EVERY block, which on this part writes the
+// L2 back each time (measured: the tile sort of 55 M pairs 1.15 -> 3.8 ms).
+__global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ gsum, int ngroups) {
+    __shared__ uint32_t s_wv[4];
+    const int d = threadIdx.x;
+    uint32_t tot = 0;
+#pragma unroll 8
+    for (int k = 0; k < ngroups; ++k) tot += gsum[(int64_t)k * 256 + d];
+    uint32_t dummy;
+    uint32_t run = block_exclusive_scan(tot, s_wv, &dummy);
+#pragma unroll 8
+    for (int k = 0; k < ngroups; ++k) {
+        uint32_t* q = &gsum[(int64_t)k * 256 + d];
+        const uint32_t v = *q;
+        *q = run;
+        run += v;
+    }
+}
+
 template <bool STAGED, int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
                                                                      int shift, uint32_t mask, int64_t nblocks,
                                                                      const uint32_t* __restrict__ hist_scanned,
                                                                      const uint32_t* __restrict__ gsum, int gsize,
-                                                                     int ngroups) {
+                                                                     int ngroups, bool gsum_is_base = false) {
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, later per-wave global bases
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -256,7 +279,16 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     uint32_t gbase;
     {   // digit d = threadIdx.x: global base of this block's run of digit d
         const uint32_t d = threadIdx.x;
-        if (gsum) {
+        if (gsum && gsum_is_base) {
+            // the histogram kernel's last block already turned the group sums into bases (large inputs)
+            const int g = blockIdx.x / gsize;
+            uint32_t before = gsum[(int64_t)g * 256 + d];
+            const int nin = (int)(blockIdx.x - (int64_t)g * gsize);
+            const uint32_t* hrow = hist_scanned + ((int64_t)g * gsize) * 256 + d;
+#pragma unroll 8
+            for (int k = 0; k < nin; ++k) before += hrow[(int64_t)k * 256];
+            gbase = before;
+        } else if (gsum) {
             // base = (keys with a smaller digit) + (same digit in earlier groups) + (same digit in earlier blocks of
             // this group); hist_scanned holds the RAW block histograms here
             const int g = blockIdx.x / gsize;
@@ -622,6 +654,40 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s) {
 // The words radix_sort_pairs(n, bits) needs zeroed beforehand in its default (grouped) configuration — an upper bound on
 // the group-sum table, so that a kernel running earlier on the stream can clear them and the sort can be called with
 // pre_zeroed = true (one launch less).  Returns false when the sort will not take the grouped path.
+// geometry of the grouped radix pass (shared by the sort and by the callers that clear its tables ahead of time)
+constexpr int64_t SCANNED_MIN_BLOCKS = 4096;     // from here on the histogram kernel's last block scans the group sums
+constexpr int SCANNED_GSIZE = 32;
+struct GroupGeom {
+    bool big, mid, scanned;
+    int items, gsize, ngroups;
+    int64_t nb;
+    GroupGeom(int64_t n, bool grouped, bool staged) {
+        big = grouped && staged && n >= SORT_BIG_N;
+        mid = !big && grouped && staged && n >= SORT_MID_N;
+        items = big ? 16 : (mid ? 8 : SORT_ITEMS);
+        nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
+        // MSGS_SORT_GROUP_SCAN=0: never; =<n>: from n blocks on (tests exercise the variant at small sizes with it)
+        static const int64_t min_blocks = [] {
+            const char* e = getenv("MSGS_SORT_GROUP_SCAN");
+            if (!e) return SCANNED_MIN_BLOCKS;
+            const long v = atol(e);
+            return v <= 0 ? (int64_t)1 << 62 : (int64_t)v;
+        }();
+        scanned = grouped && big && nb >= min_blocks;
+        if (scanned) {
+            gsize = SCANNED_GSIZE;       // short in-group walks; the number of groups is no longer what a block reads
+        } else {
+            // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
+            gsize = 8;
+            while ((int64_t)gsize * gsize < nb) gsize += 8;
+            gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
+        }
+        ngroups = (int)((nb + gsize - 1) / gsize);
+    }
+    // words behind the block-histogram table that have to be zero before the first pass: the group sums of every pass
+    size_t zero_words(int passes) const { return (size_t)passes * 256 * ngroups; }
+};
+
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {
     if (n <= 0) return false;
     int passes = (end_bit - begin_bit + 7) / 8;
@@ -630,17 +696,10 @@ bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch
     static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
     const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
     if (onesweep || scan_table || passes > 4) return false;
-    const bool big = staged && n >= SORT_BIG_N;
-    const bool mid = !big && staged && n >= SORT_MID_N;
-    const int items = big ? 16 : (mid ? 8 : SORT_ITEMS);
-    const int64_t nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
-    int gsize = 8;
-    while ((int64_t)gsize * gsize < nb) gsize += 8;
-    gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
-    const int ngroups = (int)((nb + gsize - 1) / gsize);
+    const GroupGeom G(n, true, staged);
     const SortScratch L(n);
-    *ptr = reinterpret_cast<uint32_t*>(scratch + L.hist) + (size_t)256 * nb;
-    *words = (size_t)passes * 256 * ngroups;
+    *ptr = reinterpret_cast<uint32_t*>(scratch + L.hist) + (size_t)256 * G.nb;
+    *words = G.zero_words(passes);
     return true;
 }
 
@@ -661,18 +720,13 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
     // 16 keys per thread for big inputs (longer digit runs per block -> better write coalescing; measured on the
     // tile sort: 94 -> 81 us at 4.1M pairs, 1.6 -> 1.2 ms at 55M); 8 below that, where 16 would leave CUs idle
-    const bool big = grouped && staged && n >= SORT_BIG_N;
-    const bool mid = !big && grouped && staged && n >= SORT_MID_N;
-    const int items = big ? 16 : (mid ? 8 : SORT_ITEMS);
-    const int64_t nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
-    // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
-    int gsize = 8;
-    while ((int64_t)gsize * gsize < nb) gsize += 8;
-    gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
-    const int ngroups = (int)((nb + gsize - 1) / gsize);
+    const GroupGeom G(n, grouped, staged);
+    const bool big = G.big, mid = G.mid;
+    const int64_t nb = G.nb;
+    const int gsize = G.gsize, ngroups = G.ngroups;
     uint32_t* gsum_all = hist + (size_t)256 * nb;
     if (grouped && !pre_zeroed) {
-        hipError_t e = launch_zero(gsum_all, sizeof(uint32_t) * (size_t)passes * 256 * ngroups, s);
+        hipError_t e = launch_zero(gsum_all, sizeof(uint32_t) * G.zero_words(passes), s);
         if (e != hipSuccess) return e;
     }
     // onesweep carve-up of the `hist` region: [4][256] digit histograms, [4] tickets, [1] error flag,
@@ -713,8 +767,9 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
             const dim3 grid((unsigned)nb), block(SORT_THREADS);
             if (big) {
                 hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
+                if (G.scanned) hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, s, gs, ngroups);
                 hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                                   mask, nb, hist, gs, gsize, ngroups);
+                                   mask, nb, hist, gs, gsize, ngroups, G.scanned);
             } else if (mid) {
                 hipLaunchKernelGGL((radix_hist_kernel<8>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
                 hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
