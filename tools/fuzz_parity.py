@@ -1,0 +1,76 @@
+"""Randomised parity sweep (not a test): N random small scenes — Gaussian count, image size (ragged), SH degree, multi-scale
+filters, fade, background, kernel granularity, reference-API vs fused entry — HIP forward + backward against the float32 oracle
+with the north-star tolerances of tests/parity_utils.py.  Prints one line per failure and a summary.
+usage: python tools/fuzz_parity.py [N=200] [seed=0]"""
+import os, sys, random, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests"),
+          os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import torch
+import scenes
+import diff_gaussian_rasterization as dgr
+from oracle import oracle_ctypes as oc
+from parity_utils import check_backward, check_forward, hip_render, small_scene
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(N):
+    P = rng.choice([1, 2, 7, 63, 64, 65, 200, 777, 1500, 4001, 9000])
+    W, H = rng.randint(1, 260), rng.randint(1, 200)
+    deg = rng.randint(0, 3)
+    ms = rng.random() < 0.5
+    fade = rng.choice([0.0, 0.5, 1.0])
+    gran = rng.choice([0, 1, 2])
+    bwd_gen = rng.choice([0, 1, 2])
+    seed = rng.randint(0, 10 ** 6)
+    cfg = dict(P=P, W=W, H=H, deg=deg, ms=ms, fade=fade, gran=gran, bwd_gen=bwd_gen, seed=seed)
+    try:
+        sc, cam = small_scene(P, W, H, seed, sh_degree=deg, multiscale=ms,
+                              **({"scale_k": 0.004 * 1920.0 / max(W, 8) * 0.3} if ms else {}))
+        st = dict(filter_small=ms, filter_large=ms, fade_size=fade)
+        bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
+        dL = scenes.grad_seed(W, H, seed % 97)
+        pg = dgr._C.lib.msgs_set_blend_granularity(gran)
+        pb = dgr._C.lib.msgs_set_backward_generation(bwd_gen)
+        try:
+            out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+        finally:
+            dgr._C.lib.msgs_set_blend_granularity(pg)
+            dgr._C.lib.msgs_set_backward_generation(pb)
+        orc = oc.rasterize(pc.seen, cam, st, bg)
+        og = oc.backward(orc, dL)
+        check_forward(out, orc, str(cfg))
+        check_backward(pc, m2, og, str(cfg), flagged=orc.borderline_gaussians)
+    except Exception as e:                                  # noqa: BLE001
+        bad += 1
+        print("FAIL", cfg, repr(e)[:160])
+        msg = str(e)
+        if "grad scaling" in msg or "grad rotation" in msg:
+            # is it the float32 floor of the reference algorithm itself?  the same oracle source compiled with FMA contraction
+            # (tools/parity_floor.py) against the plain oracle, same tensor, same exclusions
+            try:
+                import parity_floor as pf
+                so = pf.build_fma_oracle()
+                og2 = pf.with_oracle_lib(so, lambda: oc.backward(oc.rasterize(pc.seen, cam, st, bg), dL))
+                clean = ~orc.borderline_gaussians
+                for k in ("scales", "rotations"):
+                    ref = og[k].double()
+                    d = (og2[k].double() - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values
+                    print(f"     oracle vs FMA-contracted oracle, {k}: {(d[clean].max() / ref.abs().max().clamp_min(1e-30)).item():.3e}")
+                # and both float32 evaluations against the float64 autograd truth of the same pipeline
+                from oracle import torch_oracle as to
+                t_out, tg = to.forward_backward_tiled(pc.seen, cam, st, bg, dL)
+                flagged = orc.borderline_gaussians | (t_out["radii"] != orc.radii)
+                w_hip = check_backward(pc, m2, {k: v.float() for k, v in tg.items()}, "truth", flagged=flagged, rtol=1.0)
+                for k, kk in (("scales", "scaling"), ("rotations", "rotation")):
+                    ref = tg[k].double()
+                    d = (og[k].double().reshape(ref.shape) - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values
+                    e_orc = (d[~flagged].max() / ref.abs().max().clamp_min(1e-30)).item()
+                    print(f"     vs float64 truth, {kk}: oracle_f32 {e_orc:.3e}   HIP {w_hip[kk]:.3e}")
+            except Exception as e2:                         # noqa: BLE001
+                print("     (floor check failed:", repr(e2)[:160], ")")
+        elif "borderline" not in msg and bad <= 3:
+            traceback.print_exc()
+print(f"fuzz: {N - bad} / {N} configurations within tolerance")
