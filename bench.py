@@ -33,13 +33,51 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 # the hosts of this pool only support dmabuf IPC: without this RCCL's buffer exchange between the ranks fails in
 # hipIpcGetMemHandle (already exported on the driver's boxes; kept here for any other launcher)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+
+def _self_launch_if_needed():
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N
+    ranks HERE, as fresh child processes — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    exactly what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` would give them — relay rank 0's
+    JSON line and exit with the worst child status.  Runs before torch is imported: this process never touches the GPU
+    (a process that has initialised HIP must not be replaced, and does not need to be: it only waits)."""
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    raise SystemExit(bad[0] if bad else 0)
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()
 
 import numpy as np
 import torch
@@ -71,12 +109,15 @@ def cpu_baseline(scenes, scene, settings, W, H, runs=2):
     dL = scenes.grad_seed(W, H, 2)
     cores = os.cpu_count() or 1
 
+    d_ref = [None]
+
     def run(nt):
         t0 = time.perf_counter()
         r = oc.rasterize(scene, cam, settings, bg, num_threads=nt)
         t1 = time.perf_counter()
         oc.backward(r, dL, num_threads=nt)
         t2 = time.perf_counter()
+        d_ref[0] = r.num_instances          # the reference's duplication count (3-sigma rect): D_ref of SURVEY 8(d)
         del r
         return (t2 - t0, t1 - t0, t2 - t1)
     best = min((run(cores) for _ in range(runs)), key=lambda t: t[0])
@@ -86,8 +127,57 @@ def cpu_baseline(scenes, scene, settings, W, H, runs=2):
             "seconds": round(dt, 2), "fwd_s": round(best[1], 2), "bwd_s": round(best[2], 2),
             "single_thread": {"value": round(W * H / 1e6 / one[0], 4), "cores": 1, "seconds": round(one[0], 2),
                               "fwd_s": round(one[1], 2), "bwd_s": round(one[2], 2)},
+            "instances_reference_duplication": d_ref[0],
+            "scaling_note": f"a checker, not a tuned baseline: {cores} cores are only {one[0] / dt:.1f}x one thread "
+                            "(double atomics in the backward, serial sort stages)",
             "sample": f"the whole workload (same scene, settings, {W}x{H}), forward+backward, float32 "
                       f"C++/OpenMP oracle: all {cores} host cores (best of {runs} runs) and one thread (one run)"}
+
+
+def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
+    """What MS-GS is for, measured the reference's way (train.py:488-496,541 logs render_time per scale; viewer.py:67-81 and
+    render_traj.py:99-105 time a forward-only render() between synchronisations): the SAME 1 M-Gaussian scene at the pyramid
+    levels k = 0..6 ((W, H) = (int(1920 / 2^k), int(1080 / 2^k)), utils/camera_utils.py:38-39):
+      pyramid_ms          render() + backward() per level, training settings (filters on, fade 0)
+      render_forward_ms   forward-only render() under no_grad: "filters_on" = the viewer's --anti_alias (filter_small =
+                          filter_large = True, fade_size 1.0: viewer.py:59-72), "filters_off" = render.py's defaults"""
+    from gaussian_renderer import PIPE, render
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return round(1e3 * (time.perf_counter() - t) / steps, 4)
+
+    fb, on, off, sizes, vis = [], [], [], [], []
+    aa = dict(filter_small=True, filter_large=True, fade_size=1.0)
+    plain = dict(filter_small=False, filter_large=False, fade_size=1.0)
+    for k in range(7):
+        W, H = int(1920 / 2 ** k), int(1080 / 2 ** k)
+        cam = scenes.front_camera(W, H).to(dev)
+        dL = scenes.grad_seed(W, H, 40 + k).to(dev)
+
+        def train_step():
+            for p_ in pc.parameters():
+                p_.grad = None
+            render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+        fb.append(timed(train_step))
+        with torch.no_grad():
+            on.append(timed(lambda: render(cam, pc, PIPE, bg, **aa)))
+            off.append(timed(lambda: render(cam, pc, PIPE, bg, **plain)))
+            vis.append(int((render(cam, pc, PIPE, bg, **settings)["radii"] > 0).sum().item()))
+        sizes.append([W, H])
+    for p_ in pc.parameters():
+        p_.grad = None
+    return ({"levels": sizes, "ms": fb, "rendered_gaussians": vis,
+             "what": "render() + backward() per pyramid level k = 0..6 of the C3 scene, training settings"},
+            {"levels": sizes, "filters_on": on, "filters_off": off,
+             "what": "forward-only render() under no_grad per pyramid level (viewer.py:67-81 convention): filters_on = "
+                     "--anti_alias (both filters, fade_size 1.0), filters_off = render.py defaults"})
 
 
 def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup):
@@ -156,11 +246,31 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pyramid", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python3 bench.py --gpus N` (the script "
+                         "starts its own ranks) or under torch.distributed.run with --nproc-per-node N")
+    if os.environ.get("MSGS_BENCH_LAUNCH_ONLY") == "1":
+        # rehearsal of the rank start-up alone (tests/test_bench_launcher_cpu.py, no GPU): rendezvous over gloo, one
+        # collective, rank 0 prints a JSON line the parent has to relay
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            dist.barrier()
+            total = float(t.item())
+            dist.destroy_process_group()
+        else:
+            total = 0.0
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world, "rank_sum": total}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
     # one process per GPU; (local_rank % device_count only matters for the single-GPU rehearsal of the N > 1 path)
@@ -176,7 +286,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     import scenes
     import diff_gaussian_rasterization as dgr
@@ -225,14 +334,14 @@ def main():
         dgr._C.set_timer(timer)
         c = next_cam()
         if exchange is not None:
-            exchange.begin_view()
+            exchange.begin_view(c.camera_center)
         else:
             for p_ in pc.parameters():
                 p_.grad = None
         out = render(c, pc, PIPE, bg, **settings)
         out["render"].backward(dL)               # fixed dL/dimage (SURVEY §8(d) 'backward seed')
         if exchange is not None:                 # the exchange completes INSIDE the step: every .grad is final here
-            exchange.end_view(c.camera_center)
+            exchange.end_view()
             exchange.finish()
         return out
 
@@ -263,14 +372,19 @@ def main():
     # yields a measurement of the C4 pattern.
     exchange_used = "factored" if exchange is not None else None
     if exchange is not None:
-        ok = torch.ones(1, device=dev)
+        # the ranks agree on the outcome over a SEPARATE CPU (gloo) group: a rank that failed between its two RCCL
+        # collectives must not issue a third one on that communicator while its peers are still inside the second
+        # (mismatched collectives hang); peers stuck in a collective a failed rank never joined are bounded by the
+        # process-group timeout, not by this agreement
+        agree = dist.new_group(backend="gloo")
+        ok = torch.ones(1)
         try:
             step()
             torch.cuda.synchronize()
         except Exception as e:           # noqa: BLE001 - any failure of the new path must not lose the measurement
             print(f"[bench rank {rank}] factored exchange failed ({e!r}); falling back to the dense all-reduce", file=sys.stderr)
             ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=agree)
         if ok.item() == 0:
             from view_parallel import FlatGradBucket
             dgr.set_grad_sinks(None)
@@ -460,29 +574,60 @@ def main():
                     return max(hits, key=lambda v: v.get("launches", 1)) if hits else None
                 except Exception:
                     return None
-            tr = committed("traffic_r2.json")
+            tr = committed("traffic_r3.json")
             traffic = int(tr["hbm_bytes"]) if tr else None
-            # what actually bounds the kernel: VALU issue.  Wave-instructions per launch from the committed
-            # PMC summary (same hash rule); cycles per wave64 instruction from the calibration of tools/valu_calib.hip
-            # (profiles/r2_valu_calibration.txt: plain fp32 2.2, v_cmp / v_cndmask / DPP 4.25, v_exp / v_rcp 8.1) weighted
-            # with the instruction mix of the kernel's inner loops (counted in the ISA: forward 18 plain + 3 compares +
-            # 1 exp per pair; backward 24 + 4 + 2 per quadrant step and 8 + 21 per reduction)
+            # what actually bounds the kernel: INSTRUCTION ISSUE.  One model for both blend kernels: per
+            # launch, wave-instructions by class from the committed PMC summary (same hash rule) x the calibrated issue cost
+            # of each class (tools/valu_calib.hip -> profiles/r2_valu_calibration.txt: a SIMD issues about one instruction of
+            # ANY kind per ~2 cycles; plain fp32 VALU 2.2, v_cmp / v_cndmask / DPP 4.25, v_exp / v_rcp 8.1, scalar 2.0,
+            # LDS 4.0 per instruction per SIMD at the kernels' access widths) / (1024 SIMDs x 2.4 GHz).  The VALU mix per
+            # kernel is counted in the ISA of the inner loops (fractions of plain / half-rate / transcendental).
             valu = None
-            sq = committed("sq_r2.json")
+            sq = committed("sq_r3.json")
             if sq and "SQ_INSTS_VALU" in sq:
-                cyc = {"blend_fwd": (18 * 2.2 + 3 * 4.25 + 8.1) / 22.0,
-                       "blend_bwd": (63 * 2.2 + 30 * 4.25 + 4.6 * 8.1) / 97.6}[dom]
-                insts = float(sq["SQ_INSTS_VALU"])
-                floor_ms = insts * cyc / (1024 * 2.4e9) * 1e3
-                valu = {"wave_instructions": insts, "cycles_per_instruction_of_this_mix": round(cyc, 3),
+                mix = {"blend_fwd": (18.5 / 23.5, 4.0 / 23.5, 1.0 / 23.5),
+                       "blend_bwd": (0.64, 0.31, 0.05)}[dom]
+                nv, ns = float(sq["SQ_INSTS_VALU"]), float(sq.get("SQ_INSTS_SALU", 0.0))
+                nl = float(sq.get("SQ_INSTS_LDS", 0.0))
+                cyc_v = mix[0] * 2.2 + mix[1] * 4.25 + mix[2] * 8.1
+                cycles = nv * cyc_v + ns * 2.0 + nl * 4.0
+                floor_ms = cycles / (1024 * 2.4e9) * 1e3
+                valu = {"valu_wave_instructions": nv, "salu_wave_instructions": ns, "lds_wave_instructions": nl,
+                        "cycles_per_valu_instruction_of_this_mix": round(cyc_v, 3),
                         "issue_floor_ms": round(floor_ms, 4), "frac_of_issue_floor": round(floor_ms / kernels[dom], 4),
-                        "source": "profiles/sq_r2.json + profiles/r2_valu_calibration.txt"}
+                        "valu_only_floor_ms": round(nv * cyc_v / (1024 * 2.4e9) * 1e3, 4),
+                        "model": "sum over classes of wave-instructions x calibrated cycles per instruction per SIMD "
+                                 "(VALU mix, scalar 2.0, LDS 4.0) / (1024 SIMDs x 2.4 GHz)",
+                        "source": "profiles/sq_r3.json + profiles/r2_valu_calibration.txt"}
+            # every SURVEY 8(d) row against HBM, from the same HIP-event kernel times: the HBM-bound kernels read against
+            # HBM, the issue-bound blend pair against both
+            S_sh = 12 * 16
+            tb = max(1, math.ceil(math.log2(tiles)))
+            Dn, Vn = stats["D"], stats["V"]
+            alg_all = {"preprocess": P * (117 + S_sh) + Vn * 79, "scan": 8 * P, "emit": 12 * Dn,
+                       "sort(depth+tile)": Dn * (24 * math.ceil((32 + tb) / 8) + 8), "ranges": 8 * Dn + 8 * tiles,
+                       "blend_fwd": alg["blend_fwd"], "blend_bwd": alg["blend_bwd"],
+                       "preprocess_bwd": Vn * (309 + 36 + 24) + Vn * 236}
+            kms = dict(kernels)
+            kms["sort(depth+tile)"] = kernels.get("depth_sort", 0.0) + kernels.get("tile_sort", 0.0)
+            per_kernel = {k: {"algorithmic_bytes": int(b), "ms": round(kms[k], 4),
+                              "GBps": round(b / (kms[k] * 1e-3) / 1e9, 1),
+                              "frac": round(b / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                          for k, b in alg_all.items() if kms.get(k, 0.0) > 0}
+            total_alg = float(sum(alg_all.values()))
+            whole = {"algorithmic_bytes": int(total_alg), "ms_per_step": round(ms_per_step, 4),
+                     "GBps": round(total_alg / (ms_per_step * 1e-3) / 1e9, 1),
+                     "frac": round(total_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "instances": Dn,
+                     "note": "sum of the SURVEY 8(d) per-kernel algorithmic bytes with THIS build's instance count D (exact "
+                             "culling) / the driver-timed step / 8 TB/s; K4 priced as the reference's 64-bit-key sort"}
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom], "valu_issue": valu,
                     "blend_fwd_plus_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
                                            "algorithmic_bytes": alg["blend_fwd"] + alg["blend_bwd"],
-                                           "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)}}
+                                           "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)},
+                    "whole_step": whole, "per_kernel": per_kernel}
         result["roofline"] = roof
         result["median_of_50"] = median50
         result["kernel_ms"] = kernels
@@ -490,6 +635,12 @@ def main():
                                    f"HIP events recorded by the library on {len(timers)} of the {args.steps} timed steps")
         if extra is not None:
             result["exchange"] = extra
+        # the reference's own measurement: render time per resolution scale (train.py:488-496,541; viewer.py:67-81)
+        if world == 1 and (P, W, H) == (1_000_000, 1920, 1080) and not args.no_pyramid:
+            try:
+                result["pyramid_ms"], result["render_forward_ms"] = pyramid_timing(scenes, pc, settings, bg, dev)
+            except Exception as e:
+                result["pyramid_ms"] = result["render_forward_ms"] = {"error": repr(e)}
         # informational: the opt-in raw-parameter entry (render_fused: activations + SH concat inside K1/K9,
         # SURVEY §8(f) rank 1) on the same workload.  `value` above stays on the reference-API drop-in path.
         if world == 1:
@@ -525,6 +676,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(scenes, scene, settings, W, H)
+                # the same whole-step figure with the REFERENCE's duplication count (3-sigma rects, counted by the oracle)
+                d_ref = result["cpu_baseline"].get("instances_reference_duplication")
+                ws = (result.get("roofline") or {}).get("whole_step")
+                if d_ref and ws and stats and "D" in stats:
+                    tiles_ = ((W + 15) // 16) * ((H + 15) // 16)
+                    per_inst = 12 + (24 * math.ceil((32 + max(1, math.ceil(math.log2(tiles_)))) / 8) + 8) + 8
+                    b_ref = ws["algorithmic_bytes"] + per_inst * (d_ref - stats["D"])
+                    ws["with_reference_duplication"] = {
+                        "instances": int(d_ref), "algorithmic_bytes": int(b_ref),
+                        "frac": round(b_ref / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             except Exception as e:
                 result["cpu_baseline"] = {"error": repr(e)}
         else:

@@ -24,8 +24,10 @@
  * msgs_forward_stage1 synchronises the stream once to return the instance count (the same D2H
  * `num_rendered` read the reference's forward performs).
  *
- * Threading: re-entrant and stateless (forward is called from the Python main thread, backward
- * from PyTorch's autograd thread).
+ * Threading: re-entrant (forward is called from the Python main thread, backward from PyTorch's
+ * autograd thread).  Not stateless: three PROCESS-WIDE mode flags (msgs_set_deterministic,
+ * msgs_set_backward_generation, msgs_set_blend_granularity; the last two only choose between kernels
+ * that give the same results) and one 64-byte pinned status block per calling host thread.
  *
  * Return value: 0 = MSGS_OK; < 0 = invalid argument / capacity (MSGS_ERR_*); > 0 = hipError_t.
  */
@@ -39,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 5
+#define MSGS_ABI_VERSION 6
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -202,6 +204,18 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g,
                   void* scratch, size_t scratch_bytes,
                   const msgs_grads_t* grads,
                   const msgs_timing_t* timing, void* stream);
+
+/* msgs_backward_per_gaussian: the per-Gaussian half of msgs_backward ALONE (2-D covariance backward, projection, SH,
+ * scale / quaternion chain — upstream's computeCov2DCUDA + preprocessCUDA backward, SURVEY 2.2 K8 + K9) on per-Gaussian
+ * 2-D gradients supplied by the caller instead of the blend backward's sums: sums2d [P,9] DOUBLES (device) =
+ * {dL/dmean2D x, y (the NDC-ish units of dL_dmeans2D), dL/dconic A, B, C, dL/d(effective opacity), dL/drgb[3]}, rounded to
+ * float once like the library's own records.  `geom` and `radii` are those of the forward of the same view.  For the
+ * parity tests: fed the oracle's sums, the two per-Gaussian stages are compared on bit-identical inputs
+ * (tests/test_k8_isolation_gpu.py); also usable by a caller that blends elsewhere.  Reference-API inputs only
+ * (raw_params = 0). */
+int msgs_backward_per_gaussian(const msgs_view_t* view, const msgs_gaussians_t* g, const int32_t* radii,
+                               const void* geom, size_t geom_bytes, const double* sums2d, const msgs_grads_t* grads,
+                               void* stream);
 
 /* ---- view-parallel gradient exchange (new relative to the single-GPU reference) -------------------
  * The SH part of one view's gradient (48 of the 59 floats per Gaussian) is the outer product of the 16 SH basis values

@@ -336,6 +336,8 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     const Timer tm{timing, s};
     grad_acc_t* grad_rec = (grad_acc_t*)scratch_v;
 
+    // deterministic mode writes its own scratch layout from scratch: a "cleared by the forward" claim cannot hold there
+    if (det && grads->scratch_is_clear) return MSGS_ERR_INVALID_ARG;
     if (!grads->scratch_is_clear)           // (else: cleared by the blend kernel of this view's forward, msgs.h)
         HIP_TRY(launch_zero(grad_rec, GRAD_REC_BYTES * (size_t)P, s));
     tm.begin(MSGS_K_BLEND_BWD);
@@ -353,6 +355,23 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     tm.begin(MSGS_K_PREPROCESS_BWD);
     HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s));
     tm.end(MSGS_K_PREPROCESS_BWD);
+    return debug_sync(view, s);
+}
+
+int msgs_backward_per_gaussian(const msgs_view_t* view, const msgs_gaussians_t* g, const int32_t* radii,
+                               const void* geom_v, size_t geom_bytes, const double* sums2d, const msgs_grads_t* grads,
+                               void* stream) {
+    int rc = check_inputs(view, g);
+    if (rc) return rc;
+    if (!grads || g->raw_params) return MSGS_ERR_INVALID_ARG;
+    const int P = g->P;
+    if (P == 0) return MSGS_OK;
+    if (!radii || !geom_v || !sums2d) return MSGS_ERR_INVALID_ARG;
+    if (geom_bytes < msgs_geom_bytes(P)) return MSGS_ERR_CAPACITY;
+    if (g->shs && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_preprocess_backward(make_view_params(view), *g, radii, (const char*)geom_v,
+                                       reinterpret_cast<const grad_acc_t*>(sums2d), *grads, s, true));
     return debug_sync(view, s);
 }
 

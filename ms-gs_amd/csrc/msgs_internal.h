@@ -313,7 +313,7 @@ hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, in
                              char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
-                                      hipStream_t s);
+                                      hipStream_t s, bool textbook = false);
 hipError_t launch_sh_grad_from_views(int P, int n_views, int deg, const float* means3D, const float* campos,
                                      int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
                                      float* d_dc, float* d_rest, hipStream_t s);

@@ -558,6 +558,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 // ---------------------------------------------------------------------------------------------
 // (held to 96 registers = 5 waves per SIMD: measured 116 us with the compiler's 102 registers / 4 waves, 112 us with 5 waves and
 //  one spilled register, 125 us with 6 waves and 22 spills; 121 us before the rows were staged in two runs)
+// TEXTBOOK = true (msgs_backward_per_gaussian, the K8 + K9 isolation entry of the parity tests): grad_rec is NOT this
+// library's record of monomial sums but [P,9] doubles holding the textbook 2-D gradients {dL/dmean2D x, y (NDC-ish units),
+// dL/dconic A, B, C, dL/dopacity_eff, dL/drgb[3]}; the per-Gaussian factors that turn the one into the other are skipped
+// and everything behind them — the conic -> covariance -> scale / quaternion chain, projection, SH — is the same code.
+template <bool TEXTBOOK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void preprocess_backward_kernel(ViewParams vp, msgs_gaussians_t g,
                                                                   const int32_t* __restrict__ radii,
                                                                   const char* __restrict__ geom,
@@ -606,7 +611,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
         // the nine sums, accumulated in grad_acc_t (double by default) and rounded to float ONCE here — the CPU oracle's
         // structure (double accumulators, one cast)
         float4 ga, gb, gc;
-        {
+        if constexpr (TEXTBOOK) {
+            const double* gr = reinterpret_cast<const double*>(grad_rec) + (size_t)i * 9;
+            ga = make_float4((float)gr[0], (float)gr[1], (float)gr[2], (float)gr[3]);
+            gb = make_float4((float)gr[4], (float)gr[5], (float)gr[6], (float)gr[7]);
+            gc = make_float4((float)gr[8], 0.f, 0.f, 0.f);
+        } else {
             const grad_acc_t* gr = grad_rec + (size_t)i * GRAD_REC_FLOATS;
             grad_acc_t t[GRAD_REC_FLOATS];
             typedef grad_acc_t acc2 __attribute__((ext_vector_type(2)));
@@ -621,9 +631,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
         }
         // blend_backward_kernel accumulates [sum q dx, sum q dy, sum q dx^2, sum q dx dy, sum q dy^2, sum q]
         // with q = alpha_raw dL/dalpha; the per-Gaussian constant factors are applied here (blend.hip).
-        const float gA = -0.5f * ga.z, gBh = -0.5f * ga.w, gC = -0.5f * gb.x;
+        const float gA = TEXTBOOK ? ga.z : -0.5f * ga.z, gBh = TEXTBOOK ? ga.w : -0.5f * ga.w,
+                    gC = TEXTBOOK ? gb.x : -0.5f * gb.x;
         const float o_in = act_opacity(g, i);
-        dopac = o_in > 0.f ? gb.y / o_in : 0.f;                         // (q / (o w)) * w, SPEC M4
+        if constexpr (TEXTBOOK)
+            dopac = reinterpret_cast<const float*>(geom + L.weight)[i] * gb.y;      // SPEC M4: dL/do = w dL/do_eff
+        else
+            dopac = o_in > 0.f ? gb.y / o_in : 0.f;                     // (q / (o w)) * w, SPEC M4
         if (raw) dopac = dopac * (o_in * (1.0f - o_in));                // through the sigmoid
         dcolr[0] = gb.z; dcolr[1] = gb.w; dcolr[2] = gc.x;
         fl = flags[i];
@@ -656,7 +670,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
         compute_cov2d(t, vp, cov3D, cm.V, c2);
         const float ca = c2.a, cb = c2.b, cc = c2.c;
         const float denom = ca * cc - cb * cb;
-        {
+        if constexpr (TEXTBOOK) {
+            g2x = ga.x; g2y = ga.y;
+        } else {
             // dL/dmean2D = sum q (u, w) with u = A' dx + Bh' dy, w = C' dy + Bh' dx and (A', Bh', C') the log2-scaled
             // conic exactly as preprocess_kernel built it for the record
             constexpr float KLOG = -0.72134752044448170368f;            // -1/2 log2(e)
@@ -963,8 +979,13 @@ hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, in
 
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
-                                      hipStream_t s) {
+                                      hipStream_t s, bool textbook) {
     if (g.P == 0) return hipSuccess;
+    if (textbook) {
+        hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
+                           grad_rec, grads);
+        return hipGetLastError();
+    }
     if (g.raw_params != 0 && grads.dL_dfeatures_dc == nullptr) {          // factored SH gradient: the factors first
         hipLaunchKernelGGL(sh_factor_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, g.P, radii, geom, grad_rec,
                            grads.dL_dcolors);
@@ -975,7 +996,7 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
             if (e != hipSuccess) return e;
         }
     }
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
+    hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
                        grad_rec, grads);
     return hipGetLastError();
 }

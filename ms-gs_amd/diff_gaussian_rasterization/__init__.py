@@ -18,6 +18,7 @@ this package without lib/libmsgs_hip.so raises ImportError, and calling it with 
 """
 import ctypes as C
 import os
+import threading
 import weakref
 from typing import NamedTuple
 
@@ -101,7 +102,8 @@ def _require_identity(t, name, value, flag):
     leaf = t.grad_fn is None
     if leaf:
         hit = _identity_checked.get(id(t))
-        if hit is not None and hit[0]() is t and hit[1] == t._version:
+        # (object, version, storage address): `param.data = other` keeps the first two
+        if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
             return
     if not bool((t.detach() == value).all().item()):
         raise NotImplementedError(
@@ -112,7 +114,7 @@ def _require_identity(t, name, value, flag):
         if len(_identity_checked) > 64:
             for k in [k for k, v in _identity_checked.items() if v[0]() is None]:
                 del _identity_checked[k]
-        _identity_checked[id(t)] = (weakref.ref(t), t._version)
+        _identity_checked[id(t)] = (weakref.ref(t), t._version, t.data_ptr())
 
 
 def _check_rows(name, t, P, tail):
@@ -216,13 +218,24 @@ def _backward_scratch(P, D, dev):
 _forward_clear = os.environ.get("MSGS_NO_FORWARD_CLEAR", "0") != "1"
 
 
+# grad mode of the CALLER, noted right before .apply(): inside autograd.Function.forward grad mode is always off, and
+# ctx.needs_input_grad is True under torch.no_grad() whenever the parameters require grad — every eval / viewer render of a
+# trained model would otherwise allocate and clear 80 bytes per Gaussian for a backward that never comes
+_caller = threading.local()
+
+
+def _note_grad_mode():
+    _caller.grad_enabled = torch.is_grad_enabled()
+
+
 def _alloc_grad_records(ctx, P, dev):
     """The backward's per-Gaussian gradient records have to start from zero.  When a backward can follow, the buffer is
     allocated HERE and handed to the forward, whose blend kernel clears it on the side (include/msgs.h, grad_records: the
     kernel is instruction-bound, the stores are free) — the backward then skips its fill launch.  Not in the verification
     mode, whose scratch is sized by the instance count."""
     ctx.grad_rec = None
-    if _forward_clear and P > 0 and any(ctx.needs_input_grad) and not _C.lib.msgs_get_deterministic():
+    if _forward_clear and P > 0 and getattr(_caller, "grad_enabled", True) and any(ctx.needs_input_grad) \
+            and not _C.lib.msgs_get_deterministic():
         ctx.grad_rec = _bytes(_C.lib.msgs_backward_scratch_bytes(P), dev)
     return ctx.grad_rec
 
@@ -238,7 +251,8 @@ def _take_backward_scratch(ctx, P, D, dev):
 
 
 def set_deterministic(on=True):
-    """Process-wide switch: bitwise-reproducible backward (no float atomics; ~0.4 ms slower at 1M Gaussians / 1080p).
+    """Process-wide switch: the verification backward, reproducible by construction (exact in-tile double sums, per-entry
+    stores, stable grouping by Gaussian: DESIGN.md 4.2); about 1.4 ms slower at 1M Gaussians / 1080p.
     Returns the previous setting.  The forward is always reproducible.  Also: MSGS_DETERMINISTIC=1 in the environment."""
     return bool(_C.lib.msgs_set_deterministic(1 if on else 0))
 
@@ -598,6 +612,7 @@ def sh_grad_from_views(means3D, gathered, n_views, sh_degree, scale, out_dc, out
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
                             max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
+    _note_grad_mode()
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
                                         rotation_raw, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta,
                                         base_mask, raster_settings)
@@ -605,6 +620,7 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta, base_mask, raster_settings):
+    _note_grad_mode()
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, max_pixel_sizes, min_pixel_sizes, occ_multiplier, dc_delta,
                                      base_mask, raster_settings)
@@ -691,6 +707,7 @@ class GaussianRasterizer(nn.Module):
                               "(cat / sigmoid / exp / normalize of leaf parameters); their backward runs in autograd")
             if leaves is not None:
                 o = lambda t: t if t is not None else empty
+                _note_grad_mode()
                 return _RasterizeGaussiansChained.apply(
                     means3D, means2D, *leaves, shs.detach() if _chain_reads_cat else empty, opacities.detach(), scales.detach(),
                     rotations.detach(),

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -114,6 +114,8 @@ def _load():
     lib.msgs_backward.restype = C.c_int
     lib.msgs_backward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, sz, C.c_int64, vp, sz, vp, sz,
                                   vp, vp, sz, C.POINTER(Grads), C.POINTER(Timing), vp]
+    lib.msgs_backward_per_gaussian.restype = C.c_int
+    lib.msgs_backward_per_gaussian.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, sz, vp, C.POINTER(Grads), vp]
     lib.msgs_sh_grad_from_views.restype = C.c_int
     lib.msgs_sh_grad_from_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, C.c_int64,
                                                 C.c_float, vp, vp, vp]
@@ -171,7 +173,7 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
            "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
-           "msgs_blend_lane_stats")
+           "msgs_blend_lane_stats", "msgs_backward_per_gaussian")
 
 
 def check(rc, where):

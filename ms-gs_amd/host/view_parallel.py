@@ -68,7 +68,8 @@ class PipelinedGradExchange:
     per optimizer step use FlatGradBucket.all_reduce directly.
 
         ex = PipelinedGradExchange(params, world)
-        for each view:  ex.begin_view(); loss.backward(); ex.end_view()
+        for each view:  ex.begin_view(); loss = criterion(render(...)); loss.backward(); ex.end_view()
+        (begin_view() BEFORE the forward: the rasterizer snapshots the registered sinks when it is called)
         ex.drain()                      # every exchange finished (stream-level), buckets hold the averaged grads
 
     xGMI is per-link bound, so the exchange of a 236 MB bucket costs about as much as a whole view at 8 GPUs; hiding
@@ -164,7 +165,9 @@ class FactoredGradExchange:
     small bucket is still in flight.  Exact: no quantisation, the same float32 terms in a different (fixed) summation order.
 
         ex = FactoredGradExchange(model, world)
-        ex.begin_view(); loss.backward(); ex.end_view(camera_center); ex.finish()     # then optimizer.step()
+        ex.begin_view(camera_center)          # BEFORE the forward: the sinks are snapshotted by the render call
+        loss = criterion(render(...)); loss.backward()
+        ex.end_view(); ex.finish()            # then optimizer.step()
 
     `model` carries the reference's leaf names (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation) and
     active_sh_degree.  The rasterizer must be called through its raw / chained entry (the reference's getters or
@@ -213,33 +216,50 @@ class FactoredGradExchange:
             set_sinks = set_sinks or dgr.set_grad_sinks
         self._reconstruct, self._set_sinks = reconstruct, set_sinks
 
-    def begin_view(self):
+    def begin_view(self, camera_center=None):
+        """Call BEFORE the forward (render) of the view: the rasterizer snapshots the registered sinks at forward time.
+        camera_center (optional here, else in end_view): written into the exchange row now, on the main stream, i.e.
+        ordered before the backward and its `factors ready` event."""
         for n in ("_features_dc", "_features_rest"):
             getattr(self.model, n).grad = None
         self.small.detach_grads()
+        self._cc_written = camera_center is not None
+        if camera_center is not None:
+            self.send[3 * self.P:3 * self.P + 3] = camera_center.to(self.send.device, torch.float32).reshape(3)
         if self.ready is not None:
             self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3), factors_ready=self.ready)
         else:
             self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3))
 
-    def end_view(self, camera_center):
+    def end_view(self, camera_center=None):
         """after backward(): issue both collectives (asynchronously; they run on the communicator's stream)"""
         self._set_sinks(None)
         b = self.small
         for p, v in zip(b.params, b.views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                raise RuntimeError("FactoredGradExchange: a gradient did not land in the bucket (the rasterizer was "
-                                   "not called through its raw / chained entry)")
+                raise RuntimeError("FactoredGradExchange: a gradient did not land in the bucket — either begin_view() was "
+                                   "called AFTER the forward (the sinks are snapshotted by the render call: begin_view(); "
+                                   "render(); backward(); end_view()), or the rasterizer was not called through its raw / "
+                                   "chained entry")
+        written = getattr(self, "_cc_written", False)
+        if camera_center is None and not written:
+            raise ValueError("FactoredGradExchange: the view's camera_center was given neither to begin_view nor to end_view")
         if self.active:
             op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
-            cc = camera_center.to(self.send.device, torch.float32).reshape(3)
+            cc, converted = None, False
+            if not written:
+                converted = camera_center.device != self.send.device or camera_center.dtype != torch.float32
+                cc = camera_center.to(self.send.device, torch.float32).reshape(3)
             if self.side is not None:
                 # the factors are final once `ready` has fired (before K9 ends): gather them from the side stream,
                 # concurrently with K9; the small bucket's all-reduce follows K9 on the main stream
                 main = torch.cuda.current_stream(self.send.device)
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(self.ready)
-                    self.send[3 * self.P:3 * self.P + 3] = cc
+                    if converted:                   # a real copy / cast was enqueued on the main stream: wait for it
+                        self.side.wait_stream(main)
+                    if cc is not None:
+                        self.send[3 * self.P:3 * self.P + 3] = cc
                     ag = dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True)
                 self.send.record_stream(self.side)
                 self.gathered.record_stream(self.side)
@@ -247,10 +267,11 @@ class FactoredGradExchange:
                 self.pending = [ag, ar]
                 self._main = main
             else:
-                self.send[3 * self.P:3 * self.P + 3] = cc
+                if cc is not None:
+                    self.send[3 * self.P:3 * self.P + 3] = cc
                 self.pending = [dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True),
                                 dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)]
-        else:
+        elif not written:
             self.send[3 * self.P:3 * self.P + 3] = camera_center.to(self.send.device, torch.float32).reshape(3)
 
     def finish(self):

@@ -397,9 +397,13 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     return MSGS_OK;
 }
 
-extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_view_t* view,
-                                    const msgs_gaussians_t* g, const float* dL_dcolor,
-                                    const msgs_grads_t* grads, int num_threads) {
+// sums2d_out (nullable, [P,9] doubles): the per-Gaussian 2-D gradient accumulators as they stand between the blend
+// backward (K7) and the per-Gaussian backward (K8 + K9): {dL/dmean2D x, y (NDC-ish units), dL/dconic A, B, C,
+// dL/dopacity_eff, dL/drgb[3]}.  The isolation test of tests/test_k8_isolation_gpu.py feeds exactly these to the HIP
+// per-Gaussian backward (msgs_backward_per_gaussian) and compares the two K8 + K9 stages on identical inputs.
+extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs_view_t* view,
+                                       const msgs_gaussians_t* g, const float* dL_dcolor,
+                                       const msgs_grads_t* grads, int num_threads, double* sums2d_out) {
     if (!st || !view || !g || !grads || !dL_dcolor) return MSGS_ERR_INVALID_ARG;
     if (num_threads > 0) omp_set_num_threads(num_threads);
     const int P = st->P, W = st->W, H = st->H, gx = st->gx, gy = st->gy;
@@ -468,6 +472,15 @@ extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_vi
                     }
                 }
             }
+    }
+
+    if (sums2d_out) {
+        for (int i = 0; i < P; ++i) {
+            const Acc& a = acc[i];
+            double* o = sums2d_out + (size_t)9 * i;
+            o[0] = a.mean2D[0]; o[1] = a.mean2D[1]; o[2] = a.conic[0]; o[3] = a.conic[1]; o[4] = a.conic[2];
+            o[5] = a.opacity; o[6] = a.color[0]; o[7] = a.color[1]; o[8] = a.color[2];
+        }
     }
 
     // ---- K8 (2-D covariance backward) + K9 (preprocess backward), App. A.3 ----
@@ -653,6 +666,12 @@ extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_vi
         }
     }
     return MSGS_OK;
+}
+
+extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_view_t* view,
+                                    const msgs_gaussians_t* g, const float* dL_dcolor,
+                                    const msgs_grads_t* grads, int num_threads) {
+    return msgs_oracle_backward_ex(st, view, g, dL_dcolor, grads, num_threads, nullptr);
 }
 
 extern "C" int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* s) { return (int64_t)s->list.size(); }

@@ -30,6 +30,12 @@ int msgs_oracle_backward(const msgs_oracle_state_t* state, const msgs_view_t* vi
                          const msgs_gaussians_t* g, const float* dL_dcolor,
                          const msgs_grads_t* grads, int num_threads);
 
+/* The same backward, also exporting (sums2d_out nullable, [P,9] doubles) the per-Gaussian 2-D gradient sums between the
+ * blend backward and the per-Gaussian backward: {dL/dmean2D x, y, dL/dconic A, B, C, dL/dopacity_eff, dL/drgb[3]}. */
+int msgs_oracle_backward_ex(const msgs_oracle_state_t* state, const msgs_view_t* view,
+                            const msgs_gaussians_t* g, const float* dL_dcolor,
+                            const msgs_grads_t* grads, int num_threads, double* sums2d_out);
+
 /* introspection for tests: number of (tile, Gaussian) instances, per-pixel final_T / n_contrib,
  * per-Gaussian rect and float32 depth */
 int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* state);

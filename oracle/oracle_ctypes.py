@@ -67,6 +67,9 @@ def lib():
         L.msgs_oracle_backward.restype = C.c_int
         L.msgs_oracle_backward.argtypes = [C.c_void_p, C.POINTER(View), C.POINTER(Gaussians), C.c_void_p,
                                            C.POINTER(Grads), C.c_int]
+        L.msgs_oracle_backward_ex.restype = C.c_int
+        L.msgs_oracle_backward_ex.argtypes = [C.c_void_p, C.POINTER(View), C.POINTER(Gaussians), C.c_void_p,
+                                              C.POINTER(Grads), C.c_int, C.c_void_p]
         L.msgs_oracle_num_instances.restype = C.c_int64
         L.msgs_oracle_num_instances.argtypes = [C.c_void_p]
         for name in ("traversed", "valid_pairs", "evaluated_pairs"):
@@ -187,8 +190,10 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     return r
 
 
-def backward(r, dL_dcolor, num_threads=0):
-    """Backward on an OracleResult; returns dict of CPU float32 gradient tensors."""
+def backward(r, dL_dcolor, num_threads=0, want_sums2d=False):
+    """Backward on an OracleResult; returns dict of CPU float32 gradient tensors.  want_sums2d: also "sums2d", the
+    [P,9] float64 per-Gaussian 2-D gradient sums between the blend backward and the per-Gaussian backward
+    (msgs_oracle.h, msgs_oracle_backward_ex)."""
     L = lib()
     P, K = r.P, r.K
     dl = _f32(dL_dcolor)
@@ -205,7 +210,11 @@ def backward(r, dL_dcolor, num_threads=0):
     gr = Grads(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out.get("shs")), _ptr(out.get("colors_precomp")),
                _ptr(out["opacities"]), _ptr(out.get("scales")), _ptr(out.get("rotations")),
                _ptr(out.get("cov3D_precomp")), None, None, None)
-    rc = L.msgs_oracle_backward(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), int(num_threads))
+    sums = torch.zeros(P, 9, dtype=torch.float64) if want_sums2d else None
+    rc = L.msgs_oracle_backward_ex(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), int(num_threads),
+                                   _ptr(sums))
     if rc != 0:
         raise RuntimeError(f"msgs_oracle_backward failed: {rc}")
+    if want_sums2d:
+        out["sums2d"] = sums
     return out

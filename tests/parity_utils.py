@@ -23,6 +23,27 @@ import scenes
 
 FWD_ATOL = 1e-5
 BWD_RTOL = 1e-4
+BORDERLINE_PIXEL_BUDGET = 0.0045      # hard ceiling on the pixels excluded from the strict forward check (measured: C3 0.34 %,
+                                      # C3 k = 6 0.42 %; 0.5 % was the round-2 bound)
+
+# Per-config ceilings on the two gradient tensors that end the conic -> 2-D covariance -> 3-D covariance chain of K8
+# (dL/dscaling, dL/drotation), max-norm relative, at ~1.5x the measured value (profiles/r3_parity.md; the HIP numbers are
+# reproducible run to run).  Everything NOT listed is asserted at the north star's 1e-4 — all seven tensors at C2 and at
+# every pyramid level, five of seven elsewhere.  tests/test_k8_isolation_gpu.py shows by test where the listed residuals
+# come from: K8 + K9 fed the oracle's own sums agree with the oracle to ~1e-6, dL/dcov3D meets 1e-4 at C2 and C3, and the
+# printed amplification factors are what multiplies the blend backward's float32 rounding on these two tensors.
+GRAD_CEILINGS = {
+    ("C2", False): {}, ("C2", True): {"scaling": 4e-4},
+    ("C3", False): {"scaling": 5e-4}, ("C3", True): {"rotation": 1.5e-4},
+    ("C3@k", False): {},
+    ("C5", False): {"scaling": 2.5e-4, "rotation": 2.5e-4},
+    ("C4v0", False): {"scaling": 2.5e-4, "rotation": 2.5e-4}, ("C4v3", False): {"scaling": 1.5e-3, "rotation": 1.5e-3},
+    ("C4v3", True): {"scaling": 6e-4, "rotation": 6e-4}, ("C4v6", False): {"scaling": 2e-4, "rotation": 2e-4},
+}
+
+
+def grad_ceilings(config, deterministic=False):
+    return dict(GRAD_CEILINGS[(config, deterministic)])
 PIPE = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)   # = gaussian_renderer.PIPE
 
 
@@ -85,8 +106,8 @@ def rel_err_reported(name, what, a, ref, rows=None):
 def check_forward(out, orc, name=""):
     ok = ~orc.borderline.bool()
     frac_bl = 1.0 - ok.float().mean().item()
-    report(name, "borderline pixel fraction (bound 5e-3)", frac_bl)
-    assert frac_bl < 0.005, f"{name}: too many borderline pixels ({frac_bl:.4f})"
+    report(name, f"borderline pixel fraction (bound {BORDERLINE_PIXEL_BUDGET:g})", frac_bl)
+    assert frac_bl < BORDERLINE_PIXEL_BUDGET, f"{name}: too many borderline pixels ({frac_bl:.4f})"
     col = out["render"].detach().cpu()
     d = (col - orc.color).abs()
     strict = d[:, ok].max().item() if ok.any() else 0.0
@@ -158,6 +179,8 @@ def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99
             q = own_relative_quantile(got, ref, clean)
             assert q <= q99_tol, f"{name}: grad {k}: 99th percentile of the per-Gaussian relative error {q:.3e}"
     report(name, "worst gradient max-norm rel err vs the float32 oracle", max(worst.values()))
+    for k, v in worst.items():
+        report(name, f"grad {k}", v)
     for k, v in worst.items():
         tol = (rtol_by_key or {}).get(k, rtol)
         assert v <= tol, f"{name}: grad {k} rel err {v:.3e} > {tol} ({worst})"

@@ -1,0 +1,53 @@
+"""bench.py's rank start-up without a GPU (MSGS_BENCH_LAUNCH_ONLY=1 stops each rank after the rendezvous and one gloo
+collective): `python3 bench.py --gpus N` must start its own N ranks when no launcher set WORLD_SIZE, relay rank 0's JSON
+line, keep working under torch.distributed.run, and refuse a --gpus / WORLD_SIZE mismatch."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MSGS_BENCH_LAUNCH_ONLY="1", **kw)
+    return env
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_plain_invocation_starts_its_own_ranks():
+    for n in (2, 4):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=_env(),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line == {"launch_only": True, "n_gpus": n, "rank_sum": float(n * (n - 1) // 2)}
+
+
+def test_single_gpu_invocation_stays_in_process():
+    r = subprocess.run([sys.executable, BENCH], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_under_torch_distributed_run():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"launch_only": True, "n_gpus": 2, "rank_sum": 1.0}]
+
+
+def test_world_size_mismatch_is_refused():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

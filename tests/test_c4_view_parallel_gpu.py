@@ -9,14 +9,13 @@ import torch
 import torch.distributed as dist
 
 import scenes
-from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_err_reported
+from parity_utils import PIPE, check_backward, check_forward, grad_ceilings, hip_render, rel_err_reported
 
 pytestmark = pytest.mark.gpu
 LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
-# tests/test_fullsize_gpu.py, profiles/r2_parity_floor.md: 1e-4 on xyz / SH / opacity / means2D; dL/dscaling and dL/drotation
-# (K8's amplification of chance-sized float32 differences) at 2e-3 in the default mode (measured 9.9e-4 on view 3) and 5e-4 in
-# the deterministic mode (measured 3.8e-4)
-TIGHT_RTOL, LOOSE, LOOSE_DET = 1e-4, 2e-3, 5e-4
+# 1e-4 on xyz / SH / opacity / means2D; dL/dscaling and dL/drotation (K8's amplification of chance-sized float32
+# differences, tests/test_k8_isolation_gpu.py) at per-view ceilings ~1.5x the measured value (parity_utils.GRAD_CEILINGS)
+TIGHT_RTOL = 1e-4
 FULL_Q99 = 1e-4
 
 
@@ -57,9 +56,8 @@ def test_c4_ring_views_vs_oracle(c4, v, det):
     orc = oc.rasterize(pc.seen, cam, st, bg)
     og = oc.backward(orc, dL)
     check_forward(out, orc, f"C4 view {v}")
-    loose = LOOSE_DET if det else LOOSE
     worst = check_backward(pc, m2, og, f"C4 view {v}" + (" deterministic" if det else ""), flagged=orc.borderline_gaussians,
-                           rtol=TIGHT_RTOL, rtol_by_key={"scaling": loose, "rotation": loose}, q99_tol=FULL_Q99)
+                           rtol=TIGHT_RTOL, rtol_by_key=grad_ceilings(f"C4v{v}", det), q99_tol=FULL_Q99)
     V = int((orc.radii > 0).sum())
     print(f"C4 view {v}: V={V} D_ref={orc.num_instances} borderline px {orc.borderline.float().mean().item():.5%} "
           f"borderline Gaussians {orc.borderline_gaussians.float().mean().item():.4%} worst {max(worst.values()):.2e}")

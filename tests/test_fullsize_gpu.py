@@ -1,33 +1,26 @@
-"""Full-size GPU tests on the BASELINE.json configurations: direct comparison with the CPU oracle at C2 and
-C3, plus size-independent properties (sortedness of every tile list, checksum of tile ranges, background
-and gradient linearity, determinism).
+"""Full-size GPU tests on the BASELINE.json configurations: direct comparison with the CPU oracle at C2, C3, the C3 pyramid
+and C5, plus size-independent properties (sortedness of every tile list, checksum of tile ranges, background and gradient
+linearity, determinism).
 
-Gradient tolerance at full size (measured, profiles/r2_parity_floor.md; every number below is reproducible run to run —
-the default backward adds the tiles' float32 sums with float64 atomics).  Five of the seven gradient tensors (xyz, both SH
-tensors, opacity, means2D) meet the north star's 1e-4 max-norm at every size in both modes and are asserted at 1e-4.
-dL/dscaling and dL/drotation end the conic -> covariance chain of K8, which amplifies any difference in the per-Gaussian
-sums by the squared aspect ratio of the footprint; two float32 evaluations of the blend differ there by chance-sized
-amounts: HIP vs oracle 0.6e-4 .. 3.2e-4 at C2 / C3 / C5 (both modes), up to 1.0e-3 on one C4 view in the default mode
-(3.8e-4 in the deterministic mode, whose in-tile sums are exact), while the float32 reference algorithm itself moves by
-3e-4 .. 1.2e-3 when the same oracle source is compiled with FMA contraction and every float32 evaluation (oracle, HIP)
-sits 3e-4 .. 1.7e-3 from the float64 truth.  Asserted: (i) max-norm <= 1e-4 on the five tight tensors, (ii) <= LOOSE
-(2e-3, default mode) resp. LOOSE_DET (5e-4, deterministic mode) on scaling / rotation, (iii) the 99th percentile of the
-per-Gaussian error relative to the Gaussian's own gradient <= 1e-4 (measured 8e-6) — all on the Gaussians without a
-borderline alpha decision, whose achieved fraction every test prints."""
+Gradient tolerance at full size: the north star's 1e-4 max-norm on EVERY tensor at C2 and at every pyramid level, and on five
+of the seven tensors (xyz, both SH tensors, opacity, means2D) everywhere else.  dL/dscaling and dL/drotation end the conic
+-> covariance chain of K8, which multiplies whatever two float32 evaluations of the blend backward differ by with the
+squared aspect ratio of the footprint; they carry per-config ceilings at ~1.5x the measured value (parity_utils.GRAD_CEILINGS,
+profiles/r3_parity.md) instead of one flat number, so a regression at any config trips its own ceiling.  That this residual is
+the blend's per-pixel rounding x conditioning — and not K8 / K9 — is established by test in tests/test_k8_isolation_gpu.py.
+Also asserted: the 99th percentile of the per-Gaussian error relative to the Gaussian's own gradient <= 1e-4 (measured
+8e-6) — all on the Gaussians without a borderline alpha decision, whose achieved fraction every test prints."""
 TIGHT_RTOL = 1e-4
-LOOSE, LOOSE_DET = 2e-3, 5e-4
 LINEARITY_RTOL = {"_scaling": 1e-3, "_rotation": 3e-4}       # measured 2.5e-4 / 5.9e-5; the other tensors <= 1.5e-6
 LINEARITY_RTOL_DEFAULT = 1e-5
 FULL_Q99 = 1e-4
-FULL_TOL = {"scaling": LOOSE, "rotation": LOOSE}
-FULL_TOL_DET = {"scaling": LOOSE_DET, "rotation": LOOSE_DET}
 import ctypes as C
 
 import pytest
 import torch
 
 import scenes
-from parity_utils import PIPE, check_backward, check_forward, hip_render, rel_err, rel_err_reported
+from parity_utils import PIPE, check_backward, check_forward, grad_ceilings, hip_render, rel_err, rel_err_reported
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +39,8 @@ def test_config_c2_forward_backward_vs_oracle():
     out, pc, m2 = hip_render(sc, cam, st, bg, dL)
     orc, og = _oracle(pc.seen, cam, st, bg, dL)
     check_forward(out, orc, "C2")
-    check_backward(pc, m2, og, "C2", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=FULL_TOL, q99_tol=FULL_Q99)
+    check_backward(pc, m2, og, "C2", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=grad_ceilings("C2"),
+                   q99_tol=FULL_Q99)
 
 
 def test_config_c2_three_way_with_float64_truth():
@@ -78,7 +72,7 @@ def test_config_c2_three_way_with_float64_truth():
     report("C2", "forward, HIP vs float64 truth", e_hip)
     assert e_hip <= 1.25 * e_orc + 1e-6
     # gradients: HIP (atomic, deterministic) vs the float32 oracle, and everything vs the truth
-    check_backward(pc_d, m2_d, og, "C2 deterministic", flagged=flagged, rtol=TIGHT_RTOL, rtol_by_key=FULL_TOL_DET)
+    check_backward(pc_d, m2_d, og, "C2 deterministic", flagged=flagged, rtol=TIGHT_RTOL, rtol_by_key=grad_ceilings("C2", True))
     to_f32 = {k: v.float() for k, v in tg.items()}
     w_hip_truth = check_backward(pc, m2, to_f32, "C2 HIP vs truth", flagged=flagged, rtol=1.0)
     names = {"means3D": "_xyz", "features_dc": "_features_dc", "features_rest": "_features_rest", "opacity": "_opacity",
@@ -111,7 +105,8 @@ def test_config_c3_forward_backward_vs_oracle(c3):
     out, pc, m2 = hip_render(sc, cam, st, bg, dL)
     orc, og = _oracle(pc.seen, cam, st, bg, dL)
     check_forward(out, orc, "C3")
-    check_backward(pc, m2, og, "C3", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=FULL_TOL, q99_tol=FULL_Q99)
+    check_backward(pc, m2, og, "C3", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=grad_ceilings("C3"),
+                   q99_tol=FULL_Q99)
     assert (out["radii"] > 0).sum().item() == (orc.radii > 0).sum().item()
 
 
@@ -210,8 +205,8 @@ def test_c3_multiscale_pyramid_levels(c3):
         out, pc, m2 = hip_render(sc, cam, st, bg, dL)
         orc, og = _oracle(pc.seen, cam, st, bg, dL)
         check_forward(out, orc, f"C3@k={k}")
-        check_backward(pc, m2, og, f"C3@k={k}", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=FULL_TOL,
-                       q99_tol=FULL_Q99)
+        check_backward(pc, m2, og, f"C3@k={k}", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL,
+                       rtol_by_key=grad_ceilings("C3@k"), q99_tol=FULL_Q99)
         assert (out["radii"] > 0).sum() > 1000
 
 
@@ -234,4 +229,5 @@ def test_config_c5_stress_4k():
     assert (ranges[:, 1] - ranges[:, 0]).sum().item() + n_sentinel == D and 0 <= n_sentinel <= D // 200
     orc, og = _oracle(pc.seen, cam, st, bg, dL)
     check_forward(out, orc, "C5")
-    check_backward(pc, m2, og, "C5", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=FULL_TOL, q99_tol=FULL_Q99)
+    check_backward(pc, m2, og, "C5", flagged=orc.borderline_gaussians, rtol=TIGHT_RTOL, rtol_by_key=grad_ceilings("C5"),
+                   q99_tol=FULL_Q99)

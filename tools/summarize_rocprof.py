@@ -91,6 +91,7 @@ if fa and wa:
     json.dump({"source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing; mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction of MI355X_MICROARCH.md, HBM section)",
                "csrc_sha256": csrc_sha256(), "kernels": traffic}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 
+sq_json = None
 for sub, name in (("pmc_sq", "pmc_sq.csv"), ("pmc_sq2", "pmc_sq2.csv")):
     a, d = counters(sub)
     if not a:
@@ -103,10 +104,18 @@ for sub, name in (("pmc_sq", "pmc_sq.csv"), ("pmc_sq2", "pmc_sq2.csv")):
         for k in order[:24]:
             n = len(d[k])
             out.write(k + ",%d," % n + ",".join("%.4g" % (a[k][c] / n) for c in names) + "\n")
+    if sub == "pmc_sq2" and sq_json is not None:      # second counter pass (LDS instructions, waits) joins the same keys
+        for k in a:
+            kk = re.sub(r"<.*$", "", k)
+            if kk in sq_json["kernels"] and len(d[k]) >= sq_json["_launches"].get(kk, 0):
+                sq_json["kernels"][kk].update({c: a[k][c] / len(d[k]) for c in names})
+        sq_json.pop("_launches")
+        json.dump(sq_json, open(os.path.join(dst, "sq.json"), "w"), indent=1)
     if sub == "pmc_sq":       # machine-readable twin for bench.py's informational VALU field
-        json.dump({"source": "rocprofv3 --pmc " + " ".join(names) + " -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing; mean per launch",
+        sq_json = {"_launches": {re.sub(r"<.*$", "", k): len(d[k]) for k in sorted(order[:24], key=lambda k: len(d[k]))}}
+        sq_json.update({"source": "rocprofv3 --pmc " + " ".join(names) + " -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing; mean per launch",
                    "csrc_sha256": csrc_sha256(),
                    # template variants share a key: keep the one launched most often (the hot one)
                    "kernels": {kk: vv for kk, vv in reversed([(re.sub(r"<.*$", "", k), {c: a[k][c] / len(d[k]) for c in names})
-                                                              for k in sorted(order[:24], key=lambda k: -len(d[k]))])}},
-                  open(os.path.join(dst, "sq.json"), "w"), indent=1)
+                                                              for k in sorted(order[:24], key=lambda k: -len(d[k]))])}})
+        json.dump({k: v for k, v in sq_json.items() if k != "_launches"}, open(os.path.join(dst, "sq.json"), "w"), indent=1)
