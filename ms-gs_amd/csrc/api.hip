@@ -302,7 +302,10 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
     tm.begin(MSGS_K_BLEND_FWD);
     HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth,
                                  (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib),
+                                 (uint32_t*)(image + IL.tile_last),
                                  grad_records, grad_records ? GRAD_REC_BYTES * (size_t)P : 0, s));
+    if (grad_records)      // a backward will follow: give its one-wave-per-tile kernel a heaviest-first launch order
+        HIP_TRY(launch_tile_order(vp, (const uint32_t*)(image + IL.tile_last), (uint32_t*)(image + IL.tile_order), s));
     tm.end(MSGS_K_BLEND_FWD);
     return debug_sync(view, s);
 }
@@ -348,7 +351,7 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     else
         HIP_TRY(launch_blend_backward(vp, geom, (const uint32_t*)(binning + BL.ids), (const uint2*)(binning + BL.ranges),
                                       (const float*)(image + IL.final_T), (const uint32_t*)(image + IL.n_contrib),
-                                      dL_dcolor, grad_rec, s));
+                                      dL_dcolor, grad_rec, s, (const uint32_t*)(image + IL.tile_order)));
     tm.end(MSGS_K_BLEND_BWD);
     if ((rc = debug_sync(view, s))) return rc;
 

@@ -99,6 +99,23 @@ __device__ __forceinline__ void clear_slice(uint4* __restrict__ p, size_t n16) {
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Per-tile traversal length for the backward's launch order (ImageLayout::tile_last): the position behind the last entry any
+// pixel of the tile blended = the number of list entries the backward will walk for this tile — its work, to first order.
+// Also invalidates the previous frame's launch order (launch_tile_order re-validates it after this kernel).
+__device__ __forceinline__ void note_tile_last(uint32_t* s_wlast, int nwaves, uint32_t last, int tile, int w, int lane,
+                                               uint32_t* __restrict__ tile_last, uint32_t* __restrict__ order_flag) {
+    if (tile_last == nullptr) return;
+    const uint32_t wl = wave_max_u32(last);
+    if (lane == 0) s_wlast[w] = wl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (int k = 0; k < nwaves; ++k) m = max(m, s_wlast[k]);
+        tile_last[tile] = m;
+        if (blockIdx.x == 0 && order_flag) *order_flag = 0u;
+    }
+}
+
 // Per-pixel forward state and the walk over one wave's compacted entry list — shared by the quadrant-per-wave kernel
 // and the fine-grained (4x4 sub-block per wave) kernel, so that both evaluate every pixel with the same instructions in
 // the same order (bit-identical images, test_blend_granularities_agree).
@@ -210,9 +227,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
                                                             unsigned long long* __restrict__ lane_stats,
-                                                            uint4* __restrict__ clear_ptr, size_t clear_n16) {
+                                                            uint4* __restrict__ clear_ptr, size_t clear_n16,
+                                                            uint32_t* __restrict__ tile_last,
+                                                            uint32_t* __restrict__ order_flag) {
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ uint32_t s_mask[BATCH];
+    __shared__ uint32_t s_wlast[4];
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
     if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
@@ -271,6 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         }
     } else {
         forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+        note_tile_last(s_wlast, 4, inside ? last : 0u, tile, w, lane, tile_last, order_flag);
     }
 }
 
@@ -288,10 +309,13 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
-                                                            uint4* __restrict__ clear_ptr, size_t clear_n16) {
+                                                            uint4* __restrict__ clear_ptr, size_t clear_n16,
+                                                            uint32_t* __restrict__ tile_last,
+                                                            uint32_t* __restrict__ order_flag) {
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
     __shared__ __attribute__((aligned(16))) uint32_t s_list[16][BATCH + LIST_PAD];
+    __shared__ uint32_t s_wlast[16];
     clear_slice(clear_ptr, clear_n16);
     if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
 
@@ -359,6 +383,7 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
     forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    note_tile_last(s_wlast, 16, inside ? last : 0u, tile, w, lane, tile_last, order_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -701,8 +726,11 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
                                                                 float* __restrict__ out_depth,
                                                                 float* __restrict__ final_T,
                                                                 uint32_t* __restrict__ n_contrib,
-                                                                uint4* __restrict__ clear_ptr, size_t clear_n16) {
+                                                                uint4* __restrict__ clear_ptr, size_t clear_n16,
+                                                                uint32_t* __restrict__ tile_last,
+                                                                uint32_t* __restrict__ order_flag) {
     __shared__ float4 s_r0[WB], s_r1[WB], s_r2[WB];
+    __shared__ uint32_t s_wlast[1];
     clear_slice(clear_ptr, clear_n16);
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
@@ -762,6 +790,7 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
     fwd_quad_store(q1, bx + 8, by, vp, out_color, out_ps, out_depth, final_T, n_contrib);
     fwd_quad_store(q2, bx, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
     fwd_quad_store(q3, bx + 8, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+    note_tile_last(s_wlast, 1, max(max(q0.last, q1.last), max(q2.last, q3.last)), tile, 0, lane, tile_last, order_flag);
 }
 
 // 64-lane all-reduce of a double (deterministic mode only): the same butterfly as wave_allreduce_sum, every move on the two
@@ -852,13 +881,17 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                                                                  const float* __restrict__ final_T,
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
-                                                                 void* __restrict__ grad_out) {
+                                                                 void* __restrict__ grad_out,
+                                                                 const uint32_t* __restrict__ tile_order) {
     __shared__ float4 s_r0[WB], s_r1[WB];
     __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
                                                            // address register serves every LDS read of an entry
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    // launch order: heaviest tiles first inside every XCD's contiguous run (launch_tile_order) when the forward left a valid
+    // order behind, the plain XCD swizzle otherwise
+    int tile = swizzled_tile(blockIdx.x, num_tiles);
+    if (tile_order != nullptr && tile_order[num_tiles] == TILE_ORDER_MAGIC) tile = (int)tile_order[tile];
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
     const float bxf = (float)bx, byf = (float)by;
@@ -1019,9 +1052,77 @@ static bool bwd_v1(int tiles) {
     return forced ? forced == 1 : tiles < BWD_GEN2_MIN_TILES;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Launch order of the one-wave-per-tile backward.  A tile is ONE sequential wave there and a SIMD holds six of them, about eight
+// tiles per SIMD in total at 1080p: with tiles dispatched in image order the SIMDs run dry at very different times (measured:
+// the number of running waves falls linearly over the second half of the kernel).  Dispatching the heaviest tiles first
+// leaves only light tiles for the end.  Key = the forward's per-tile traversal length (tile_last), NOT the list length: with
+// early termination the two differ by 2.3x on average and by much more per tile.  One 1024-thread block per XCD run of the
+// swizzled order (the tiles of a run stay on their XCD): counting sort into 2048 bins of 8 entries, heaviest first.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int ORDER_BINS = 2048, ORDER_SHIFT = 3;
+__global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const uint32_t* __restrict__ tile_last,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_bin[ORDER_BINS];
+    __shared__ uint32_t s_wave[16];
+    const int per = num_tiles >> 3, main = per << 3;
+    const int x = blockIdx.x;                           // XCD run x: swizzled positions = tiles [x * per, (x + 1) * per)
+    const int tid = threadIdx.x;
+    for (int b = tid; b < ORDER_BINS; b += 1024) s_bin[b] = 0;
+    __syncthreads();
+    for (int j = tid; j < per; j += 1024) {
+        const uint32_t key = min(tile_last[x * per + j] >> ORDER_SHIFT, (uint32_t)(ORDER_BINS - 1));
+        atomicAdd(&s_bin[ORDER_BINS - 1 - key], 1u);    // bin 0 = heaviest
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 bins: two per thread
+    const uint32_t c0 = s_bin[2 * tid], c1 = s_bin[2 * tid + 1];
+    uint32_t v = c0 + c1;
+    const int lane = tid & 63, w = tid >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t n = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += n;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < w; ++k) base += s_wave[k];
+    const uint32_t ex = base + inc - v;
+    __syncthreads();
+    s_bin[2 * tid] = ex;
+    s_bin[2 * tid + 1] = ex + c0;
+    __syncthreads();
+    for (int j = tid; j < per; j += 1024) {
+        const uint32_t t = (uint32_t)(x * per + j);
+        const uint32_t key = min(tile_last[t] >> ORDER_SHIFT, (uint32_t)(ORDER_BINS - 1));
+        const uint32_t pos = atomicAdd(&s_bin[ORDER_BINS - 1 - key], 1u);
+        order[x * per + pos] = t;
+    }
+    if (x == 0) {
+        for (int t = main + tid; t < num_tiles; t += 1024) order[t] = (uint32_t)t;      // ragged tail: identity
+        if (tid == 0) order[num_tiles] = TILE_ORDER_MAGIC;     // visible to the backward through the stream order
+    }
+}
+}  // namespace
+
+static bool bwd_uses_tile_kernel(int tiles) {
+    return !(g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD))) && !bwd_v1(tiles);
+}
+
+hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, uint32_t* tile_order, hipStream_t s) {
+    static const bool off = [] { const char* e = getenv("MSGS_BWD_LPT"); return e && e[0] == '0'; }();
+    const int tiles = vp.gx * vp.gy;
+    if (off || tiles < 8 || !bwd_uses_tile_kernel(tiles)) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, s, tiles, tile_last, tile_order);
+    return hipGetLastError();
+}
+
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                uint32_t* n_contrib, void* clear_ptr, size_t clear_bytes, hipStream_t s) {
+                                uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s) {
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return clear_ptr && clear_bytes ? launch_zero(clear_ptr, clear_bytes, s) : hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
@@ -1037,21 +1138,24 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     }
     uint4* const cp = inline_clear ? reinterpret_cast<uint4*>(clear_ptr) : nullptr;
     const size_t cn = inline_clear ? clear_bytes / 16 : 0;
+    // tile_last sits in front of tile_order in the image state (ImageLayout): the order's validity word
+    uint32_t* order_flag = tile_last ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_last) +
+                                                                   align256(4 * (size_t)tiles)) + tiles : nullptr;
     if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
         hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib, cp, cn);
+                           out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
     else if (fwd_gen == 1)
         hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn);
+                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last, order_flag);
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
-                           out_ps, out_depth, final_T, n_contrib, cp, cn);
+                           out_ps, out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 grad_acc_t* grad_rec, hipStream_t s) {
+                                 grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order) {
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
@@ -1060,7 +1164,7 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
                            n_contrib, dL_dcolor, grad_rec);
     else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
-                           n_contrib, dL_dcolor, grad_rec);
+                           n_contrib, dL_dcolor, grad_rec, tile_order);
     else
         hipLaunchKernelGGL(blend_backward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);
@@ -1125,7 +1229,7 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
     hipError_t e = launch_zero(inst, sizeof(double) * DET_INST_FLOATS * (size_t)D, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
-                       n_contrib, dL_dcolor, inst);
+                       n_contrib, dL_dcolor, inst, (const uint32_t*)nullptr);
     e = hipMemcpyAsync(keys, ids, 4 * (size_t)D, hipMemcpyDeviceToDevice, s);      // the sort clobbers its input
     if (e != hipSuccess) return e;
     int bits = 1;
@@ -1146,7 +1250,7 @@ hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const
     if (tiles)
         hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, reinterpret_cast<const GaussRec*>(geom),
                            ids, ranges, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0);
+                           (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -44,6 +44,7 @@ constexpr int GRAD_REC_FLOATS = 12;     // accumulators per record (9 used)
 typedef double grad_acc_t;
 constexpr int GRAD_REC_FLOATS = 10;     // accumulators per record (9 used)
 #endif
+constexpr uint32_t TILE_ORDER_MAGIC = 0x4C505431u;
 constexpr size_t GRAD_REC_BYTES = sizeof(grad_acc_t) * GRAD_REC_FLOATS;
 constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode: the nine K7 sums (DOUBLES)
 
@@ -132,11 +133,17 @@ struct Stage2Scratch {
 };
 
 struct ImageLayout {
-    size_t final_T, n_contrib, total;
+    size_t final_T, n_contrib, tile_last, tile_order, total;
     __host__ __device__ ImageLayout(int64_t W, int64_t H) {
         size_t o = 0;
-        final_T = o;   o = align256(o + 4 * (size_t)(W * H));
-        n_contrib = o; o = align256(o + 4 * (size_t)(W * H));
+        const size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)((H + TILE - 1) / TILE);
+        final_T = o;    o = align256(o + 4 * (size_t)(W * H));
+        n_contrib = o;  o = align256(o + 4 * (size_t)(W * H));
+        tile_last = o;  o = align256(o + 4 * tiles);   // per tile: position behind the last entry any of its pixels blended
+                                                       // (written by the forward blend; = the entries the backward traverses)
+        tile_order = o; o = align256(o + 4 * (tiles + 1));   // backward launch order: heaviest tiles first inside every XCD's
+                                                       // run; word [tiles] = TILE_ORDER_MAGIC when valid (written by the
+                                                       // forward's order kernel, cleared by every forward blend)
         total = o;
     }
 };
@@ -380,10 +387,12 @@ hipError_t voxel_pool_average(const float* features, int F, const uint32_t* orde
 // blend.hip
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                uint32_t* n_contrib, void* clear_ptr, size_t clear_bytes, hipStream_t s);
+                                uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s);
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 grad_acc_t* grad_rec, hipStream_t s);
+                                 grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order = nullptr);
+// heaviest-first launch order of the one-wave-per-tile backward from the forward's per-tile traversal lengths
+hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, uint32_t* tile_order, hipStream_t s);
 hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                    unsigned long long* out3 /* device, zeroed inside */, hipStream_t s);
 hipError_t launch_binning_stats(const ViewParams& vp, int P, const int32_t* radii, const uint32_t* n_contrib,

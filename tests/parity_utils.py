@@ -36,9 +36,9 @@ GRAD_CEILINGS = {
     ("C2", False): {}, ("C2", True): {"scaling": 4e-4},
     ("C3", False): {"scaling": 5e-4}, ("C3", True): {"rotation": 1.5e-4},
     ("C3@k", False): {},
-    ("C5", False): {"scaling": 2.5e-4, "rotation": 2.5e-4},
-    ("C4v0", False): {"scaling": 2.5e-4, "rotation": 2.5e-4}, ("C4v3", False): {"scaling": 1.5e-3, "rotation": 1.5e-3},
-    ("C4v3", True): {"scaling": 6e-4, "rotation": 6e-4}, ("C4v6", False): {"scaling": 2e-4, "rotation": 2e-4},
+    ("C5", False): {"scaling": 2.5e-4},
+    ("C4v0", False): {"scaling": 1.3e-4, "rotation": 2.2e-4}, ("C4v3", False): {"scaling": 1.5e-3, "rotation": 4e-4},
+    ("C4v3", True): {"scaling": 6e-4, "rotation": 3.5e-4}, ("C4v6", False): {"scaling": 1.4e-4},
 }
 
 

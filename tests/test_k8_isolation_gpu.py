@@ -22,7 +22,7 @@ from parity_utils import hip_render, rel_err, report
 
 pytestmark = pytest.mark.gpu
 
-K8_RTOL = 2e-6            # measured: see the [parity] lines this test prints
+K8_RTOL = 1e-6            # measured 2e-8 on dL/dmeans3D, 0.0 (bit-equal) on the other five tensors at C2 and C3
 COV_RTOL = 1e-4           # north star
 
 
