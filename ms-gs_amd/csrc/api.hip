@@ -139,7 +139,8 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     // depth order of the Gaussians (not rendered -> key 0xFFFFFFFF -> sorted last, zero tiles)
     tm.begin(MSGS_K_DEPTH_SORT);
     HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(scratch + SL.keys_a),
-                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed));
+                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed,
+                             (uint32_t*)(geom + GL.nvalid)));
     tm.end(MSGS_K_DEPTH_SORT);
     if ((rc = debug_sync(view, s))) return rc;
 
@@ -179,7 +180,8 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     tm.begin(MSGS_K_SCAN);
     HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
-                               classic ? status_dev : nullptr, classic && polled ? t_host_dev : nullptr, ticket));
+                               classic ? status_dev : nullptr, classic && polled ? t_host_dev : nullptr, ticket,
+                               (const uint32_t*)(geom + GL.nvalid)));
     tm.end(MSGS_K_SCAN);
     if (!classic) {        // look-back sort / scan variants: watchdog flags join the status in a final tiny kernel
         const SortScratch SSL(P);

@@ -26,6 +26,7 @@ template <int EMIT_STAGE>
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids,
                                                    int64_t D, ZeroJob zj) {
+    // ranks 0 .. V-1 of the depth order are the Gaussians that stayed in the compacting depth sort (GeomLayout::nvalid)
     {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
         const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
         for (size_t t = t0; t < zj.n0; t += nt) zj.p0[t] = 0u;
@@ -39,13 +40,15 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
 
+    const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
     const int r0 = blockIdx.x * blockDim.x;
+    if (r0 >= V) return;
     const int r = r0 + threadIdx.x;
-    const int rlast = min(r0 + (int)blockDim.x, P) - 1;
+    const int rlast = min(r0 + (int)blockDim.x, V) - 1;
     uint32_t gi = 0, count = 0;
     int64_t off = 0;
     // the count of rank r is the difference of consecutive scanned offsets (coalesced; no gather of tiles[order[r]])
-    if (r < P) { gi = order[r]; off = offs[r]; count = (uint32_t)((r + 1 < P ? (int64_t)offs[r + 1] : D) - off); }
+    if (r < V) { gi = order[r]; off = offs[r]; count = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - off); }
     if (threadIdx.x == 0) s_range[0] = off;
     if (r == rlast) s_range[1] = min((int64_t)off + count, D);
     __syncthreads();

@@ -102,16 +102,20 @@ __device__ __forceinline__ void clear_slice(uint4* __restrict__ p, size_t n16) {
 // Per-tile traversal length for the backward's launch order (ImageLayout::tile_last): the position behind the last entry any
 // pixel of the tile blended = the number of list entries the backward will walk for this tile — its work, to first order.
 // Also invalidates the previous frame's launch order (launch_tile_order re-validates it after this kernel).
-__device__ __forceinline__ void note_tile_last(uint32_t* s_wlast, int nwaves, uint32_t last, int tile, int w, int lane,
-                                               uint32_t* __restrict__ tile_last, uint32_t* __restrict__ order_flag) {
+// The stored key estimates the backward's instruction count for the tile (/ 16): ~52 per traversed entry (record fetch, loop
+// control, the 64-lane reduction, the atomics) + ~36 per (quadrant, entry) evaluation, the latter counted as the entries the
+// forward's waves walked (`walked`, wave-uniform).
+__device__ __forceinline__ void note_tile_last(uint32_t* s_wlast, int nwaves, uint32_t last, uint32_t walked, int tile, int w,
+                                               int lane, uint32_t* __restrict__ tile_last,
+                                               uint32_t* __restrict__ order_flag) {
     if (tile_last == nullptr) return;
     const uint32_t wl = wave_max_u32(last);
-    if (lane == 0) s_wlast[w] = wl;
+    if (lane == 0) { s_wlast[w] = wl; s_wlast[nwaves + w] = walked; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t m = 0;
-        for (int k = 0; k < nwaves; ++k) m = max(m, s_wlast[k]);
-        tile_last[tile] = m;
+        uint32_t m = 0, q = 0;
+        for (int k = 0; k < nwaves; ++k) { m = max(m, s_wlast[k]); q += s_wlast[nwaves + k]; }
+        tile_last[tile] = (52u * m + 36u * q) >> 4;
         if (blockIdx.x == 0 && order_flag) *order_flag = 0u;
     }
 }
@@ -154,7 +158,7 @@ __device__ __forceinline__ void pad_list(uint32_t* lp, int cnt, int lane) {
 template <bool COUNT = false>
 __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
                                                  const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io,
-                                                 LaneStats* stats = nullptr) {
+                                                 uint32_t& walked, LaneStats* stats = nullptr) {
     // the state lives in LOCAL scalars while the list is walked (through the struct reference the compiler turned the
     // two selects of the update into EXEC-masked moves with duplicated loop-carried copies: +14 % VALU instructions)
     float T = st.T, C0 = st.C0, C1 = st.C1, C2 = st.C2, aps = st.aps, adp = st.adp;
@@ -188,11 +192,13 @@ __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, co
         T = blend ? test_T : T;
         last_off = blend ? off : last_off;
     };
-    for (int j = 0; j < cnt; j += LIST_PAD) {              // the list is padded to a multiple of four
+    int j = 0;
+    for (; j < cnt; j += LIST_PAD) {                       // the list is padded to a multiple of four
         if (alive == 0) break;
         const uint4 o = *reinterpret_cast<const uint4*>(lp + j);
         blend_entry(o.x); blend_entry(o.y); blend_entry(o.z); blend_entry(o.w);
     }
+    walked += (uint32_t)min(j, cnt);                       // wave-uniform: entries this wave evaluated (backward work estimate)
     st.T = T; st.C0 = C0; st.C1 = C1; st.C2 = C2; st.aps = aps; st.adp = adp;
     alive_io = alive;
     return last_off;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
                                                             uint32_t* __restrict__ order_flag) {
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ uint32_t s_mask[BATCH];
-    __shared__ uint32_t s_wlast[4];
+    __shared__ uint32_t s_wlast[8];
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
     if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
 
     FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
     LaneStats ls = {0u, 0u, 0u};
-    uint32_t last = 0;
+    uint32_t last = 0, walked = 0;
     // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
     // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
     // instruction count), and per-lane selects take their condition from the mask for free
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
             cnt += __popcll(b);
         }
         pad_list(s_list[w], cnt, lane);
-        const uint32_t last_off = forward_walk<COUNT>(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, &ls);
+        const uint32_t last_off = forward_walk<COUNT>(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked, &ls);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
     if (COUNT) {
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         }
     } else {
         forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-        note_tile_last(s_wlast, 4, inside ? last : 0u, tile, w, lane, tile_last, order_flag);
+        note_tile_last(s_wlast, 4, inside ? last : 0u, walked, tile, w, lane, tile_last, order_flag);
     }
 }
 
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
     __shared__ __attribute__((aligned(16))) uint32_t s_list[16][BATCH + LIST_PAD];
-    __shared__ uint32_t s_wlast[16];
+    __shared__ uint32_t s_wlast[32];
     clear_slice(clear_ptr, clear_n16);
     if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
 
@@ -333,19 +339,27 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t last = 0;
+    uint32_t last = 0, walked = 0;
     // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
     // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
     // instruction count), and per-lane selects take their condition from the mask for free
     uint64_t alive = __builtin_amdgcn_ballot_w64(inside);
 
+    // In this regime (at most a few workgroups per CU) nothing else hides the id -> record gather of a batch (two dependent
+    // global latencies, ~2 us of the ~4.5 us a batch takes): the NEXT batch's records are fetched into registers while the current
+    // one is classified and walked.
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+    if (tid < min(BATCH, len)) {
+        const uint32_t id = ids[range.x + tid];
+        p0 = rec[id].r0; p1 = rec[id].r1; p2 = rec[id].r2;
+    }
     for (int base = 0; base < len; base += BATCH) {
         if (__syncthreads_and(alive == 0)) break;    // barrier also protects the LDS batch
         const int n = min(BATCH, len - base);
-        if (tid < n) {
-            const uint32_t id = ids[range.x + base + tid];
-            const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
-            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
+        if (tid < n) { s_r0[tid] = doubled_w(p0); s_r1[tid] = p1; s_r2[tid] = p2; }
+        if (tid < BATCH && base + BATCH + tid < len) {
+            const uint32_t id = ids[range.x + base + BATCH + tid];
+            p0 = rec[id].r0; p1 = rec[id].r1; p2 = rec[id].r2;
         }
         __syncthreads();
         {   // classification spread over the 1024 threads: thread -> (record e, sub-block row g), four 4x4 rectangles each
@@ -379,11 +393,11 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
             cnt += __popcll(b);
         }
         pad_list(s_list[w], cnt, lane);
-        const uint32_t last_off = forward_walk(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive);
+        const uint32_t last_off = forward_walk(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
     forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    note_tile_last(s_wlast, 16, inside ? last : 0u, tile, w, lane, tile_last, order_flag);
+    note_tile_last(s_wlast, 16, inside ? last : 0u, walked >> 2, tile, w, lane, tile_last, order_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -615,16 +629,24 @@ __global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp
     const uint32_t aoff = row_reduce_component(lane);
 
     const int nb = ((int)tile_last + BATCH - 1) / BATCH;
+    // register prefetch of the next (nearer) batch, as in blend_forward_fine_kernel
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+    uint32_t pid = 0;
+    if (nb > 0 && tid < BATCH && (nb - 1) * BATCH + tid < (int)tile_last) {
+        pid = ids[range.x + (nb - 1) * BATCH + tid];
+        p0 = rec[pid].r0; p1 = rec[pid].r1; p2 = rec[pid].r2;
+    }
     for (int b = nb - 1; b >= 0; --b) {
         __syncthreads();                              // previous batch fully consumed (and flushed)
         const int base = b * BATCH;
         const int n = min(BATCH, (int)tile_last - base);
         if (tid < n) {
-            const uint32_t id = ids[range.x + base + tid];
-            const float4 r0 = rec[id].r0, r1 = rec[id].r1;
-            const float4 r2 = rec[id].r2;
-            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_b[tid] = r2.x; s_id[tid] = id;
-            s_tau[tid] = r2.w;
+            s_r0[tid] = doubled_w(p0); s_r1[tid] = p1; s_b[tid] = p2.x; s_id[tid] = pid;
+            s_tau[tid] = p2.w;
+        }
+        if (b > 0 && tid < BATCH) {                   // the batches in front of the last one are full
+            pid = ids[range.x + base - BATCH + tid];
+            p0 = rec[pid].r0; p1 = rec[pid].r1; p2 = rec[pid].r2;
         }
         __syncthreads();
         {   // classification spread over the 1024 threads: thread -> (record e, sub-block row g), four 4x4 rectangles each
@@ -730,7 +752,7 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
                                                                 uint32_t* __restrict__ tile_last,
                                                                 uint32_t* __restrict__ order_flag) {
     __shared__ float4 s_r0[WB], s_r1[WB], s_r2[WB];
-    __shared__ uint32_t s_wlast[1];
+    __shared__ uint32_t s_wlast[2];
     clear_slice(clear_ptr, clear_n16);
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
@@ -790,7 +812,10 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
     fwd_quad_store(q1, bx + 8, by, vp, out_color, out_ps, out_depth, final_T, n_contrib);
     fwd_quad_store(q2, bx, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
     fwd_quad_store(q3, bx + 8, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    note_tile_last(s_wlast, 1, max(max(q0.last, q1.last), max(q2.last, q3.last)), tile, 0, lane, tile_last, order_flag);
+    {
+        const uint32_t l = max(max(q0.last, q1.last), max(q2.last, q3.last));
+        note_tile_last(s_wlast, 1, l, 2u * __builtin_amdgcn_readfirstlane(wave_max_u32(l)), tile, 0, lane, tile_last, order_flag);
+    }
 }
 
 // 64-lane all-reduce of a double (deterministic mode only): the same butterfly as wave_allreduce_sum, every move on the two
@@ -872,6 +897,13 @@ __device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSumsT<A>& v, co
     return validm;
 }
 
+#if defined(MSGS_TRACE_TILES)
+// tool build (tools/trace_tiles.sh): per-tile {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID, tile, traversal length} of the
+// one-wave-per-tile backward, for the occupancy timeline in profiles/; never part of the product library
+__device__ unsigned long long* g_tile_trace = nullptr;
+__global__ void trace_set_kernel(unsigned long long* p) { g_tile_trace = p; }
+#endif
+
 // DET = true (deterministic mode): instead of atomics, the nine sums of tile entry j (its position in the sorted instance
 // array) are STORED to inst_grad[j][0..8]; det_reduce_kernel then adds every Gaussian's entries in a fixed order.
 template <bool DET>
@@ -891,7 +923,11 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     // launch order: heaviest tiles first inside every XCD's contiguous run (launch_tile_order) when the forward left a valid
     // order behind, the plain XCD swizzle otherwise
     int tile = swizzled_tile(blockIdx.x, num_tiles);
-    if (tile_order != nullptr && tile_order[num_tiles] == TILE_ORDER_MAGIC) tile = (int)tile_order[tile];
+    if (tile_order != nullptr) {
+        const uint32_t flag = tile_order[num_tiles];
+        if (flag == TILE_ORDER_MAGIC) tile = (int)tile_order[tile];                       // per XCD run
+        else if (flag == TILE_ORDER_MAGIC + 1u) tile = (int)tile_order[blockIdx.x];       // one global sequence
+    }
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
     const float bxf = (float)bx, byf = (float)by;
@@ -899,6 +935,9 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     const uint2 range = ranges[tile];
     const size_t N = (size_t)vp.W * vp.H;
 
+#if defined(MSGS_TRACE_TILES)
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     BwdQuad q0, q1, q2, q3;
     uint32_t ql0, ql1, ql2, ql3;                           // wave-uniform: last blended position per quadrant
     {
@@ -990,6 +1029,16 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             }
         }
     }
+#if defined(MSGS_TRACE_TILES)
+    if (!DET && g_tile_trace && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = g_tile_trace + 4ull * blockIdx.x;
+        o[0] = trace_t0; o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = ((unsigned long long)tile << 32) | tile_last;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1062,11 +1111,14 @@ static bool bwd_v1(int tiles) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int ORDER_BINS = 2048, ORDER_SHIFT = 3;
+// GLOBAL (one block): one heaviest-first sequence over all tiles, dealt to the XCDs round-robin by the dispatcher (block b ->
+// XCD b % 8): balances the XCDs against each other as well, at the price of the L2 locality of the contiguous runs.
+template <bool GLOBAL>
 __global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const uint32_t* __restrict__ tile_last,
                                                           uint32_t* __restrict__ order) {
     __shared__ uint32_t s_bin[ORDER_BINS];
     __shared__ uint32_t s_wave[16];
-    const int per = num_tiles >> 3, main = per << 3;
+    const int per = GLOBAL ? num_tiles : num_tiles >> 3, main = GLOBAL ? num_tiles : per << 3;
     const int x = blockIdx.x;                           // XCD run x: swizzled positions = tiles [x * per, (x + 1) * per)
     const int tid = threadIdx.x;
     for (int b = tid; b < ORDER_BINS; b += 1024) s_bin[b] = 0;
@@ -1103,7 +1155,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const u
     }
     if (x == 0) {
         for (int t = main + tid; t < num_tiles; t += 1024) order[t] = (uint32_t)t;      // ragged tail: identity
-        if (tid == 0) order[num_tiles] = TILE_ORDER_MAGIC;     // visible to the backward through the stream order
+        if (tid == 0) order[num_tiles] = TILE_ORDER_MAGIC + (GLOBAL ? 1u : 0u);     // visible to the backward through the stream order
     }
 }
 }  // namespace
@@ -1113,10 +1165,14 @@ static bool bwd_uses_tile_kernel(int tiles) {
 }
 
 hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, uint32_t* tile_order, hipStream_t s) {
-    static const bool off = [] { const char* e = getenv("MSGS_BWD_LPT"); return e && e[0] == '0'; }();
+    // MSGS_BWD_LPT = 0: plain XCD swizzle; 1: heaviest first inside every XCD's contiguous run; 2: one global sequence
+    static const int mode = [] { const char* e = getenv("MSGS_BWD_LPT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
     const int tiles = vp.gx * vp.gy;
-    if (off || tiles < 8 || !bwd_uses_tile_kernel(tiles)) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, s, tiles, tile_last, tile_order);
+    if (mode == 0 || tiles < 8 || !bwd_uses_tile_kernel(tiles)) return hipSuccess;
+    if (mode == 2)
+        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1), dim3(1024), 0, s, tiles, tile_last, tile_order);
+    else
+        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(8), dim3(1024), 0, s, tiles, tile_last, tile_order);
     return hipGetLastError();
 }
 
@@ -1265,3 +1321,10 @@ hipError_t launch_binning_stats(const ViewParams& vp, int P, const int32_t* radi
 }
 
 }  // namespace msgs
+
+#if defined(MSGS_TRACE_TILES)
+extern "C" int msgs_debug_set_tile_trace(void* p) {
+    hipLaunchKernelGGL(msgs::trace_set_kernel, dim3(1), dim3(1), 0, 0, (unsigned long long*)p);
+    return (int)hipDeviceSynchronize();
+}
+#endif

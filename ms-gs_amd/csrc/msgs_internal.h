@@ -51,7 +51,7 @@ constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode:
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct GeomLayout {
-    size_t rec, binrec, tiles, key, flags, weight, order, offs, total;
+    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, total;
     __host__ __device__ explicit GeomLayout(int64_t P) {
         size_t o = 0;
         rec = o;    o = align256(o + sizeof(GaussRec) * P);
@@ -62,7 +62,8 @@ struct GeomLayout {
         weight = o; o = align256(o + 4 * P);        // multi-scale fade weight
         order = o;  o = align256(o + 4 * P);        // Gaussian ids in depth order
         offs = o;   o = align256(o + 4 * P);        // exclusive scan of tiles[order[r]]
-        total = o + 256;
+        nvalid = o;                                 // one word: V = Gaussians that stayed in the (compacting) depth sort —
+        total = o + 256;                            // order[0..V) / offs[0..V) are the ranks the scan and the emit cover
     }
 };
 
@@ -332,13 +333,15 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // inputs are clobbered when more than one pass is needed.
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch /* SortScratch(n) */,
-                            hipStream_t s, bool pre_zeroed = false);
+                            hipStream_t s, bool pre_zeroed = false, uint32_t* n_valid_dev = nullptr);
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words);
 
 // out[r] = exclusive sum of in[gather ? gather[r] : r]; *total (device, u64) = grand total
+// n_ptr (optional, device word): the number of elements actually scanned, <= n (n sizes the grids)
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s,
-                              uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0);
+                              uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0,
+                              const uint32_t* n_ptr = nullptr);
 bool use_classic_sort();
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
                                  uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);

@@ -81,8 +81,10 @@ __device__ __forceinline__ void scan_store_items(uint32_t* out, int64_t base, in
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in,
                                                                    const uint32_t* __restrict__ gather,
                                                                    int64_t n, uint64_t* __restrict__ partials,
-                                                                   uint32_t* __restrict__ staged) {
+                                                                   uint32_t* __restrict__ staged,
+                                                                   const uint32_t* __restrict__ n_ptr) {
     __shared__ uint32_t s_wave[4];
+    if (n_ptr) n = (int64_t)*n_ptr;
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     if (gather) {
@@ -149,8 +151,10 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
 // `in` may alias `out` (in-place: every thread reads its SCAN_ITEMS values before it writes them)
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather,
                                                                   uint32_t* out, int64_t n,
-                                                                  const uint64_t* __restrict__ partials) {
+                                                                  const uint64_t* __restrict__ partials,
+                                                                  const uint32_t* __restrict__ n_ptr) {
     __shared__ uint32_t s_wave[4];
+    if (n_ptr) n = (int64_t)*n_ptr;
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     if (gather) {
@@ -188,20 +192,32 @@ __device__ __forceinline__ int64_t elem_index(int64_t chunk_base, int w, int r, 
 // With `gsum` (grouped path) the block histograms are stored block-major (hist[block][digit]) and the
 // per-(group of `gsize` blocks, digit) sums gsum[group][digit] are accumulated with atomics: with those every
 // scatter block derives its own output bases (no scan kernels at all).
-template <int ITEMS>
+// Compaction (depth sort of the rasterizer): with DROP the pass ignores keys equal to 0xFFFFFFFF (Gaussians that are not
+// rendered) — they are neither counted here nor written by the scatter, so the pass's output holds only the survivors, in
+// stable order — and the scatter publishes their number; the later passes take their element count from that device word
+// (n_ptr) and run over the survivors only: their grids are still sized for the upper bound, surplus blocks leave at once.
+template <int ITEMS, bool DROP = false>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
                                                                   int shift, uint32_t mask, int64_t nblocks,
                                                                   uint32_t* __restrict__ hist,
-                                                                  uint32_t* __restrict__ gsum, int gsize, int ngroups) {
+                                                                  uint32_t* __restrict__ gsum, int gsize, int ngroups,
+                                                                  const uint32_t* __restrict__ n_ptr = nullptr) {
     __shared__ uint32_t s_hist[256];
+    const int64_t chunk_base = (int64_t)blockIdx.x * (SORT_THREADS * ITEMS);
+    if (n_ptr) {
+        n = (int64_t)*n_ptr;
+        if (chunk_base >= n) return;                   // (its histogram row is never read: rows of EARLIER blocks only)
+    }
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t chunk_base = (int64_t)blockIdx.x * (SORT_THREADS * ITEMS);
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-        if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+        if (i < n) {
+            const uint32_t k = keys[i];
+            if (!DROP || k != 0xFFFFFFFFu) atomicAdd(&s_hist[(k >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     const uint32_t c = s_hist[threadIdx.x];
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ 
     }
 }
 
-template <bool STAGED, int ITEMS>
+template <bool STAGED, int ITEMS, bool DROP = false>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
@@ -244,11 +260,17 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
                                                                      int shift, uint32_t mask, int64_t nblocks,
                                                                      const uint32_t* __restrict__ hist_scanned,
                                                                      const uint32_t* __restrict__ gsum, int gsize,
-                                                                     int ngroups, bool gsum_is_base = false) {
+                                                                     int ngroups, bool gsum_is_base = false,
+                                                                     const uint32_t* __restrict__ n_ptr = nullptr,
+                                                                     uint32_t* __restrict__ n_out = nullptr) {
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, later per-wave global bases
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t chunk_base = (int64_t)blockIdx.x * (SORT_THREADS * ITEMS);
+    if (n_ptr) {
+        n = (int64_t)*n_ptr;
+        if (chunk_base >= n) return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
     __syncthreads();
@@ -258,8 +280,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-        const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        key[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        const bool valid = i < n && (!DROP || key[r] != 0xFFFFFFFFu);      // DROP: not-rendered Gaussians leave the sort here
         val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
         const uint32_t d = (key[r] >> shift) & mask;
         // match-any over the 8 digit bits
@@ -303,8 +325,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
             const uint32_t* hrow = hist_scanned + ((int64_t)g * gsize) * 256 + d;
 #pragma unroll 8
             for (int k = 0; k < nin; ++k) before += hrow[(int64_t)k * 256];
-            uint32_t dummy;
-            gbase = block_exclusive_scan(tot, s_wave, &dummy) + before;
+            uint32_t total;
+            gbase = block_exclusive_scan(tot, s_wave, &total) + before;
+            if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = total;     // survivors of a DROP pass
         } else {
             gbase = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
         }
@@ -321,7 +344,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-            if (i < n) {
+            if (i < n && (!DROP || key[r] != 0xFFFFFFFFu)) {
                 const uint32_t d = (key[r] >> shift) & mask;
                 const uint32_t pos = s_cnt[w][d] + rank[r];
                 keys_out[pos] = key[r];
@@ -333,13 +356,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     // STAGED: reorder the chunk by digit in LDS first, then write it out in local order — consecutive lanes write
     // consecutive addresses inside each digit run (a wave store touches a few runs instead of 64 scattered words)
     __shared__ uint32_t s_key[STAGED ? SORT_THREADS * ITEMS : 1], s_val[STAGED ? SORT_THREADS * ITEMS : 1], s_delta[256];
+    uint32_t nkept;                                                        // keys of this chunk that stay in the sort
     {
         const uint32_t d = threadIdx.x;
         uint32_t c[4], ltot = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { c[k] = s_cnt[k][d]; ltot += c[k]; }
-        uint32_t dummy;
-        const uint32_t lbase = block_exclusive_scan(ltot, s_wave, &dummy);   // position of digit d's run in the chunk
+        const uint32_t lbase = block_exclusive_scan(ltot, s_wave, &nkept);   // position of digit d's run in the chunk
         uint32_t run = lbase;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s_cnt[k][d] = run; run += c[k]; }
@@ -349,14 +372,14 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-        if (i < n) {
+        if (i < n && (!DROP || key[r] != 0xFFFFFFFFu)) {
             const uint32_t lp = s_cnt[w][(key[r] >> shift) & mask] + rank[r];
             s_key[lp] = key[r];
             s_val[lp] = val[r];
         }
     }
     __syncthreads();
-    const int nvalid = (int)min((int64_t)(SORT_THREADS * ITEMS), n - chunk_base);
+    const int nvalid = DROP ? (int)nkept : (int)min((int64_t)(SORT_THREADS * ITEMS), n - chunk_base);
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int j = r * SORT_THREADS + threadIdx.x;
@@ -603,7 +626,7 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
-                              uint64_t* host_mapped, uint64_t ticket) {
+                              uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr) {
     const int64_t nb = scan_blocks(n > 0 ? n : 1);
     if (n <= 0) {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total, status,
@@ -622,11 +645,11 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     // with a gather the first pass leaves the gathered values in `out` and the last pass scans `out` in place
     const bool stage = gather != nullptr && out != in;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
-                       stage ? out : (uint32_t*)nullptr);
+                       stage ? out : (uint32_t*)nullptr, n_ptr);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
                        (volatile uint64_t*)host_mapped, ticket);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
-                       stage ? (const uint32_t*)nullptr : gather, out, n, partials);
+                       stage ? (const uint32_t*)nullptr : gather, out, n, partials, n_ptr);
     return hipGetLastError();
 }
 
@@ -703,9 +726,40 @@ bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch
     return true;
 }
 
+namespace {
+__global__ void store_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+
+// one grouped pass (histogram + scatter) with ITEMS keys per thread; drop / n_ptr / n_out: compaction (radix_hist_kernel)
+template <int ITEMS>
+void launch_grouped_pass(const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v, int64_t n, int shift,
+                         uint32_t mask, int64_t nb, uint32_t* hist, uint32_t* gs, int gsize, int ngroups, bool drop,
+                         const uint32_t* n_ptr, uint32_t* n_out, hipStream_t s) {
+    const dim3 grid((unsigned)nb), block(SORT_THREADS);
+    if (drop) {
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, true>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
+                           (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, true>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
+                           mask, nb, hist, gs, gsize, ngroups, false, (const uint32_t*)nullptr, n_out);
+    } else {
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, false>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
+                           n_ptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, false>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
+                           mask, nb, hist, gs, gsize, ngroups, false, n_ptr, (uint32_t*)nullptr);
+    }
+}
+}  // namespace
+
+// n_valid_dev (optional, device word): COMPACTING sort — pairs whose key is 0xFFFFFFFF are dropped by the first pass, the
+// number of survivors V is written to *n_valid_dev, the remaining passes run over V pairs, and keys_out / vals_out hold the V
+// sorted survivors (the tail beyond V is unspecified).  Configurations without the compacting kernels sort all n pairs
+// (the dropped keys sort last) and report V = n: every consumer of *n_valid_dev stays correct either way.
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                            int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s, bool pre_zeroed) {
-    if (n <= 0) return hipSuccess;
+                            int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s, bool pre_zeroed,
+                            uint32_t* n_valid_dev) {
+    if (n <= 0) {
+        if (n_valid_dev) hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, n_valid_dev, 0u);
+        return hipSuccess;
+    }
     const SortScratch L(n);
     uint32_t* keys_alt = reinterpret_cast<uint32_t*>(scratch + L.keys_alt);
     uint32_t* vals_alt = reinterpret_cast<uint32_t*>(scratch + L.vals_alt);
@@ -742,6 +796,9 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
         hipLaunchKernelGGL(radix_hist_all_kernel, dim3(hb), dim3(256), 0, s, keys_in, n, begin_bit, end_bit, passes,
                            digit_hist);
     }
+    static const bool no_compact = [] { const char* e = getenv("MSGS_SORT_NO_COMPACT"); return e && e[0] == '1'; }();
+    const bool compact = n_valid_dev != nullptr && grouped && staged && !G.scanned && !no_compact;
+    if (n_valid_dev && !compact) hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, n_valid_dev, (uint32_t)n);
     // ping-pong so that the LAST pass writes keys_out/vals_out
     const uint32_t* src_k = keys_in;
     const uint32_t* src_v = vals_in;
@@ -765,32 +822,36 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
             // two kernels per pass: block histograms + group sums, then a scatter that derives its own bases
             uint32_t* gs = gsum_all + (size_t)p * 256 * ngroups;
             const dim3 grid((unsigned)nb), block(SORT_THREADS);
-            if (big) {
-                hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
-                if (G.scanned) hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, s, gs, ngroups);
+            const bool drop = compact && p == 0;
+            const uint32_t* np = compact && p > 0 ? n_valid_dev : nullptr;
+            uint32_t* no = drop ? n_valid_dev : nullptr;
+            if (big && G.scanned) {
+                hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
+                                   (const uint32_t*)nullptr);
+                hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, s, gs, ngroups);
                 hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                                   mask, nb, hist, gs, gsize, ngroups, G.scanned);
+                                   mask, nb, hist, gs, gsize, ngroups, true, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+            } else if (big) {
+                launch_grouped_pass<16>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np, no, s);
             } else if (mid) {
-                hipLaunchKernelGGL((radix_hist_kernel<8>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups);
-                hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                                   mask, nb, hist, gs, gsize, ngroups);
+                launch_grouped_pass<8>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np, no, s);
+            } else if (staged) {
+                launch_grouped_pass<SORT_ITEMS>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np,
+                                                no, s);
             } else {
                 hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
-                                   ngroups);
-                if (staged)
-                    hipLaunchKernelGGL((radix_scatter_kernel<true, SORT_ITEMS>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
-                                       shift, mask, nb, hist, gs, gsize, ngroups);
-                else
-                    hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
-                                       shift, mask, nb, hist, gs, gsize, ngroups);
+                                   ngroups, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
+                                   shift, mask, nb, hist, gs, gsize, ngroups, false, (const uint32_t*)nullptr, (uint32_t*)nullptr);
             }
         } else {
             hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask,
-                               nb, hist, (uint32_t*)nullptr, 1, 1);
+                               nb, hist, (uint32_t*)nullptr, 1, 1, (const uint32_t*)nullptr);
             hipError_t e = exclusive_scan_u32(hist, nullptr, hist, 256 * nb, partials, nullptr, s);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v,
-                               dst_k, dst_v, n, shift, mask, nb, hist, (const uint32_t*)nullptr, 1, 1);
+                               dst_k, dst_v, n, shift, mask, nb, hist, (const uint32_t*)nullptr, 1, 1, false,
+                               (const uint32_t*)nullptr, (uint32_t*)nullptr);
         }
         src_k = dst_k;
         src_v = dst_v;
