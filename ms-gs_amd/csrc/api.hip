@@ -108,6 +108,7 @@ int msgs_set_deterministic(int32_t on) { return g_deterministic.exchange(on ? 1 
 int msgs_get_deterministic(void) { return g_deterministic.load(); }
 int msgs_set_backward_generation(int32_t gen) { return set_backward_generation(gen); }
 int msgs_set_blend_granularity(int32_t mode) { return set_blend_granularity(mode); }
+int msgs_set_forward_variant(int32_t variant) { return set_forward_variant(variant); }
 
 int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
                         void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,

@@ -145,6 +145,9 @@ struct LaneStats { uint32_t steps, alive, blended; };
 // measured the same time and was not kept; eight entries per trip: 184 us, no gain.)
 constexpr int LIST_PAD = 4;
 constexpr uint32_t SENTINEL_OFF = (uint32_t)BATCH << 4;
+constexpr int SBATCH = 128;                                   // records per batch of the strip kernel (below)
+constexpr uint32_t SENTINEL_OFF_S = (uint32_t)SBATCH << 4;
+constexpr uint32_t SENTINEL_MIN = SENTINEL_OFF_S;             // offsets >= this are a sentinel in either kernel
 __device__ __forceinline__ void write_sentinel_record(float4* s_r0, float4* s_r1, float4* s_r2) {
     s_r0[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
     s_r1[BATCH] = make_float4(0.f, -1.0e30f, 0.f, 0.f);
@@ -180,7 +183,9 @@ __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, co
         const uint64_t validm = alive & m_pow & m_alpha;
         const uint64_t stopm = validm & m_stop;
         if (COUNT) {
-            if (__builtin_amdgcn_readfirstlane(off) != SENTINEL_OFF) {
+            // (per-row lists of the strip kernel: a trip counts when any row holds a real entry; a row on padding evaluates the
+            //  sentinel record and can never blend)
+            if (__builtin_amdgcn_ballot_w64(off < SENTINEL_MIN) != 0) {
                 stats->steps += 1u; stats->alive += (uint32_t)__popcll(alive); stats->blended += (uint32_t)__popcll(validm & ~stopm);
             }
         }
@@ -288,6 +293,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         pad_list(s_list[w], cnt, lane);
         const uint32_t last_off = forward_walk<COUNT>(s_list[w], cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked, &ls);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
+    }
+    if (COUNT) {
+        if (lane == 0) {
+            atomicAdd(&lane_stats[0], (unsigned long long)ls.steps);
+            atomicAdd(&lane_stats[1], (unsigned long long)ls.alive);
+            atomicAdd(&lane_stats[2], (unsigned long long)ls.blended);
+        }
+    } else {
+        forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
+        note_tile_last(s_wlast, 4, inside ? last : 0u, walked, tile, w, lane, tile_last, order_flag);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6, strip lists (gen 3): the same workgroup / wave / lane <-> pixel mapping as blend_forward_kernel, but every DPP ROW of a
+// wave — sixteen lanes = an 8x2 pixel strip of the wave's quadrant — walks its OWN entry list, the four rows in lock step:
+// in one trip row r evaluates entry j of list r.  An entry reaches an 8x2 strip far less often than an 8x8 quadrant, so the
+// longest of the four lists is shorter than the quadrant's list (simulated on the C3 scene: 0.84x the trips, lane efficiency
+// 0.53 -> 0.63), at the same instructions per trip: the walk is forward_walk unchanged, reading the list and the records
+// through per-lane LDS addresses (a ds_read_b128 serves a 16-lane row per pass either way).  Rows on a shorter list evaluate
+// the sentinel record.  Same arithmetic per pixel in the same order: outputs bit-identical to blend_forward_kernel.
+// Strip membership: the exact quadrant test of the loading thread AND
+//   STRIP_EXACT = false: the y-extent of the level set (gy +- sqrt(A tau / det), one sqrt per record) overlaps the strip's two
+//                        pixel rows — conservative (ignores the quadrant's x-range), ~12 instructions per 64 records and wave;
+//   STRIP_EXACT = true:  the exact 8x2 rectangle test (levelset_hits_rect) — four tests per (record, wave).
+// 128 records per batch: the sixteen lists of a workgroup (4 waves x 4 rows x 132 words) and the records fit 15 KB, so that
+// eight workgroups stay resident per CU (the walk is issue-bound and wants 8 waves per SIMD).
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT, bool STRIP_EXACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void blend_forward_strip_kernel(
+    ViewParams vp, const GaussRec* __restrict__ rec, const uint32_t* __restrict__ ids, const uint2* __restrict__ ranges,
+    float* __restrict__ out_color, float* __restrict__ out_ps, float* __restrict__ out_depth, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, unsigned long long* __restrict__ lane_stats, uint4* __restrict__ clear_ptr,
+    size_t clear_n16, uint32_t* __restrict__ tile_last, uint32_t* __restrict__ order_flag) {
+    __shared__ float4 s_r0[SBATCH + 1], s_r1[SBATCH + 1], s_r2[SBATCH + 1];     // slot SBATCH: the sentinel record
+    __shared__ uint32_t s_mask[SBATCH];
+    __shared__ float2 s_yr[SBATCH];                                              // y-extent of the alpha >= 1/255 level set
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][4][SBATCH + LIST_PAD];
+    __shared__ uint32_t s_wlast[8];
+    clear_slice(clear_ptr, clear_n16);
+    if (threadIdx.x == 0) {
+        s_r0[SBATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_r1[SBATCH] = make_float4(0.f, -1.0e30f, 0.f, 0.f);
+        s_r2[SBATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int num_tiles = vp.gx * vp.gy;
+    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tx = tile % vp.gx, ty = tile / vp.gx;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, row = lane >> 4;
+    const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (w >> 1) * 8 + (lane >> 3);
+    const bool inside = px < vp.W && py < vp.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const float qx0 = tx0 + (float)((w & 1) * 8), qy0 = ty0 + (float)((w >> 1) * 8);   // this wave's quadrant
+
+    FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    LaneStats ls = {0u, 0u, 0u};
+    uint32_t last = 0, walked = 0;
+    uint64_t alive = __builtin_amdgcn_ballot_w64(inside);
+    uint32_t* const my_list = s_list[w][row];
+
+    for (int base = 0; base < len; base += SBATCH) {
+        if (__syncthreads_and(alive == 0)) break;    // barrier also protects the LDS batch
+        const int n = min(SBATCH, len - base);
+        if (tid < n) {
+            const uint32_t id = ids[range.x + base + tid];
+            const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
+            s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
+            // y-extent of {f >= tau2}: |dy| <= sqrt(A tau2 / det) (levelset_rows_setup); everything when it cannot be bounded
+            float ylo = -3.0e38f, yhi = 3.0e38f;
+            if (r2.w > -1.0e38f) {
+                const float det = r0.z * r1.x - r0.w * r0.w;
+                const float e = sqrtf(fmaxf(0.0f, (r0.z * r2.w) / det)) + 0.05f;
+                if (det > 0.0f && e == e) { ylo = r0.y - e; yhi = r0.y + e; }
+            }
+            s_yr[tid] = make_float2(ylo, yhi);
+        }
+        __syncthreads();
+        // four row lists per wave: ballot + popcount prefix per strip
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+        for (int c = 0; c < SBATCH / 64; ++c) {
+            const int e = c * 64 + lane;
+            const bool hitq = e < n && ((s_mask[e] >> w) & 1u);
+            bool b0 = false, b1 = false, b2 = false, b3 = false;
+            if (hitq) {
+                if (STRIP_EXACT) {
+                    const float4 r0 = s_r0[e];
+                    const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                    if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
+                    else {
+                        b0 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0, qy0 + 1.0f);
+                        b1 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0 + 2.0f, qy0 + 3.0f);
+                        b2 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0 + 4.0f, qy0 + 5.0f);
+                        b3 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0 + 6.0f, qy0 + 7.0f);
+                    }
+                } else {
+                    const float2 yr = s_yr[e];
+                    b0 = yr.x <= qy0 + 1.0f && yr.y >= qy0;
+                    b1 = yr.x <= qy0 + 3.0f && yr.y >= qy0 + 2.0f;
+                    b2 = yr.x <= qy0 + 5.0f && yr.y >= qy0 + 4.0f;
+                    b3 = yr.x <= qy0 + 7.0f && yr.y >= qy0 + 6.0f;
+                }
+            }
+            const uint32_t off = (uint32_t)(e << 4);
+            const uint64_t B0 = __ballot(b0), B1 = __ballot(b1), B2 = __ballot(b2), B3 = __ballot(b3);
+            if (b0) s_list[w][0][c0 + __popcll(B0 & lt_mask)] = off;
+            if (b1) s_list[w][1][c1 + __popcll(B1 & lt_mask)] = off;
+            if (b2) s_list[w][2][c2 + __popcll(B2 & lt_mask)] = off;
+            if (b3) s_list[w][3][c3 + __popcll(B3 & lt_mask)] = off;
+            c0 += __popcll(B0); c1 += __popcll(B1); c2 += __popcll(B2); c3 += __popcll(B3);
+        }
+        // lock step: the trip count is the longest list (rounded up to the four entries of a trip); shorter lists are padded
+        // with the sentinel record by their own sixteen lanes
+        const int cnt = (max(max(c0, c1), max(c2, c3)) + LIST_PAD - 1) & ~(LIST_PAD - 1);
+        const int mine = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
+        for (int j = mine + (lane & 15); j < cnt; j += 16) my_list[j] = SENTINEL_OFF_S;
+        const uint32_t last_off = forward_walk<COUNT>(my_list, cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked, &ls);
+        if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;
     }
     if (COUNT) {
         if (lane == 0) {
@@ -1077,7 +1206,7 @@ __global__ __launch_bounds__(256) void visible_count_kernel(int P, const int32_t
 // -fno-slp-vectorize, which alone took the backward from 558 to 495 us.)
 static int env_gen(const char* name, int dflt) {
     const char* e = getenv(name);
-    return (e && e[0] >= '1' && e[0] <= '2') ? e[0] - '0' : dflt;
+    return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : dflt;
 }
 // backward generation: MSGS_BWD_GEN = 1 | 2 forces one; default (0) picks by tile count — one wave per tile (gen 2) needs
 // >= ~4000 tiles to occupy 1024 SIMDs, below that four waves per tile (gen 1) win (C3 scene, profiles/r1_notes.md:
@@ -1087,6 +1216,11 @@ constexpr int BWD_GEN2_MIN_TILES = 4096;
 // forward 510 tiles 109 -> 100 us, 135 tiles 184 -> 112, 40 tiles 285 -> 161; backward 510 tiles 167 -> 184 (worse),
 // 135 tiles 262 -> 185, 40 tiles 372 -> 236
 constexpr int FINE_MAX_TILES_FWD = 600, FINE_MAX_TILES_BWD = 300;
+// forward kernel variant: 1 = quadrant lists (one 8x8 quadrant per wave), 2 = one wave per tile, 3 = 8x2 strip lists with the
+// y-extent strip test, 4 = strip lists with the exact strip test; MSGS_FWD_GEN / msgs_set_forward_variant
+constexpr int FWD_GEN_DEFAULT = 1;
+static std::atomic<int> g_fwd_gen{env_gen("MSGS_FWD_GEN", FWD_GEN_DEFAULT)};
+int set_forward_variant(int v) { return g_fwd_gen.exchange(v >= 1 && v <= 4 ? v : FWD_GEN_DEFAULT); }
 static std::atomic<int> g_bwd_gen{[] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen == 2 ? gen : 0); }
 // blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
@@ -1182,7 +1316,7 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return clear_ptr && clear_bytes ? launch_zero(clear_ptr, clear_bytes, s) : hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
-    static const int fwd_gen = env_gen("MSGS_FWD_GEN", 1);
+    const int fwd_gen = g_fwd_gen.load();
     // the gradient records are cleared by the blend kernel itself when it has enough workgroups to spread the stores over the
     // chip; with few tiles (low pyramid levels: 2 .. 500 workgroups, measured 150 -> 410 us at 2 tiles for 80 MB) a fill
     // kernel in front of it is faster
@@ -1203,6 +1337,17 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     else if (fwd_gen == 1)
         hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last, order_flag);
+    else if (fwd_gen == 3 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 8x2 strip lists, strips by the level set's y-extent
+        hipLaunchKernelGGL((blend_forward_strip_kernel<false, false>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
+                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
+                           order_flag);
+    else if (fwd_gen == 4 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 8x2 strip lists, exact strip test
+        hipLaunchKernelGGL((blend_forward_strip_kernel<false, true>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
+                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
+                           order_flag);
+    else if (fwd_gen >= 3)
+        hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
                            out_ps, out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
@@ -1303,8 +1448,17 @@ hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const
     hipError_t e = hipMemsetAsync(out3, 0, 24, s);
     if (e != hipSuccess) return e;
     const int tiles = vp.gx * vp.gy;
-    if (tiles)
-        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, reinterpret_cast<const GaussRec*>(geom),
+    const int fwd_gen = g_fwd_gen.load();                            // the replica of the kernel variant in use
+    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
+    float* const nf = nullptr;
+    if (tiles && fwd_gen == 3)
+        hipLaunchKernelGGL((blend_forward_strip_kernel<true, false>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, nf, nf,
+                           nf, nf, (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    else if (tiles && fwd_gen == 4)
+        hipLaunchKernelGGL((blend_forward_strip_kernel<true, true>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, nf, nf,
+                           nf, nf, (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    else if (tiles)
+        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec,
                            ids, ranges, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                            (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
     return hipGetLastError();

@@ -103,6 +103,8 @@ def _load():
     lib.msgs_set_backward_generation.argtypes = [C.c_int32]
     lib.msgs_set_blend_granularity.restype = C.c_int
     lib.msgs_set_blend_granularity.argtypes = [C.c_int32]
+    lib.msgs_set_forward_variant.restype = C.c_int
+    lib.msgs_set_forward_variant.argtypes = [C.c_int32]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, vp, sz, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
@@ -173,7 +175,7 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
            "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
-           "msgs_blend_lane_stats", "msgs_backward_per_gaussian")
+           "msgs_blend_lane_stats", "msgs_backward_per_gaussian", "msgs_set_forward_variant")
 
 
 def check(rc, where):
