@@ -531,14 +531,20 @@ def main():
                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stats")
             stats = {"D": int(D), "D_trav": int(o[0]), "V": int(o[1])}
             # lane efficiency of the blend forward, measured by a counting replica of the kernel on this state
-            o3 = (C.c_int64 * 3)()
+            o3 = (C.c_int64 * 7)()
             dgr._C.check(lib.msgs_blend_lane_stats(C.byref(ctx.call.view), C.c_void_p(geom.data_ptr()), geom.numel(), P, int(D),
                                                    C.c_void_p(binning.data_ptr()), binning.numel(),
+                                                   C.c_void_p(image.data_ptr()), image.numel(),
                                                    C.c_void_p(scratch.data_ptr()), scratch.numel(), o3,
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lane stats")
             stats["blend_fwd_lanes"] = {"wave_entry_evaluations": int(o3[0]), "evaluated_lanes": 64 * int(o3[0]),
                                         "lanes_still_blending": int(o3[1]), "lanes_blended": int(o3[2]),
                                         "lane_efficiency": round(int(o3[2]) / max(64 * int(o3[0]), 1), 4)}
+            if o3[3] >= 0:      # counting replica of the one-wave-per-tile backward
+                stats["blend_bwd_lanes"] = {"tile_entry_visits": int(o3[3]), "quadrant_entry_evaluations": int(o3[4]),
+                                            "evaluated_lanes": 64 * int(o3[4]), "lanes_contributing": int(o3[5]),
+                                            "visits_with_a_contribution": int(o3[6]),
+                                            "lane_efficiency": round(int(o3[5]) / max(64 * int(o3[4]), 1), 4)}
         except Exception as e:  # statistics are informative; never fail the bench line on them
             stats = {"error": repr(e)}
         kernels = None

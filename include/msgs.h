@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 6
+#define MSGS_ABI_VERSION 7
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -244,13 +244,17 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
-/* Diagnostic: lane efficiency of the blend forward.  Replays the quadrant-per-wave forward kernel on the state a forward left
- * behind (geom / binning of msgs_forward; nothing is written to them or to any image) with scalar counters:
- * out_host[0] = (wave, entry) evaluations — each evaluates 64 lanes; out_host[1] = lanes still blending summed over them;
- * out_host[2] = lanes that blended (alpha >= 1/255, power <= 0, before termination).  Synchronises `stream`. */
+/* Diagnostic: lane efficiency of the blend kernels.  Replays the blend forward in use (msgs_set_forward_variant) and — when
+ * image_state is given — the one-wave-per-tile backward on the state a forward left behind (nothing is written to geom / binning /
+ * image or to any output) with scalar counters:
+ *   out_host[0] = forward (wave, entry) evaluations — each evaluates 64 lanes; [1] = lanes still blending summed over them;
+ *   [2] = lanes that blended (alpha >= 1/255, power <= 0, before termination);
+ *   [3] = backward (tile, entry) visits; [4] = backward (quadrant, entry) evaluations — each 64 lanes; [5] = lanes that
+ *   contributed a gradient; [6] = visits with at least one contributing lane (= reductions + atomic instructions); -1 each
+ *   without image_state.  out_host holds 7 values; scratch >= 64 bytes.  Synchronises `stream`. */
 int msgs_blend_lane_stats(const msgs_view_t* view, const void* geom, size_t geom_bytes, int32_t P, int64_t D,
-                          const void* binning, size_t binning_bytes, void* scratch, size_t scratch_bytes,
-                          int64_t* out_host, void* stream);
+                          const void* binning, size_t binning_bytes, const void* image_state, size_t image_bytes,
+                          void* scratch, size_t scratch_bytes, int64_t* out_host, void* stream);
 
 /* Deterministic (verification) mode (process-wide switch; initial value from the environment variable
  * MSGS_DETERMINISTIC=1).  The forward is always bitwise reproducible.  The default backward adds the float32 sum each

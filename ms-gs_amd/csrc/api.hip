@@ -420,22 +420,30 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
 }
 
 int msgs_blend_lane_stats(const msgs_view_t* view, const void* geom, size_t geom_bytes, int32_t P, int64_t D,
-                          const void* binning_v, size_t binning_bytes, void* scratch, size_t scratch_bytes,
-                          int64_t* out_host, void* stream) {
-    if (!view || !geom || !binning_v || !scratch || !out_host || scratch_bytes < 24 || P < 0) return MSGS_ERR_INVALID_ARG;
+                          const void* binning_v, size_t binning_bytes, const void* image_v, size_t image_bytes,
+                          void* scratch, size_t scratch_bytes, int64_t* out_host, void* stream) {
+    if (!view || !geom || !binning_v || !scratch || !out_host || scratch_bytes < 64 || P < 0) return MSGS_ERR_INVALID_ARG;
     const int W = view->image_width, H = view->image_height;
     if (geom_bytes < msgs_geom_bytes(P) || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_ERR_CAPACITY;
+    if (image_v && image_bytes < msgs_image_bytes(W, H)) return MSGS_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
     const ViewParams vp = make_view_params(view);
     const BinningLayout BL(D, vp.gx * vp.gy);
+    const ImageLayout IL(W, H);
     const char* binning = (const char*)binning_v;
     unsigned long long* dev = (unsigned long long*)scratch;
     HIP_TRY(launch_blend_lane_stats(vp, (const char*)geom, (const uint32_t*)(binning + BL.ids),
                                     (const uint2*)(binning + BL.ranges), dev, s));
-    unsigned long long host[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(host, dev, 24, hipMemcpyDeviceToHost, s));
+    if (image_v)
+        HIP_TRY(launch_blend_backward_lane_stats(vp, (const char*)geom, (const uint32_t*)(binning + BL.ids),
+                                                 (const uint2*)(binning + BL.ranges),
+                                                 (const float*)((const char*)image_v + IL.final_T),
+                                                 (const uint32_t*)((const char*)image_v + IL.n_contrib), dev + 4, s));
+    unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(host, dev, 64, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int k = 0; k < 3; ++k) out_host[k] = (int64_t)host[k];
+    for (int k = 0; k < 4; ++k) out_host[3 + k] = image_v ? (int64_t)host[4 + k] : -1;
     return MSGS_OK;
 }
 

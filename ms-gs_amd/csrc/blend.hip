@@ -147,7 +147,7 @@ constexpr int LIST_PAD = 4;
 constexpr uint32_t SENTINEL_OFF = (uint32_t)BATCH << 4;
 constexpr int SBATCH = 128;                                   // records per batch of the strip kernel (below)
 constexpr uint32_t SENTINEL_OFF_S = (uint32_t)SBATCH << 4;
-constexpr uint32_t SENTINEL_MIN = SENTINEL_OFF_S;             // offsets >= this are a sentinel in either kernel
+
 __device__ __forceinline__ void write_sentinel_record(float4* s_r0, float4* s_r1, float4* s_r2) {
     s_r0[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
     s_r1[BATCH] = make_float4(0.f, -1.0e30f, 0.f, 0.f);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void pad_list(uint32_t* lp, int cnt, int lane) {
     if (lane < LIST_PAD - 1) lp[cnt + lane] = SENTINEL_OFF;
 }
 
-template <bool COUNT = false>
+template <bool COUNT = false, uint32_t SENT = SENTINEL_OFF>
 __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
                                                  const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io,
                                                  uint32_t& walked, LaneStats* stats = nullptr) {
@@ -185,7 +185,7 @@ __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, co
         if (COUNT) {
             // (per-row lists of the strip kernel: a trip counts when any row holds a real entry; a row on padding evaluates the
             //  sentinel record and can never blend)
-            if (__builtin_amdgcn_ballot_w64(off < SENTINEL_MIN) != 0) {
+            if (__builtin_amdgcn_ballot_w64(off != SENT) != 0) {
                 stats->steps += 1u; stats->alive += (uint32_t)__popcll(alive); stats->blended += (uint32_t)__popcll(validm & ~stopm);
             }
         }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         const int cnt = (max(max(c0, c1), max(c2, c3)) + LIST_PAD - 1) & ~(LIST_PAD - 1);
         const int mine = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
         for (int j = mine + (lane & 15); j < cnt; j += 16) my_list[j] = SENTINEL_OFF_S;
-        const uint32_t last_off = forward_walk<COUNT>(my_list, cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked, &ls);
+        const uint32_t last_off = forward_walk<COUNT, SENTINEL_OFF_S>(my_list, cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked, &ls);
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;
     }
     if (COUNT) {
@@ -1035,7 +1035,9 @@ __global__ void trace_set_kernel(unsigned long long* p) { g_tile_trace = p; }
 
 // DET = true (deterministic mode): instead of atomics, the nine sums of tile entry j (its position in the sorted instance
 // array) are STORED to inst_grad[j][0..8]; det_reduce_kernel then adds every Gaussian's entries in a fixed order.
-template <bool DET>
+// COUNT = true (diagnostic replica, msgs_blend_lane_stats): nothing is reduced or written; grad_out receives four counters —
+// (tile, entry) visits, (quadrant, entry) evaluations (each 64 lanes), lanes that contributed, visits with a contribution.
+template <bool DET, bool COUNT = false>
 __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                                  const uint32_t* __restrict__ ids,
                                                                  const uint2* __restrict__ ranges,
@@ -1067,6 +1069,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
 #if defined(MSGS_TRACE_TILES)
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    uint32_t cnt_visits = 0, cnt_steps = 0, cnt_lanes = 0, cnt_hits = 0;       // COUNT only
     BwdQuad q0, q1, q2, q3;
     uint32_t ql0, ql1, ql2, ql3;                           // wave-uniform: last blended position per quadrant
     {
@@ -1076,9 +1079,10 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             const size_t pix = (size_t)py * vp.W + px;
             const float Tf = inside ? final_T[pix] : 1.0f;
             s.last = inside ? n_contrib[pix] : 0u;
-            s.dL0 = inside ? dL_dcolor[pix] : 0.f;
-            s.dL1 = inside ? dL_dcolor[N + pix] : 0.f;
-            s.dL2 = inside ? dL_dcolor[2 * N + pix] : 0.f;
+            // (the counting replica does not read dL/dcolor: it only enters the sums, not the validity of a lane)
+            s.dL0 = (inside && !COUNT) ? dL_dcolor[pix] : 0.f;
+            s.dL1 = (inside && !COUNT) ? dL_dcolor[N + pix] : 0.f;
+            s.dL2 = (inside && !COUNT) ? dL_dcolor[2 * N + pix] : 0.f;
             s.S = vp.bg[0] * s.dL0 + vp.bg[1] * s.dL1 + vp.bg[2] * s.dL2;
             s.T = Tf;
             return __builtin_amdgcn_readfirstlane(wave_max_u32(s.last));
@@ -1124,6 +1128,16 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             const float dx = r0.x - bxf, dy = r0.y - byf;
             BwdSumsT<typename std::conditional<DET, double, float>::type> v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint64_t any = 0;
+            if constexpr (COUNT) {
+                uint64_t m;
+                cnt_visits += 1u;
+                if (h0 & bit) { m = bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h1 & bit) { m = bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h2 & bit) { m = bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h3 & bit) { m = bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (any) cnt_hits += 1u;
+                continue;
+            }
             if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
             if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
             if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
@@ -1158,8 +1172,15 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             }
         }
     }
+    if constexpr (COUNT) {
+        if (lane == 0) {
+            unsigned long long* o = (unsigned long long*)grad_out;
+            atomicAdd(&o[0], (unsigned long long)cnt_visits); atomicAdd(&o[1], (unsigned long long)cnt_steps);
+            atomicAdd(&o[2], (unsigned long long)cnt_lanes); atomicAdd(&o[3], (unsigned long long)cnt_hits);
+        }
+    }
 #if defined(MSGS_TRACE_TILES)
-    if (!DET && g_tile_trace && lane == 0) {
+    if (!DET && !COUNT && g_tile_trace && lane == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1443,6 +1464,19 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
 }
 
 // diagnostic: the quadrant-per-wave forward replayed with lane counters (no outputs written)
+hipError_t launch_blend_backward_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
+                                            const float* final_T, const uint32_t* n_contrib, unsigned long long* out4,
+                                            hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out4, 0, 32, s);
+    if (e != hipSuccess) return e;
+    const int tiles = vp.gx * vp.gy;
+    if (tiles)
+        hipLaunchKernelGGL((blend_backward_tile_kernel<false, true>), dim3(tiles), dim3(64), 0, s, vp,
+                           reinterpret_cast<const GaussRec*>(geom), ids, ranges, final_T, n_contrib, (const float*)nullptr, (void*)out4,
+                           (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                    unsigned long long* out3, hipStream_t s) {
     hipError_t e = hipMemsetAsync(out3, 0, 24, s);

@@ -399,6 +399,9 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
 hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, uint32_t* tile_order, hipStream_t s);
 hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                    unsigned long long* out3 /* device, zeroed inside */, hipStream_t s);
+hipError_t launch_blend_backward_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
+                                            const float* final_T, const uint32_t* n_contrib,
+                                            unsigned long long* out4 /* device, zeroed inside */, hipStream_t s);
 hipError_t launch_binning_stats(const ViewParams& vp, int P, const int32_t* radii, const uint32_t* n_contrib,
                                 unsigned long long* out2 /* device, zeroed inside */, hipStream_t s);
 

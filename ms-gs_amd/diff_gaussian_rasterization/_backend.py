@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -127,7 +127,7 @@ def _load():
     lib.msgs_binning_stats.argtypes = [C.POINTER(View), C.c_int32, vp, vp, sz, vp, sz, vp, sz,
                                        C.POINTER(C.c_int64), vp]
     lib.msgs_blend_lane_stats.restype = C.c_int
-    lib.msgs_blend_lane_stats.argtypes = [C.POINTER(View), vp, sz, C.c_int32, C.c_int64, vp, sz, vp, sz,
+    lib.msgs_blend_lane_stats.argtypes = [C.POINTER(View), vp, sz, C.c_int32, C.c_int64, vp, sz, vp, sz, vp, sz,
                                           C.POINTER(C.c_int64), vp]
     lib.msgs_voxel_pool_scratch_bytes.restype = sz
     lib.msgs_voxel_pool_scratch_bytes.argtypes = [C.c_int64]

@@ -43,7 +43,7 @@ def _oracle(scene, cam, st, bg, dL=None, **kw):
 def test_library_is_the_hip_one():
     import diff_gaussian_rasterization as dgr
     assert dgr._C._LIB_PATH.endswith("libmsgs_hip.so")
-    assert dgr._C.lib.msgs_abi_version() == 6
+    assert dgr._C.lib.msgs_abi_version() == 7
 
 
 @pytest.mark.parametrize("P,W,H,seed,deg,bgv", [
@@ -370,14 +370,18 @@ def test_lane_stats_diagnostic_matches_the_oracle_pair_count():
     geom, binning, image, D = ctx.state
     before = out["render"].clone()
     scratch = torch.empty(256, dtype=torch.uint8, device="cuda")
-    o3 = (C.c_int64 * 3)()
+    o3 = (C.c_int64 * 7)()
     dgr._C.check(dgr._C.lib.msgs_blend_lane_stats(C.byref(ctx.call.view), C.c_void_p(geom.data_ptr()), geom.numel(), sc.P, int(D),
                                                   C.c_void_p(binning.data_ptr()), binning.numel(),
+                                                  C.c_void_p(image.data_ptr()), image.numel(),
                                                   C.c_void_p(scratch.data_ptr()), scratch.numel(), o3,
                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lane stats")
     steps, alive, blended = int(o3[0]), int(o3[1]), int(o3[2])
     assert torch.equal(out["render"], before)
     assert 0 < blended <= alive <= 64 * steps
+    # backward replica: the lanes that contribute a gradient are exactly the pairs the forward blended
+    visits, qsteps, lanes, hits = int(o3[3]), int(o3[4]), int(o3[5]), int(o3[6])
+    assert lanes == blended and 0 < hits <= visits <= qsteps <= 4 * visits and lanes <= 64 * qsteps
     from oracle import oracle_ctypes as oc
     import copy
     seen = copy.copy(sc)

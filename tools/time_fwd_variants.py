@@ -27,11 +27,12 @@ for v in (1, 3, 4, 1, 3, 4):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
     ctx = out["render"].grad_fn
     geom, binning, image, D = ctx.state
-    scratch = torch.empty(256, dtype=torch.uint8, device="cuda"); o3 = (C.c_int64 * 3)()
+    scratch = torch.empty(256, dtype=torch.uint8, device="cuda"); o3 = (C.c_int64 * 7)()
     dgr._C.check(lib.msgs_blend_lane_stats(C.byref(ctx.call.view), C.c_void_p(geom.data_ptr()), geom.numel(), sc.P, int(D),
-                                           C.c_void_p(binning.data_ptr()), binning.numel(), C.c_void_p(scratch.data_ptr()),
-                                           scratch.numel(), o3, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stats")
+                                           C.c_void_p(binning.data_ptr()), binning.numel(), C.c_void_p(image.data_ptr()), image.numel(),
+                                           C.c_void_p(scratch.data_ptr()), scratch.numel(), o3, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stats")
     ms = tm.read_ms()
     print(f"{cfg} variant {v}: step {dt*1e3:.3f} ms blend_fwd {ms['blend_fwd']*1e3:.1f} us blend_bwd {ms['blend_bwd']*1e3:.1f} us "
-          f"trips {o3[0]} lane_eff {o3[2] / max(64 * o3[0], 1):.4f}")
+          f"trips {o3[0]} lane_eff {o3[2] / max(64 * o3[0], 1):.4f} | bwd visits {o3[3]} quad steps {o3[4]} lane_eff "
+          f"{o3[5] / max(64 * o3[4], 1):.4f} visits with contribution {o3[6]}")
 lib.msgs_set_forward_variant(0)
