@@ -187,10 +187,8 @@ class _Call:
             if self.fdc.numel() != 3 * P or self.frest.numel() != 45 * P:
                 raise ValueError("raw mode needs features_dc [P,1,3] and features_rest [P,15,3]")
             self.K = 16
-        self.bg = _f32c(rs.bg.to(dev))
-        self.vm = _f32c(rs.viewmatrix.to(dev))
-        self.pm = _f32c(rs.projmatrix.to(dev))
-        self.cp = _f32c(rs.campos.to(dev))
+        on = lambda t: _f32c(t if t.device == dev else t.to(dev))
+        self.bg, self.vm, self.pm, self.cp = on(rs.bg), on(rs.viewmatrix), on(rs.projmatrix), on(rs.campos)
         self.W, self.H = int(rs.image_width), int(rs.image_height)
         self.view = _C.View(self.H, self.W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                             float(rs.fade_size), int(rs.sh_degree), self.K,
@@ -204,6 +202,7 @@ class _Call:
                               _ptr(self.colors), _ptr(self.opac), _ptr(self.scales), _ptr(self.rot), _ptr(self.cov),
                               _ptr(self.maxps), _ptr(self.minps), _ptr(self.occ), _ptr(self.dcd), _ptr(self.base),
                               _ptr(self.fdc), _ptr(self.frest), _ptr(self.rot_raw))
+        self.view_ref, self.g_ref = C.byref(self.view), C.byref(self.g)
 
 
 def _backward_scratch(P, D, dev):
@@ -262,6 +261,25 @@ def set_deterministic(on=True):
 _last_instances = {}
 
 
+_size_cache = {}
+
+
+def _sizes(P, W, H):
+    """(geom, stage-1 scratch, image) byte counts per (P, W, H): three ctypes calls saved per forward"""
+    k = (P, W, H)
+    v = _size_cache.get(k)
+    if v is None:
+        lib = _C.lib
+        if len(_size_cache) > 256:
+            _size_cache.clear()
+        v = _size_cache[k] = (int(lib.msgs_geom_bytes(P)), int(lib.msgs_stage1_scratch_bytes(P)), int(lib.msgs_image_bytes(W, H)))
+    return v
+
+
+def _a256(n):
+    return (int(n) + 255) & ~255
+
+
 def _forward_impl(call, grad_rec=None):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
@@ -270,36 +288,40 @@ def _forward_impl(call, grad_rec=None):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         pixel_sizes = torch.empty(P, dtype=torch.float32, device=dev)
-        geom = _bytes(lib.msgs_geom_bytes(P), dev)
-        scratch1 = _bytes(lib.msgs_stage1_scratch_bytes(P), dev)
-        image = _bytes(lib.msgs_image_bytes(W, H), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         acc_ps = torch.empty(H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+        n_geom, n_s1, n_img = _sizes(P, W, H)
         guess = _last_instances.get(key)
-        binning = scratch2 = None
+        # two allocations instead of five: what the backward needs again (geom | image | binning) and what dies with the
+        # forward (stage-1 scratch | stage-2 scratch); every part starts on a 256-byte boundary
+        n_bin = n_s2 = 0
         if guess is not None:
             cap = guess + (guess >> 3) + 4096
-            binning = _bytes(lib.msgs_binning_bytes(cap, W, H), dev)
-            scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(cap, W, H), dev)
+            n_bin, n_s2 = int(lib.msgs_binning_bytes(cap, W, H)), int(lib.msgs_stage2_scratch_bytes(cap, W, H))
+        keep = _bytes(_a256(n_geom) + _a256(n_img) + n_bin, dev)
+        geom, image = keep[:n_geom], keep[_a256(n_geom):_a256(n_geom) + n_img]
+        binning = keep[_a256(n_geom) + _a256(n_img):] if n_bin else None
+        tmp = _bytes(_a256(n_s1) + n_s2, dev)
+        scratch1 = tmp[:n_s1]
+        scratch2 = tmp[_a256(n_s1):] if n_s2 else None
         D, done = C.c_int64(0), C.c_int32(0)
-        _C.check(lib.msgs_forward(C.byref(call.view), C.byref(call.g), _ptr(radii), _ptr(pixel_sizes),
-                                  _ptr(geom), geom.numel(), _ptr(scratch1), scratch1.numel(),
-                                  _ptr(binning), binning.numel() if binning is not None else 0,
-                                  _ptr(scratch2), scratch2.numel() if scratch2 is not None else 0,
-                                  _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+        _C.check(lib.msgs_forward(call.view_ref, call.g_ref, _ptr(radii), _ptr(pixel_sizes),
+                                  _ptr(geom), n_geom, _ptr(scratch1), n_s1,
+                                  _ptr(binning), n_bin, _ptr(scratch2), n_s2,
+                                  _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),
                                   _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
         # views of one scene differ in D: remember a slowly decaying maximum rather than the last value
         _last_instances[key] = max(D, int(0.97 * guess)) if guess is not None else D
-        del scratch1
+        del scratch1, scratch2, tmp
         if not done.value:                              # first frame of this shape, or the scene grew past the margin
             binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
             scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
-            _C.check(lib.msgs_forward_stage2(C.byref(call.view), C.byref(call.g), _ptr(geom), geom.numel(), D,
+            _C.check(lib.msgs_forward_stage2(call.view_ref, call.g_ref, _ptr(geom), n_geom, D,
                                              _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
-                                             _ptr(image), image.numel(), _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                             _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),
                                              _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
                                              _C.timer_ptr(), stream), "msgs_forward_stage2")
     return color, acc_ps, depth, radii, pixel_sizes, (geom, binning, image, D)
@@ -366,7 +388,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch, is_clear = _take_backward_scratch(ctx, P, D, dev)
             grads = _C.Grads(_ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col), _ptr(g_opac),
                              _ptr(g_scales), _ptr(g_rot), _ptr(g_cov), None, None, None, is_clear)
-            _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
+            _C.check(lib.msgs_backward(call.view_ref, call.g_ref, _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
                                        _C.timer_ptr(), stream), "msgs_backward")
@@ -490,7 +512,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                              _ptr(g_dc), _ptr(g_rest),
                              C.c_void_p(ready.cuda_event) if (factor is not None and ready is not None) else None,
                              is_clear)
-            _C.check(lib.msgs_backward(C.byref(call.view), C.byref(call.g), _ptr(ctx.radii), _ptr(geom),
+            _C.check(lib.msgs_backward(call.view_ref, call.g_ref, _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
                                        _C.timer_ptr(), stream), "msgs_backward")
