@@ -176,9 +176,21 @@ class FactoredGradExchange:
 
     SMALL = ("_xyz", "_opacity", "_scaling", "_rotation")
 
-    def __init__(self, model, world=None, group=None, reconstruct=None, set_sinks=None):
+    def __init__(self, model, world=None, group=None, reconstruct=None, set_sinks=None, visible_rows=False,
+                 visible_rows_max_fraction=0.85):
+        """visible_rows: reduce only the rows of the small bucket that SOME rank rendered this step (end_view then needs
+        each rank's visibility mask): the ranks all-gather their [P] visibility bytes, form the union, pack the union's
+        rows of the 11 non-SH floats into one dense [U, 11] buffer, all-reduce that and scatter it back — rows no view
+        rendered are zero on every rank and stay where they are.  Worth it at 2-4 ranks on scenes where a view sees a
+        fraction of the model (C3-like frusta: 56 % rendered per view); when the union exceeds
+        `visible_rows_max_fraction` of the model (C4: every ring camera sees 99.9 % of the ball) the step falls back to the
+        dense small bucket.  Costs one host synchronisation per step (the size of the union)."""
         self.model = model
         self.group = group
+        self.visible_rows = bool(visible_rows)
+        self.visible_rows_max_fraction = float(visible_rows_max_fraction)
+        self._packed = None                 # (idx, packed buffer) of the step in flight
+        self.last_union_rows = None
         self.active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(group) > 1 or os.environ.get("MSGS_EXCHANGE_FORCE") == "1")
         self.world = world if world is not None else (dist.get_world_size(group) if self.active else 1)
@@ -231,8 +243,25 @@ class FactoredGradExchange:
         else:
             self._set_sinks(self.small.sinks(), sh_factor=self.send[:3 * self.P].view(self.P, 3))
 
-    def end_view(self, camera_center=None):
-        """after backward(): issue both collectives (asynchronously; they run on the communicator's stream)"""
+    def _small_exchange(self, visibility, op):
+        """the small bucket's all-reduce: dense, or — visible_rows — over the rows rendered somewhere this step"""
+        b = self.small
+        self._packed = None
+        if self.visible_rows and visibility is not None:
+            vis8 = visibility.reshape(-1).to(torch.uint8).contiguous()
+            allvis = torch.empty(self.n_rows, self.P, dtype=torch.uint8, device=vis8.device)
+            dist.all_gather_into_tensor(allvis.view(-1), vis8, group=self.group)
+            idx = allvis.max(dim=0).values.nonzero().squeeze(1)          # host sync: the size of the union
+            self.last_union_rows = int(idx.numel())
+            if self.last_union_rows <= self.visible_rows_max_fraction * self.P:
+                packed = torch.cat([v.reshape(self.P, -1).index_select(0, idx) for v in b.views], dim=1).contiguous()
+                self._packed = (idx, packed)
+                return dist.all_reduce(packed, op=op, group=self.group, async_op=True)
+        return dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+
+    def end_view(self, camera_center=None, visibility=None):
+        """after backward(): issue both collectives (asynchronously; they run on the communicator's stream).
+        visibility: this view's `visibility_filter` ([P] bool), needed by the visible_rows exchange only"""
         self._set_sinks(None)
         b = self.small
         for p, v in zip(b.params, b.views):
@@ -263,14 +292,14 @@ class FactoredGradExchange:
                     ag = dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True)
                 self.send.record_stream(self.side)
                 self.gathered.record_stream(self.side)
-                ar = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+                ar = self._small_exchange(visibility, op)
                 self.pending = [ag, ar]
                 self._main = main
             else:
                 if cc is not None:
                     self.send[3 * self.P:3 * self.P + 3] = cc
                 self.pending = [dist.all_gather_into_tensor(self.gathered.view(-1), self.send, group=self.group, async_op=True),
-                                dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)]
+                                self._small_exchange(visibility, op)]
         elif not written:
             self.send[3 * self.P:3 * self.P + 3] = camera_center.to(self.send.device, torch.float32).reshape(3)
 
@@ -285,7 +314,17 @@ class FactoredGradExchange:
         for w in self.pending[1:]:
             w.wait()
         self.pending = []
-        if self.world > 1 and (not self.active or self.avg_op is None):
+        if self._packed is not None:            # visible-rows exchange: the reduced rows go back where they came from
+            idx, packed = self._packed
+            self._packed = None
+            if self.world > 1 and self.avg_op is None:
+                packed.div_(self.world)
+            col = 0
+            for v in self.small.views:
+                v2 = v.reshape(self.P, -1)
+                v2.index_copy_(0, idx, packed[:, col:col + v2.shape[1]])
+                col += v2.shape[1]
+        elif self.world > 1 and (not self.active or self.avg_op is None):
             self.small.flat.div_(self.world)
         self.model._features_dc.grad = self.g_dc
         self.model._features_rest.grad = self.g_rest
@@ -294,6 +333,15 @@ class FactoredGradExchange:
         """bytes a GPU receives per step: all-gather of the factors + ring-equivalent all-reduce of the small bucket"""
         n = max(self.n_rows, 1)
         return 4 * ((n - 1) * self.send.numel() + 2 * (n - 1) * self.small.flat.numel() // n)
+
+    def bytes_last_step_visible_rows(self):
+        """the same count for the last step when it went through the visible-rows exchange (None otherwise): factors +
+        visibility bytes + the packed [U, 11] all-reduce"""
+        if not self.visible_rows or self.last_union_rows is None or \
+                self.last_union_rows > self.visible_rows_max_fraction * self.P:
+            return None
+        n = max(self.n_rows, 1)
+        return 4 * (n - 1) * self.send.numel() + (n - 1) * self.P + 4 * 2 * (n - 1) * (11 * self.last_union_rows) // n
 
 
 def gather_pixel_size_observations(visibility_filter, pixel_sizes, reso_lvl, group=None):

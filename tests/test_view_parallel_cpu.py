@@ -225,3 +225,75 @@ def test_factored_exchange_and_pixel_size_stats_world2():
     ret = mgr.dict()
     mp.spawn(_factored_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# visible-rows exchange: only the rows some rank rendered travel; equal to the dense exchange
+# ---------------------------------------------------------------------------------------------------------------------
+def _visible_rows_worker(rank, world, port, ret):
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ms-gs_amd", "host")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from view_parallel import FactoredGradExchange
+    torch.manual_seed(0)
+    P, deg = 517, 1
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    shapes = ((P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4))
+    ok = True
+    results = {}
+    for mode, frac in (("dense", None), ("rows", 0.95), ("rows-fallback", 0.05)):
+        torch.manual_seed(0)
+        model = types.SimpleNamespace(active_sh_degree=deg)
+        for n, s in zip(names, shapes):
+            setattr(model, n, torch.nn.Parameter(torch.randn(*s)))
+        sinks = {}
+
+        def set_sinks(mapping, sh_factor=None):
+            sinks.clear()
+            if mapping:
+                sinks.update(mapping=mapping, sh_factor=sh_factor)
+        ex = FactoredGradExchange(model, world, reconstruct=_torch_sh_reconstruct, set_sinks=set_sinks,
+                                  visible_rows=mode != "dense", visible_rows_max_fraction=frac or 0.85)
+        for it in range(2):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            vis = torch.rand(P, generator=g) < (0.35 if world == 2 else 0.2)        # this rank's visibility_filter
+            ex.begin_view(torch.randn(3, generator=g))
+            for p_, dest in sinks["mapping"].items():
+                val = torch.randn(*p_.shape, generator=g)
+                val[~vis] = 0.0                                                    # K9 writes zeros for rows it did not render
+                dest.copy_(val)
+                p_.grad = dest.view(p_.shape)
+            drgb = torch.randn(P, 3, generator=g)
+            drgb[~vis] = 0.0
+            sinks["sh_factor"].copy_(drgb)
+            ex.end_view(visibility=vis)
+            ex.finish()
+            results[(mode, it)] = {n: getattr(model, n).grad.clone() for n in names}
+            if mode == "rows":
+                ok = ok and ex.bytes_last_step_visible_rows() is not None and ex.last_union_rows < P
+                ok = ok and ex.bytes_last_step_visible_rows() < ex.bytes_per_step()
+            if mode == "rows-fallback":
+                ok = ok and ex.bytes_last_step_visible_rows() is None
+    for it in range(2):
+        for n in names:
+            for mode in ("rows", "rows-fallback"):
+                a, b = results[("dense", it)][n], results[(mode, it)][n]
+                # two ranks: a + b is the same float whichever buffer it travels in; four: the ring reduces the chunks of
+                # the dense and of the packed buffer in different rank orders (last-bit differences)
+                ok = ok and (bool(torch.equal(a, b)) if world == 2 else bool(torch.allclose(a, b, rtol=1e-6, atol=1e-7)))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_visible_rows_exchange_equals_dense(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_visible_rows_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
