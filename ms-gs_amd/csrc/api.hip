@@ -110,15 +110,9 @@ int msgs_set_backward_generation(int32_t gen) { return set_backward_generation(g
 int msgs_set_blend_granularity(int32_t mode) { return set_blend_granularity(mode); }
 int msgs_set_forward_variant(int32_t variant) { return set_forward_variant(variant); }
 
-}  // extern "C"
-
-// bubble_zero: a buffer to clear with a fill launch placed BEHIND the last stage-1 kernel and IN FRONT of the host's wait for the
-// instance count: the GPU runs it while the host learns D and launches stage 2 (that gap was 14 us of idle per step), instead of
-// the forward blend clearing it on the side (msgs_forward hands the backward's gradient records over this way)
-static int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
-                               void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
-                               int64_t* num_instances_host, const msgs_timing_t* timing, void* stream, void* bubble_zero,
-                               size_t bubble_zero_bytes) {
+int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+                        void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
+                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (!num_instances_host) return MSGS_ERR_INVALID_ARG;
@@ -196,7 +190,6 @@ static int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* 
                                       (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
                                       status_dev, polled ? t_host_dev : nullptr, ticket, s));
     }
-    if (bubble_zero && bubble_zero_bytes) HIP_TRY(launch_zero(bubble_zero, bubble_zero_bytes, s));
     if (polled) {
         volatile uint64_t* hv = t_host;
         uint64_t spins = 0;
@@ -223,21 +216,6 @@ static int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* 
     return MSGS_OK;
 }
 
-extern "C" {
-
-int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
-                        void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
-                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream) {
-    return forward_stage1_impl(view, g, radii, pixel_sizes, geom_v, geom_bytes, scratch_v, scratch_bytes, num_instances_host,
-                               timing, stream, nullptr, 0);
-}
-
-static int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes,
-                               int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
-                               void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
-                               void* grad_records, size_t grad_records_bytes, const msgs_timing_t* timing, void* stream,
-                               bool records_already_clear);
-
 int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes, void* geom,
                  size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
                  void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
@@ -245,21 +223,16 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
                  int64_t* num_instances_host, int32_t* stage2_done, const msgs_timing_t* timing, void* stream) {
     if (!stage2_done) return MSGS_ERR_INVALID_ARG;
     *stage2_done = 0;
-    if (grad_records && g && grad_records_bytes < msgs_backward_scratch_bytes(g->P)) return MSGS_ERR_CAPACITY;
-    // the gradient records are cleared in the bubble behind stage 1 (forward_stage1_impl); MSGS_NO_BUBBLE_FILL=1: by the forward
-    // blend on the side, as before (A/B)
-    static const bool bubble = [] { const char* e = getenv("MSGS_NO_BUBBLE_FILL"); return !(e && e[0] == '1'); }();
-    const bool fill = bubble && grad_records && g && g->P > 0;
-    int rc = forward_stage1_impl(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, num_instances_host,
-                                 timing, stream, fill ? grad_records : nullptr, fill ? GRAD_REC_BYTES * (size_t)g->P : 0);
+    int rc = msgs_forward_stage1(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes,
+                                 num_instances_host, timing, stream);
     if (rc) return rc;
     const int64_t D = *num_instances_host;
     const int W = view->image_width, H = view->image_height;
     if (!binning || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_OK;
     if (D > 0 && (!scratch2 || scratch2_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_OK;
-    rc = forward_stage2_impl(view, g, geom, geom_bytes, D, binning, binning_bytes, scratch2, scratch2_bytes, image,
+    rc = msgs_forward_stage2(view, g, geom, geom_bytes, D, binning, binning_bytes, scratch2, scratch2_bytes, image,
                              image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, timing,
-                             stream, fill);
+                             stream);
     if (rc) return rc;
     *stage2_done = 1;
     return MSGS_OK;
@@ -282,16 +255,6 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                         int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
                         void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
                         void* grad_records, size_t grad_records_bytes, const msgs_timing_t* timing, void* stream) {
-    return forward_stage2_impl(view, g, geom_v, geom_bytes, D, binning_v, binning_bytes, scratch_v, scratch_bytes, image_v,
-                               image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, timing, stream,
-                               false);
-}
-
-static int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes,
-                               int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
-                               void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
-                               void* grad_records, size_t grad_records_bytes, const msgs_timing_t* timing, void* stream,
-                               bool records_already_clear) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (D < 0 || D > 0xFFFFFFFFll) return MSGS_ERR_TOO_MANY;
@@ -343,8 +306,7 @@ static int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* 
     HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth,
                                  (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib),
                                  (uint32_t*)(image + IL.tile_last),
-                                 records_already_clear ? nullptr : grad_records,
-                                 grad_records && !records_already_clear ? GRAD_REC_BYTES * (size_t)P : 0, s));
+                                 grad_records, grad_records ? GRAD_REC_BYTES * (size_t)P : 0, s));
     if (grad_records)      // a backward will follow: give its one-wave-per-tile kernel a heaviest-first launch order
         HIP_TRY(launch_tile_order(vp, (const uint32_t*)(image + IL.tile_last), (uint32_t*)(image + IL.tile_order), s));
     tm.end(MSGS_K_BLEND_FWD);
