@@ -276,7 +276,7 @@ int msgs_set_backward_generation(int32_t gen);
 
 /* Pixel granularity of the blend kernels' workgroups: 0 (default) = by tile count, 1 = always one wave64 per 8x8 pixel
  * quadrant (forward) / per quadrant or tile (backward, see above), 2 = always the fine-grained kernels — sixteen waves
- * per 16x16 tile, one per 4x4 pixel sub-block — which the default picks below 600 (forward) / 300 (backward) tiles (the low levels of the
+ * per 16x16 tile, one per 4x4 pixel sub-block — which the default picks below 300 tiles (the low levels of the
  * resolution pyramid MS-GS trains on, utils/camera_utils.py:38-39), where the blend kernels are latency-bound and a
  * shorter per-wave entry list matters more than idle lanes.  Same per-pixel arithmetic in the same order: forward
  * results are bit-identical across granularities.  2 overrides msgs_set_backward_generation.  Initial value from
@@ -291,12 +291,14 @@ int msgs_set_blend_granularity(int32_t mode);
  * tests and A/B measurements.  Initial value from MSGS_FWD_GEN.  Returns the previous value. */
 int msgs_set_forward_variant(int32_t variant);
 
-/* msgs_forward: both stages in ONE call.  Runs stage 1, synchronises once to learn the instance count D, and — when
- * the caller's `binning` and `scratch2` buffers are large enough for D (msgs_binning_bytes(D, W, H),
- * msgs_stage2_scratch_bytes(D, W, H)) — launches stage 2 immediately, with no allocation and no second library call
- * inside the bubble the synchronisation opens on the GPU (*stage2_done = 1).  Buffers sized from the previous frame's
- * D plus a margin make that the normal case.  Otherwise *stage2_done = 0 and *num_instances_host = D: grow the
- * buffers and call msgs_forward_stage2.  The binning buffer's internal layout depends on D only, not on its capacity. */
+/* msgs_forward: both stages in ONE call.  The caller passes `binning` and `scratch2` sized for a GUESS of the instance count
+ * (the previous frame's D plus a margin).  Stage 1 is launched, stage 2 is launched right behind it on those buffers — sized for
+ * their capacity, the kernels read min(D, capacity) from a device word the scan writes — and only then the host waits for D (one
+ * poll of pinned host words): the GPU never idles while the host learns D.  D <= capacity (the normal case): *stage2_done = 1.
+ * Otherwise (first frame of a shape, or the scene outgrew the margin) *stage2_done = 0 and *num_instances_host = D: grow the
+ * buffers and call msgs_forward_stage2, which overwrites the truncated result (same stream).  The binning buffer's internal
+ * layout depends neither on D nor on the capacity (tile ranges first).  view->debug, the look-back sort variants and
+ * MSGS_NO_SPECULATIVE_STAGE2=1 take the sequential route (wait for D, then launch stage 2 if the buffers suffice). */
 int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int32_t* radii, float* pixel_sizes,
                  void* geom, size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning,
                  size_t binning_bytes, void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes,

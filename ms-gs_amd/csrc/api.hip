@@ -110,9 +110,31 @@ int msgs_set_backward_generation(int32_t gen) { return set_backward_generation(g
 int msgs_set_blend_granularity(int32_t mode) { return set_blend_granularity(mode); }
 int msgs_set_forward_variant(int32_t variant) { return set_forward_variant(variant); }
 
-int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+}  // extern "C"
+
+namespace {
+// Speculative stage 2 (msgs_forward): everything stage 2 needs, handed to stage 1 so that it can launch stage 2 on the caller's
+// capacity-sized buffers right behind its own last kernel — BEFORE the host waits for the instance count.  The stage-2 kernels then
+// read min(D, capacity) from a device word the scan writes; the host checks D <= capacity afterwards (and the caller redoes
+// stage 2 on exact buffers when the scene outgrew the guess).  Without it the GPU idled ~14 us per step between the scan and
+// the emit while the host learned D and launched (profiles/r3_idle.txt).
+struct SpecStage2 {
+    int64_t capacity;
+    void* binning; size_t binning_bytes;
+    void* scratch2; size_t scratch2_bytes;
+    void* image; size_t image_bytes;
+    float* out_color; float* out_acc_ps; float* out_depth;
+    void* grad_records; size_t grad_records_bytes;
+    int launched_rc;           // out: status of the speculative launch
+};
+int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes, int64_t D,
+                        void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes, void* image_v,
+                        size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
+                        size_t grad_records_bytes, const msgs_timing_t* timing, void* stream, const uint32_t* D_dev);
+
+int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
                         void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
-                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream) {
+                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream, SpecStage2* spec) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (!num_instances_host) return MSGS_ERR_INVALID_ARG;
@@ -176,13 +198,16 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     const bool classic = use_classic_sort();
     uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
     uint64_t* status_dev = total_dev + 2;
+    uint32_t* clamped_dev = (uint32_t*)(total_dev + 5);       // min(D, capacity) for a speculative stage 2
+    if (spec && !classic) spec = nullptr;                     // (the look-back scan variant does not write it)
     uint64_t host_status[2] = {0, 0};
 
     tm.begin(MSGS_K_SCAN);
     HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
                                classic ? status_dev : nullptr, classic && polled ? t_host_dev : nullptr, ticket,
-                               (const uint32_t*)(geom + GL.nvalid)));
+                               (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
+                               spec ? (uint64_t)spec->capacity : 0));
     tm.end(MSGS_K_SCAN);
     if (!classic) {        // look-back sort / scan variants: watchdog flags join the status in a final tiny kernel
         const SortScratch SSL(P);
@@ -190,6 +215,11 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                       (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
                                       status_dev, polled ? t_host_dev : nullptr, ticket, s));
     }
+    if (spec)       // stage 2 goes out NOW, sized for the capacity; the GPU runs it while the host waits for D below
+        spec->launched_rc = forward_stage2_impl(view, g, geom_v, geom_bytes, spec->capacity, spec->binning, spec->binning_bytes,
+                                                spec->scratch2, spec->scratch2_bytes, spec->image, spec->image_bytes,
+                                                spec->out_color, spec->out_acc_ps, spec->out_depth, spec->grad_records,
+                                                spec->grad_records_bytes, timing, stream, clamped_dev);
     if (polled) {
         volatile uint64_t* hv = t_host;
         uint64_t spins = 0;
@@ -216,6 +246,29 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     return MSGS_OK;
 }
 
+// largest D with bytes_of(D) <= bytes (bytes_of monotone); 0 if none
+template <class F>
+static int64_t max_instances_for(size_t bytes, F bytes_of) {
+    if (bytes_of(1) > bytes) return 0;
+    int64_t lo = 1, hi = 0xFFFFFFFFll;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo + 1) / 2;
+        if (bytes_of(mid) <= bytes) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+                        void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
+                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream) {
+    return forward_stage1_impl(view, g, radii, pixel_sizes, geom_v, geom_bytes, scratch_v, scratch_bytes, num_instances_host,
+                               timing, stream, nullptr);
+}
+
 int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes, void* geom,
                  size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
                  void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
@@ -223,11 +276,40 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
                  int64_t* num_instances_host, int32_t* stage2_done, const msgs_timing_t* timing, void* stream) {
     if (!stage2_done) return MSGS_ERR_INVALID_ARG;
     *stage2_done = 0;
-    int rc = msgs_forward_stage1(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes,
-                                 num_instances_host, timing, stream);
+    if (!view || !g) return MSGS_ERR_INVALID_ARG;
+    // speculative stage 2 on the caller's buffers (MSGS_NO_SPECULATIVE_STAGE2=1: wait for D first, as before)
+    static const bool no_spec = [] { const char* e = getenv("MSGS_NO_SPECULATIVE_STAGE2"); return e && e[0] == '1'; }();
+    SpecStage2 spec{};
+    bool use_spec = false;
+    if (!no_spec && !view->debug && g->P > 0 && binning && scratch2 && image && out_color && out_acc_ps && out_depth &&
+        view->image_width > 0 && view->image_height > 0) {
+        const int W0 = view->image_width, H0 = view->image_height;
+        const int64_t cb = max_instances_for(binning_bytes, [&](int64_t d) { return msgs_binning_bytes(d, W0, H0); });
+        const int64_t cs = max_instances_for(scratch2_bytes, [&](int64_t d) { return msgs_stage2_scratch_bytes(d, W0, H0); });
+        const int64_t cap = cb < cs ? cb : cs;
+        const int tiles0 = ((W0 + TILE - 1) / TILE) * ((H0 + TILE - 1) / TILE);
+        if (cap >= 4096 && radix_sort_supports_device_count(cap, 0, tile_bits(tiles0))) {
+            spec.capacity = cap;
+            spec.binning = binning; spec.binning_bytes = binning_bytes;
+            spec.scratch2 = scratch2; spec.scratch2_bytes = scratch2_bytes;
+            spec.image = image; spec.image_bytes = image_bytes;
+            spec.out_color = out_color; spec.out_acc_ps = out_acc_ps; spec.out_depth = out_depth;
+            spec.grad_records = grad_records; spec.grad_records_bytes = grad_records_bytes;
+            spec.launched_rc = MSGS_OK;
+            use_spec = true;
+        }
+    }
+    int rc = forward_stage1_impl(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, num_instances_host,
+                                 timing, stream, use_spec ? &spec : nullptr);
     if (rc) return rc;
     const int64_t D = *num_instances_host;
     const int W = view->image_width, H = view->image_height;
+    if (use_spec && spec.capacity > 0 && spec.launched_rc != MSGS_OK) return spec.launched_rc;
+    if (use_spec && D <= spec.capacity) {       // the normal case: stage 2 already ran (is running) on these buffers
+        *stage2_done = 1;
+        return MSGS_OK;
+    }
+    if (use_spec) return MSGS_OK;               // the scene outgrew the guess: the caller redoes stage 2 on exact buffers
     if (!binning || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_OK;
     if (D > 0 && (!scratch2 || scratch2_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_OK;
     rc = msgs_forward_stage2(view, g, geom, geom_bytes, D, binning, binning_bytes, scratch2, scratch2_bytes, image,
@@ -255,6 +337,20 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                         int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
                         void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
                         void* grad_records, size_t grad_records_bytes, const msgs_timing_t* timing, void* stream) {
+    return forward_stage2_impl(view, g, geom_v, geom_bytes, D, binning_v, binning_bytes, scratch_v, scratch_bytes, image_v,
+                               image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, timing, stream,
+                               nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+// D_dev != nullptr: speculative launch — D is the CAPACITY (layouts, grids, sort geometry), the kernels read the instance count
+// min(D_true, capacity) from *D_dev
+int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes, int64_t D,
+                        void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes, void* image_v,
+                        size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
+                        size_t grad_records_bytes, const msgs_timing_t* timing, void* stream, const uint32_t* D_dev) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (D < 0 || D > 0xFFFFFFFFll) return MSGS_ERR_TOO_MANY;
@@ -288,17 +384,17 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
         const bool sort2_prezeroed = radix_sort_zero_region(D, 0, tile_bits(num_tiles), scratch + SL.sort, &zj2.p0, &zj2.n0);
         ranges_prezeroed = true;
         tm.begin(MSGS_K_EMIT);
-        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2));
+        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2, D_dev));
         tm.end(MSGS_K_EMIT);
         if ((rc = debug_sync(view, s))) return rc;
         tm.begin(MSGS_K_TILE_SORT);
         HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, D, 0, tile_bits(num_tiles), scratch + SL.sort, s,
-                                 sort2_prezeroed));
+                                 sort2_prezeroed, nullptr, D_dev));
         tm.end(MSGS_K_TILE_SORT);
         if ((rc = debug_sync(view, s))) return rc;
     }
     tm.begin(MSGS_K_RANGES);
-    HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s, ranges_prezeroed));
+    HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s, ranges_prezeroed, D_dev));
     tm.end(MSGS_K_RANGES);
     if ((rc = debug_sync(view, s))) return rc;
 
@@ -312,6 +408,9 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
     tm.end(MSGS_K_BLEND_FWD);
     return debug_sync(view, s);
 }
+}  // namespace
+
+extern "C" {
 
 int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int32_t* radii, const void* geom_v,
                   size_t geom_bytes, int64_t D, const void* binning_v, size_t binning_bytes, const void* image_v,

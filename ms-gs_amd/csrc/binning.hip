@@ -25,7 +25,7 @@ namespace {
 template <int EMIT_STAGE>
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids,
-                                                   int64_t D, ZeroJob zj) {
+                                                   int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev) {
     // ranks 0 .. V-1 of the depth order are the Gaussians that stayed in the compacting depth sort (GeomLayout::nvalid)
     {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
         const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
 
+    if (D_dev) D = (int64_t)*D_dev;      // speculative stage 2: min(instance count, capacity), from the scan
     const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
     const int r0 = blockIdx.x * blockDim.x;
     if (r0 >= V) return;
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
 }
 
 __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ keys, int64_t D,
-                                                     uint2* __restrict__ ranges, int num_tiles) {
+                                                     uint2* __restrict__ ranges, int num_tiles,
+                                                     const uint32_t* __restrict__ D_dev) {
+    if (D_dev) D = (int64_t)*D_dev;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
     const uint32_t t = keys[i];
@@ -104,23 +107,23 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
 }  // namespace
 
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids, int64_t D,
-                       hipStream_t s, ZeroJob zj) {
+                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev) {
     if (P == 0 || D == 0) return hipSuccess;     // (callers fold a ZeroJob in only when D > 0)
     if (D > 8 * (int64_t)P)
-        hipLaunchKernelGGL((emit_kernel<6144>), dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj);
+        hipLaunchKernelGGL((emit_kernel<6144>), dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
     else
-        hipLaunchKernelGGL((emit_kernel<3072>), dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj);
+        hipLaunchKernelGGL((emit_kernel<3072>), dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
     return hipGetLastError();
 }
 
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
-                         bool pre_zeroed) {
+                         bool pre_zeroed, const uint32_t* D_dev) {
     if (!pre_zeroed) {
         hipError_t e = launch_zero(ranges, sizeof(uint2) * (size_t)num_tiles, s);
         if (e != hipSuccess) return e;
     }
     if (D == 0) return hipSuccess;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys, D, ranges, num_tiles);
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys, D, ranges, num_tiles, D_dev);
     return hipGetLastError();
 }
 

@@ -1236,7 +1236,8 @@ constexpr int BWD_GEN2_MIN_TILES = 4096;
 // below these tile counts: the sixteen-waves-per-tile kernels (latency-bound regime).  C3 scene, profiles/r1_notes.md:
 // forward 510 tiles 109 -> 100 us, 135 tiles 184 -> 112, 40 tiles 285 -> 161; backward 510 tiles 167 -> 184 (worse),
 // 135 tiles 262 -> 185, 40 tiles 372 -> 236
-constexpr int FINE_MAX_TILES_FWD = 600, FINE_MAX_TILES_BWD = 300;
+constexpr int FINE_MAX_TILES_FWD = 300, FINE_MAX_TILES_BWD = 300;     // (round 3 sweep: 510 tiles forward 102 us coarse vs 127 fine;
+                                                                       //  135 tiles 155 vs 104; backward 510 tiles 168 vs 229, 135 tiles 263 vs 182)
 // forward kernel variant: 1 = quadrant lists (one 8x8 quadrant per wave), 2 = one wave per tile, 3 = 8x2 strip lists with the
 // y-extent strip test, 4 = strip lists with the exact strip test; MSGS_FWD_GEN / msgs_set_forward_variant
 constexpr int FWD_GEN_DEFAULT = 1;

@@ -111,12 +111,14 @@ struct Stage1Scratch {
     }
 };
 
+// (the tile ranges come FIRST: the position of every part is then independent of D, so that stage 2 can be launched on
+//  capacity-sized buffers before the host knows D, and the backward finds the parts whatever capacity the forward used)
 struct BinningLayout {
     size_t ids, ranges, total;
     __host__ __device__ BinningLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
-        ids = o;    o = align256(o + 4 * (size_t)(D > 0 ? D : 1));
         ranges = o; o = align256(o + 8 * (size_t)tiles);
+        ids = o;    o = align256(o + 4 * (size_t)(D > 0 ? D : 1));
         total = o;
     }
 };
@@ -333,15 +335,17 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // inputs are clobbered when more than one pass is needed.
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch /* SortScratch(n) */,
-                            hipStream_t s, bool pre_zeroed = false, uint32_t* n_valid_dev = nullptr);
+                            hipStream_t s, bool pre_zeroed = false, uint32_t* n_valid_dev = nullptr,
+                            const uint32_t* n_dev = nullptr);
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words);
+bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit);
 
 // out[r] = exclusive sum of in[gather ? gather[r] : r]; *total (device, u64) = grand total
 // n_ptr (optional, device word): the number of elements actually scanned, <= n (n sizes the grids)
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s,
                               uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0,
-                              const uint32_t* n_ptr = nullptr);
+                              const uint32_t* n_ptr = nullptr, uint32_t* clamped_total = nullptr, uint64_t clamp = 0);
 bool use_classic_sort();
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
                                  uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);
@@ -349,10 +353,12 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 // call on this runtime (barrier packets around the fill), four of them per step were 3 % of the C3 step
 hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and bytes multiples of 4
 // binning.hip
+// D_dev (optional, device word): the instance count when the host does not know it yet (speculative stage 2); D is then the
+// CAPACITY the grids and the geometry are sized for
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
-                       int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
+                       int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0}, const uint32_t* D_dev = nullptr);
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
-                         bool pre_zeroed = false);
+                         bool pre_zeroed = false, const uint32_t* D_dev = nullptr);
 int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value
 int set_blend_granularity(int mode);
 int set_forward_variant(int v);           // blend.hip: 0 = default, 1 quadrant lists, 2 tile, 3 | 4 strip lists; returns the previous      // blend.hip: 0 = by tile count, 1 = coarse, 2 = fine (16 waves per tile)

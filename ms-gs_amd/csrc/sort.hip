@@ -110,7 +110,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict__ partials, int64_t nb,
                                                             uint64_t* __restrict__ total_out,
                                                             uint64_t* __restrict__ status = nullptr,
-                                                            volatile uint64_t* host = nullptr, uint64_t ticket = 0) {
+                                                            volatile uint64_t* host = nullptr, uint64_t ticket = 0,
+                                                            uint32_t* __restrict__ clamped_total = nullptr,
+                                                            uint64_t clamp = 0) {
     __shared__ uint64_t s_w[4];
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
     if (threadIdx.x == 0) {
         partials[nb] = s_carry;
         if (total_out) *total_out = s_carry;
+        if (clamped_total) *clamped_total = (uint32_t)(s_carry < clamp ? s_carry : clamp);   // speculative stage 2's D
         if (status) { status[0] = s_carry; status[1] = 0; }
         if (host) {
             host[0] = s_carry;
@@ -626,11 +629,12 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
-                              uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr) {
+                              uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr, uint32_t* clamped_total,
+                              uint64_t clamp) {
     const int64_t nb = scan_blocks(n > 0 ? n : 1);
     if (n <= 0) {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total, status,
-                           (volatile uint64_t*)host_mapped, ticket);
+                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp);
         return hipGetLastError();
     }
     if (!use_classic_sort()) {
@@ -647,7 +651,7 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
                        stage ? out : (uint32_t*)nullptr, n_ptr);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
-                       (volatile uint64_t*)host_mapped, ticket);
+                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
                        stage ? (const uint32_t*)nullptr : gather, out, n, partials, n_ptr);
     return hipGetLastError();
@@ -711,6 +715,17 @@ struct GroupGeom {
     size_t zero_words(int passes) const { return (size_t)passes * 256 * ngroups; }
 };
 
+// does radix_sort_pairs(n, bits) honour a device-side element count?  (the grouped, staged configurations do)
+bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit) {
+    if (n <= 0) return false;
+    int passes = (end_bit - begin_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
+    static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
+    const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
+    return !onesweep && !scan_table && passes <= 4 && staged;
+}
+
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {
     if (n <= 0) return false;
     int passes = (end_bit - begin_bit + 7) / 8;
@@ -753,9 +768,12 @@ void launch_grouped_pass(const uint32_t* src_k, const uint32_t* src_v, uint32_t*
 // number of survivors V is written to *n_valid_dev, the remaining passes run over V pairs, and keys_out / vals_out hold the V
 // sorted survivors (the tail beyond V is unspecified).  Configurations without the compacting kernels sort all n pairs
 // (the dropped keys sort last) and report V = n: every consumer of *n_valid_dev stays correct either way.
+// n_dev (optional, device word): the element count when the host only knows an upper bound n (speculative stage 2): every pass
+// takes its count from it, grids and group geometry are those of n.  Grouped configurations only (the caller checks with
+// radix_sort_supports_device_count).
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s, bool pre_zeroed,
-                            uint32_t* n_valid_dev) {
+                            uint32_t* n_valid_dev, const uint32_t* n_dev) {
     if (n <= 0) {
         if (n_valid_dev) hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, n_valid_dev, 0u);
         return hipSuccess;
@@ -823,14 +841,14 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
             uint32_t* gs = gsum_all + (size_t)p * 256 * ngroups;
             const dim3 grid((unsigned)nb), block(SORT_THREADS);
             const bool drop = compact && p == 0;
-            const uint32_t* np = compact && p > 0 ? n_valid_dev : nullptr;
+            const uint32_t* np = n_dev ? n_dev : (compact && p > 0 ? n_valid_dev : nullptr);
             uint32_t* no = drop ? n_valid_dev : nullptr;
             if (big && G.scanned) {
                 hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
-                                   (const uint32_t*)nullptr);
+                                   np);
                 hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, s, gs, ngroups);
                 hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                                   mask, nb, hist, gs, gsize, ngroups, true, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                                   mask, nb, hist, gs, gsize, ngroups, true, np, (uint32_t*)nullptr);
             } else if (big) {
                 launch_grouped_pass<16>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np, no, s);
             } else if (mid) {

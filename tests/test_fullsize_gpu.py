@@ -129,9 +129,9 @@ def test_c3_tile_lists_are_depth_sorted_and_ranges_checksum(c3):
     P = sc.P
     W, H = cam.image_width, cam.image_height
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    ids = binning[:4 * D].view(torch.int32).long()
-    roff = (4 * max(D, 1) + 255) // 256 * 256
-    ranges = binning[roff:roff + 8 * tiles].view(torch.int32).view(tiles, 2).long()
+    ioff = (8 * tiles + 255) // 256 * 256                                # BinningLayout: tile ranges first, then the ids
+    ids = binning[ioff:ioff + 4 * D].view(torch.int32).long()
+    ranges = binning[:8 * tiles].view(torch.int32).view(tiles, 2).long()
     lo, hi = ranges[:, 0], ranges[:, 1]
     nonempty = hi > lo
     n_sentinel = D - hi.max().item()                                     # surplus slots parked behind the last tile
@@ -223,8 +223,7 @@ def test_config_c5_stress_4k():
     assert D > 10_000_000
     assert torch.isfinite(out["render"]).all() and all(torch.isfinite(p.grad).all() for p in pc.parameters())
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    roff = (4 * D + 255) // 256 * 256
-    ranges = binning[roff:roff + 8 * tiles].view(torch.int32).view(tiles, 2).long()
+    ranges = binning[:8 * tiles].view(torch.int32).view(tiles, 2).long()                  # BinningLayout: ranges first
     n_sentinel = D - ranges[:, 1].max().item()
     assert (ranges[:, 1] - ranges[:, 0]).sum().item() + n_sentinel == D and 0 <= n_sentinel <= D // 200
     orc, og = _oracle(pc.seen, cam, st, bg, dL)

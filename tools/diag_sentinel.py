@@ -19,9 +19,9 @@ call = dgr._Call(dgr.GaussianRasterizationSettings(image_height=cam.image_height
 color, aps, dep, radii, psz, (geom, binning, image, D) = dgr._forward_impl(call)
 P = sc.P; W, H = cam.image_width, cam.image_height
 gx, gy = (W + 15) // 16, (H + 15) // 16; tiles = gx * gy
-ids = binning[:4 * D].view(torch.int32).long()
-roff = (4 * D + 255) // 256 * 256
-ranges = binning[roff:roff + 8 * tiles].view(torch.int32).view(tiles, 2).long()
+ioff = (8 * tiles + 255) // 256 * 256
+ids = binning[ioff:ioff + 4 * D].view(torch.int32).long()
+ranges = binning[:8 * tiles].view(torch.int32).view(tiles, 2).long()
 print("D", D, "sum", (ranges[:,1]-ranges[:,0]).sum().item(), "max hi", ranges[:,1].max().item())
 g = ids[D - 1].item()
 def al(x): return (x + 255) // 256 * 256

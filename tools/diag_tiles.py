@@ -14,8 +14,7 @@ geom, binning, image, D = ctx.state
 W, H = cam.image_width, cam.image_height
 gx, gy = (W + 15) // 16, (H + 15) // 16
 tiles = gx * gy
-roff = (4 * max(D, 1) + 255) // 256 * 256
-ranges = binning[roff:roff + 8 * tiles].view(torch.int32).view(tiles, 2).long()
+ranges = binning[:8 * tiles].view(torch.int32).view(tiles, 2).long()
 lens = (ranges[:, 1] - ranges[:, 0]).float()
 N = W * H
 ncon = image[(4 * N + 255) // 256 * 256:][:4 * N].view(torch.int32).view(H, W).float()
