@@ -430,13 +430,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
     }
 }
 
-// Fine-grained variant for FEW tiles (low pyramid levels): sixteen wave64s per tile, each owning one 4x4 pixel sub-block
-// (lanes 0..15).  With fewer than ~500 tiles the kernel above is latency-bound — one wave per SIMD at best, and a
-// pixel's list is inherently sequential — so its time is the length of the longest per-wave entry chain; splitting a
-// quadrant into four sub-blocks with their own exact hit lists shortens that chain (an entry reaches a 4x4 block far
-// less often than an 8x8 one) at the price of idle lanes, which are free in that regime.  Same arithmetic per pixel in
-// the same order: results are bit-identical to blend_forward_kernel.
-__global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+// Fine-grained variant for FEW tiles (low pyramid levels): one wave64 per 4x4 pixel sub-block (lanes 0..15) — sixteen per tile —
+// in workgroups of WAVES waves, G = 16 / WAVES workgroups per tile.  With fewer than ~300 tiles the quadrant kernel is latency-bound
+// — one wave per SIMD at best, and a pixel's list is inherently sequential — so its time is the length of the longest per-wave entry
+// chain; a 4x4 block with its own exact hit list shortens that chain (an entry reaches it far less often than an 8x8 quadrant) at
+// the price of idle lanes, which are free in that regime.  Round 3: (i) the sixteen waves of a tile used to share ONE workgroup,
+// i.e. one CU did a whole tile's work while at 135 / 40 / 12 / 2 tiles most CUs had none; the launch now splits a tile over G
+// workgroups (every one stages the tile's list for itself: redundant reads of a few MB against idle CUs) so that tiles x G fills
+// the chip; (ii) every wave classifies the batch against its OWN block and compacts in the same pass (lanes = records) — no mask
+// array, one barrier less per batch; (iii) the next batch's records travel in registers while the current one is walked.
+// Same arithmetic per pixel in the same order: results are bit-identical to blend_forward_kernel.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
                                                             float* __restrict__ out_color,
@@ -445,78 +450,67 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
                                                             uint4* __restrict__ clear_ptr, size_t clear_n16,
-                                                            uint32_t* __restrict__ tile_last,
                                                             uint32_t* __restrict__ order_flag) {
+    constexpr int T = 64 * WAVES, G = 16 / WAVES;
+    constexpr int R = (BATCH + T - 1) / T;               // records a thread stages per batch
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
-    __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[16][BATCH + LIST_PAD];
-    __shared__ uint32_t s_wlast[32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[WAVES][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
-    if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
-
-    const int num_tiles = vp.gx * vp.gy;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    if (threadIdx.x == 0) {
+        write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
+        if (blockIdx.x == 0 && order_flag) *order_flag = 0u;      // (no backward launch order in this regime)
+    }
+    const int tile = blockIdx.x / G, grp = blockIdx.x % G;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int px = tx * TILE + (w & 3) * 4 + (lane & 3);
-    const int py = ty * TILE + (w >> 2) * 4 + ((lane >> 2) & 3);
+    const int sb = grp * WAVES + w;                       // this wave's 4x4 sub-block of the tile
+    const int px = tx * TILE + (sb & 3) * 4 + (lane & 3);
+    const int py = ty * TILE + (sb >> 2) * 4 + ((lane >> 2) & 3);
     const bool inside = lane < 16 && px < vp.W && py < vp.H;     // lanes 16..63 idle: this variant buys latency, not throughput
     const float pxf = (float)px, pyf = (float)py;
-    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const float bx0 = (float)(tx * TILE + (sb & 3) * 4), by0 = (float)(ty * TILE + (sb >> 2) * 4);
     const uint2 range = ranges[tile];
     const int len = (int)(range.y - range.x);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t last = 0, walked = 0;
-    // lanes still blending, as a SCALAR mask: every predicate below is the ballot of one direct comparison combined with
-    // scalar logic (a ballot of a derived bool costs two VALU instructions per use; these kernels' time is their VALU
-    // instruction count), and per-lane selects take their condition from the mask for free
     uint64_t alive = __builtin_amdgcn_ballot_w64(inside);
 
-    // In this regime (at most a few workgroups per CU) nothing else hides the id -> record gather of a batch (two dependent
-    // global latencies, ~2 us of the ~4.5 us a batch takes): the NEXT batch's records are fetched into registers while the current
-    // one is classified and walked.
-    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-    if (tid < min(BATCH, len)) {
-        const uint32_t id = ids[range.x + tid];
-        p0 = rec[id].r0; p1 = rec[id].r1; p2 = rec[id].r2;
-    }
+    float4 p0[R], p1[R], p2[R];
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int e = tid + k * T;
+            if (e < BATCH && base + e < len) {
+                const uint32_t id = ids[range.x + base + e];
+                p0[k] = rec[id].r0; p1[k] = rec[id].r1; p2[k] = rec[id].r2;
+            }
+        }
+    };
+    fetch(0);
     for (int base = 0; base < len; base += BATCH) {
         if (__syncthreads_and(alive == 0)) break;    // barrier also protects the LDS batch
         const int n = min(BATCH, len - base);
-        if (tid < n) { s_r0[tid] = doubled_w(p0); s_r1[tid] = p1; s_r2[tid] = p2; }
-        if (tid < BATCH && base + BATCH + tid < len) {
-            const uint32_t id = ids[range.x + base + BATCH + tid];
-            p0 = rec[id].r0; p1 = rec[id].r1; p2 = rec[id].r2;
-        }
-        __syncthreads();
-        {   // classification spread over the 1024 threads: thread -> (record e, sub-block row g), four 4x4 rectangles each
-            const int e = tid & (BATCH - 1), g = tid >> 8;
-            uint32_t m = 0;
-            if (e < n) {
-                const float4 r0 = s_r0[e];
-                const float C = s_r1[e].x, tau2 = s_r2[e].w;
-                if (!(tau2 > -1.0e38f)) m = 0xFu;
-                else {
-                    const float y0 = ty0 + (float)(4 * g);
 #pragma unroll
-                    for (int sx = 0; sx < 4; ++sx) {
-                        const float x0 = tx0 + (float)(4 * sx);
-                        if (levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, x0, x0 + 3.0f, y0, y0 + 3.0f)) m |= 1u << sx;
-                    }
-                }
-            }
-            s_mask[g][e] = (uint8_t)m;
+        for (int k = 0; k < R; ++k) {
+            const int e = tid + k * T;
+            if (e < n) { s_r0[e] = doubled_w(p0[k]); s_r1[e] = p1[k]; s_r2[e] = p2[k]; }
         }
+        fetch(base + BATCH);
         __syncthreads();
-        // per-wave compaction of the batch to this wave's quadrant; the list holds BYTE offsets of the 16-byte records
-        // (one shift less per pair evaluation)
+        // classification against this wave's block and compaction in one pass; the list holds BYTE offsets of the records
         int cnt = 0;
 #pragma unroll
         for (int c = 0; c < BATCH / 64; ++c) {
             const int e = c * 64 + lane;
-            const bool hit = e < n && ((s_mask[w >> 2][e] >> (w & 3)) & 1u);
+            bool hit = false;
+            if (e < n) {
+                const float4 r0 = s_r0[e];
+                const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                hit = !(tau2 > -1.0e38f) ||
+                      levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + 3.0f, by0, by0 + 3.0f);
+            }
             const uint64_t b = __ballot(hit);
             if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint32_t)(e << 4);
             cnt += __popcll(b);
@@ -526,7 +520,6 @@ __global__ __launch_bounds__(1024) void blend_forward_fine_kernel(ViewParams vp,
         if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;   // once per batch, not per pair
     }
     forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    note_tile_last(s_wlast, 16, inside ? last : 0u, walked >> 2, tile, w, lane, tile_last, order_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -705,32 +698,35 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
     }
 }
 
-// Fine-grained variant for FEW tiles (low pyramid levels), the counterpart of blend_forward_fine_kernel: sixteen wave64s
-// per tile on 4x4 pixel sub-blocks (lanes 0..15), same per-pixel arithmetic in the same order as blend_backward_kernel;
-// one atomic per (sub-block, Gaussian, component).
-__global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+// Fine-grained variant for FEW tiles (low pyramid levels), the counterpart of blend_forward_fine_kernel: one wave64 per 4x4 pixel
+// sub-block (lanes 0..15), WAVES per workgroup, 16 / WAVES workgroups per tile; same per-pixel arithmetic in the same order as
+// blend_backward_kernel; one atomic per (sub-block, Gaussian, component).  A workgroup walks the tile's list back from the last
+// entry ITS pixels blended.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                              const uint32_t* __restrict__ ids,
                                                              const uint2* __restrict__ ranges,
                                                              const float* __restrict__ final_T,
                                                              const uint32_t* __restrict__ n_contrib,
                                                              const float* __restrict__ dL_dcolor,
                                                              grad_acc_t* __restrict__ grad_rec) {
+    constexpr int T = 64 * WAVES, G = 16 / WAVES;
+    constexpr int R = (BATCH + T - 1) / T;               // records a thread stages per batch
     __shared__ float4 s_r0[BATCH], s_r1[BATCH];
     __shared__ float s_b[BATCH], s_tau[BATCH];
     __shared__ uint32_t s_id[BATCH];
-    __shared__ uint8_t s_mask[4][BATCH];                 // [sub-block row][record]: bit sx = sub-block (sx, row) is reached
-    __shared__ uint16_t s_list[16][BATCH];
-    __shared__ uint32_t s_wmax[16];
+    __shared__ uint16_t s_list[WAVES][BATCH];
+    __shared__ uint32_t s_wmax[WAVES];
 
-    const int num_tiles = vp.gx * vp.gy;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+    const int tile = blockIdx.x / G, grp = blockIdx.x % G;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int px = tx * TILE + (w & 3) * 4 + (lane & 3);
-    const int py = ty * TILE + (w >> 2) * 4 + ((lane >> 2) & 3);
+    const int sb = grp * WAVES + w;                       // this wave's 4x4 sub-block of the tile
+    const int px = tx * TILE + (sb & 3) * 4 + (lane & 3);
+    const int py = ty * TILE + (sb >> 2) * 4 + ((lane >> 2) & 3);
     const bool inside = lane < 16 && px < vp.W && py < vp.H;     // lanes 16..63 idle (see blend_forward_fine_kernel)
     const float pxf = (float)px, pyf = (float)py;
-    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+    const float bx0 = (float)(tx * TILE + (sb & 3) * 4), by0 = (float)(ty * TILE + (sb >> 2) * 4);
     const uint2 range = ranges[tile];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const size_t N = (size_t)vp.W * vp.H;
@@ -745,9 +741,9 @@ __global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp
     const uint32_t wave_last = wave_max_u32(st.last);
     if (lane == 0) s_wmax[w] = wave_last;
     __syncthreads();
-    uint32_t tile_last = 0;
+    uint32_t grp_last = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) tile_last = max(tile_last, s_wmax[k]);
+    for (int k = 0; k < WAVES; ++k) grp_last = max(grp_last, s_wmax[k]);
 
     // S = sum_c dL/dC_c * (colour composited BEHIND the current entry, background included, normalised by the
     // transmittance in front of it).  dL/dalpha_i = T_i (g_i - S_i) with g_i = sum_c dL/dC_c colour_i,c, and
@@ -757,51 +753,47 @@ __global__ __launch_bounds__(1024) void blend_backward_fine_kernel(ViewParams vp
     const bool alane = lane < 16 && (!(lane & 2) || lane == 2);        // the nine lanes that issue the per-entry atomics
     const uint32_t aoff = row_reduce_component(lane);
 
-    const int nb = ((int)tile_last + BATCH - 1) / BATCH;
+    const int nb = ((int)grp_last + BATCH - 1) / BATCH;
     // register prefetch of the next (nearer) batch, as in blend_forward_fine_kernel
-    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-    uint32_t pid = 0;
-    if (nb > 0 && tid < BATCH && (nb - 1) * BATCH + tid < (int)tile_last) {
-        pid = ids[range.x + (nb - 1) * BATCH + tid];
-        p0 = rec[pid].r0; p1 = rec[pid].r1; p2 = rec[pid].r2;
-    }
+    float4 p0[R], p1[R], p2[R];
+    uint32_t pid[R];
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int e = tid + k * T;
+            if (e < BATCH && base + e < (int)grp_last) {
+                pid[k] = ids[range.x + base + e];
+                p0[k] = rec[pid[k]].r0; p1[k] = rec[pid[k]].r1; p2[k] = rec[pid[k]].r2;
+            }
+        }
+    };
+    if (nb > 0) fetch((nb - 1) * BATCH);
     for (int b = nb - 1; b >= 0; --b) {
         __syncthreads();                              // previous batch fully consumed (and flushed)
         const int base = b * BATCH;
-        const int n = min(BATCH, (int)tile_last - base);
-        if (tid < n) {
-            s_r0[tid] = doubled_w(p0); s_r1[tid] = p1; s_b[tid] = p2.x; s_id[tid] = pid;
-            s_tau[tid] = p2.w;
-        }
-        if (b > 0 && tid < BATCH) {                   // the batches in front of the last one are full
-            pid = ids[range.x + base - BATCH + tid];
-            p0 = rec[pid].r0; p1 = rec[pid].r1; p2 = rec[pid].r2;
-        }
-        __syncthreads();
-        {   // classification spread over the 1024 threads: thread -> (record e, sub-block row g), four 4x4 rectangles each
-            const int e = tid & (BATCH - 1), g = tid >> 8;
-            uint32_t m = 0;
-            if (e < n) {
-                const float4 r0 = s_r0[e];
-                const float C = s_r1[e].x, tau2 = s_tau[e];
-                if (!(tau2 > -1.0e38f)) m = 0xFu;
-                else {
-                    const float y0 = ty0 + (float)(4 * g);
+        const int n = min(BATCH, (int)grp_last - base);
 #pragma unroll
-                    for (int sx = 0; sx < 4; ++sx) {
-                        const float x0 = tx0 + (float)(4 * sx);
-                        if (levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, x0, x0 + 3.0f, y0, y0 + 3.0f)) m |= 1u << sx;
-                    }
-                }
+        for (int k = 0; k < R; ++k) {
+            const int e = tid + k * T;
+            if (e < n) {
+                s_r0[e] = doubled_w(p0[k]); s_r1[e] = p1[k]; s_b[e] = p2[k].x; s_id[e] = pid[k];
+                s_tau[e] = p2[k].w;
             }
-            s_mask[g][e] = (uint8_t)m;
         }
+        if (b > 0) fetch(base - BATCH);
         __syncthreads();
+        // classification against this wave's block and compaction in one pass
         int cnt = 0;
 #pragma unroll
         for (int c = 0; c < BATCH / 64; ++c) {
             const int e = c * 64 + lane;
-            const bool hit = e < n && (uint32_t)(base + e) < wave_last && ((s_mask[w >> 2][e] >> (w & 3)) & 1u);
+            bool hit = false;
+            if (e < n && (uint32_t)(base + e) < wave_last) {
+                const float4 r0 = s_r0[e];
+                const float C = s_r1[e].x, tau2 = s_tau[e];
+                hit = !(tau2 > -1.0e38f) ||
+                      levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + 3.0f, by0, by0 + 3.0f);
+            }
             const uint64_t bal = __ballot(hit);
             if (hit) s_list[w][cnt + __popcll(bal & lt_mask)] = (uint16_t)e;
             cnt += __popcll(bal);
@@ -1248,6 +1240,24 @@ int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen
 // blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
 static std::atomic<int> g_granularity{[] { const char* e = getenv("MSGS_BLEND_GRANULARITY"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_blend_granularity(int mode) { return g_granularity.exchange(mode == 1 || mode == 2 ? mode : 0); }
+// workgroups per tile of the fine-grained kernels (1, 2, 4, 8 or 16): enough of them that tiles x G fills the 256 CUs a few
+// times over (MSGS_FINE_SPLIT = 1 | 2 | 4 | 8 | 16 forces one; measured in profiles/r3_notes.md)
+static int fine_split(int tiles) {
+    static const int forced = [] { const char* e = getenv("MSGS_FINE_SPLIT"); const int v = e ? atoi(e) : 0;
+                                   return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }();
+    if (forced) return forced;
+    int g = 1;
+    while (g < 16 && (long long)tiles * g < 768) g <<= 1;
+    return g;
+}
+template <int WAVES, class... Args>
+static void launch_fine_fwd(int tiles, hipStream_t s, Args... args) {
+    hipLaunchKernelGGL((blend_forward_fine_kernel<WAVES>), dim3(tiles * (16 / WAVES)), dim3(64 * WAVES), 0, s, args...);
+}
+template <int WAVES, class... Args>
+static void launch_fine_bwd(int tiles, hipStream_t s, Args... args) {
+    hipLaunchKernelGGL((blend_backward_fine_kernel<WAVES>), dim3(tiles * (16 / WAVES)), dim3(64 * WAVES), 0, s, args...);
+}
 static bool use_fine(int tiles, int max_tiles) {
     const int g = g_granularity.load();
     return g == 2 || (g == 0 && tiles < max_tiles);
@@ -1353,9 +1363,17 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     // tile_last sits in front of tile_order in the image state (ImageLayout): the order's validity word
     uint32_t* order_flag = tile_last ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_last) +
                                                                    align256(4 * (size_t)tiles)) + tiles : nullptr;
-    if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))        // few tiles (low pyramid levels): sixteen waves per tile on 4x4 sub-blocks
-        hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
+    auto fine = [&] {            // few tiles (low pyramid levels): one wave per 4x4 sub-block, the tile split over G workgroups
+        switch (fine_split(tiles)) {
+            case 1: launch_fine_fwd<16>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
+            case 2: launch_fine_fwd<8>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
+            case 4: launch_fine_fwd<4>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
+            case 8: launch_fine_fwd<2>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
+            default: launch_fine_fwd<1>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
+        }
+    };
+    if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))
+        fine();
     else if (fwd_gen == 1)
         hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last, order_flag);
@@ -1368,8 +1386,7 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
                            out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
                            order_flag);
     else if (fwd_gen >= 3)
-        hipLaunchKernelGGL(blend_forward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
+        fine();
     else
         hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
                            out_ps, out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
@@ -1383,8 +1400,13 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
     if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD)))
-        hipLaunchKernelGGL(blend_backward_fine_kernel, dim3(tiles), dim3(1024), 0, s, vp, rec, ids, ranges, final_T,
-                           n_contrib, dL_dcolor, grad_rec);
+        switch (fine_split(tiles)) {
+            case 1: launch_fine_bwd<16>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
+            case 2: launch_fine_bwd<8>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
+            case 4: launch_fine_bwd<4>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
+            case 8: launch_fine_bwd<2>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
+            default: launch_fine_bwd<1>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
+        }
     else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec, tile_order);
