@@ -1240,15 +1240,16 @@ int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen
 // blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
 static std::atomic<int> g_granularity{[] { const char* e = getenv("MSGS_BLEND_GRANULARITY"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_blend_granularity(int mode) { return g_granularity.exchange(mode == 1 || mode == 2 ? mode : 0); }
-// workgroups per tile of the fine-grained kernels (1, 2, 4, 8 or 16): enough of them that tiles x G fills the 256 CUs a few
-// times over (MSGS_FINE_SPLIT = 1 | 2 | 4 | 8 | 16 forces one; measured in profiles/r3_notes.md)
+// workgroups per tile of the fine-grained kernels (MSGS_FINE_SPLIT = 1 | 2 | 4 | 8 | 16 forces one).  Measured on the pyramid of the
+// C3 scene (forward / backward us at 135, 40, 12, 2 tiles; profiles/r3_notes.md): G = 1: 105/184, 139/228, 146/241, 132/224;
+// G = 2: 87/152, 114/192, 115/194, 100/175; G = 4: 87/140, 111/180, 108/182, 98/166; G = 8: 112/151, 133/190, 138/188, 117/166;
+// G = 16: 152/164, 158/198, 149/176, 130/162 — four workgroups of four waves per tile at every level: beyond that every workgroup
+// stages and classifies the tile's whole list with too few threads.
 static int fine_split(int tiles) {
     static const int forced = [] { const char* e = getenv("MSGS_FINE_SPLIT"); const int v = e ? atoi(e) : 0;
                                    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }();
     if (forced) return forced;
-    int g = 1;
-    while (g < 16 && (long long)tiles * g < 768) g <<= 1;
-    return g;
+    return tiles < 768 ? 4 : 1;          // (>= 768 tiles only when the fine kernels are forced: one workgroup per tile fills the chip)
 }
 template <int WAVES, class... Args>
 static void launch_fine_fwd(int tiles, hipStream_t s, Args... args) {
