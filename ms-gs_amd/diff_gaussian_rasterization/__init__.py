@@ -256,8 +256,11 @@ def set_deterministic(on=True):
     return bool(_C.lib.msgs_set_deterministic(1 if on else 0))
 
 
-# instance count of the previous forward per (device, P, W, H): the next call sizes its binning buffers from it, so
-# that msgs_forward can run both stages in one library call (no allocation in the bubble behind the one host sync)
+# instance-count guess per (device, P, W, H, filters): the next call sizes its binning buffers from it (+12.5 %), and
+# msgs_forward launches stage 2 on them speculatively, with grids sized for that capacity — so the guess has to follow the
+# scene DOWN quickly as well (an outlier, e.g. one render of the same model without its multi-scale filters, would otherwise
+# leave every following call with stage-2 grids and buffers many times too large): it halves its excess over the last count
+# on every call; views whose counts differ by up to ~28 % alternate without outgrowing it.
 _last_instances = {}
 
 
@@ -283,7 +286,7 @@ def _a256(n):
 def _forward_impl(call, grad_rec=None):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
-    key = (dev.index, P, W, H)
+    key = (dev.index, P, W, H, call.view.filter_small, call.view.filter_large)
     with _on_device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
@@ -313,8 +316,7 @@ def _forward_impl(call, grad_rec=None):
                                   _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
-        # views of one scene differ in D: remember a slowly decaying maximum rather than the last value
-        _last_instances[key] = max(D, int(0.97 * guess)) if guess is not None else D
+        _last_instances[key] = max(D, (guess + D) // 2) if guess is not None else D
         del scratch1, scratch2, tmp
         if not done.value:                              # first frame of this shape, or the scene grew past the margin
             binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)

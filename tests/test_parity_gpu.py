@@ -259,12 +259,14 @@ def test_forward_capacity_guess_paths_give_identical_results():
     bg = torch.tensor([0.0, 0.1, 0.2])
     dL = scenes.grad_seed(W, H, 23)
 
+    key = (torch.cuda.current_device(), 4000, W, H, 0, 0)     # (device, P, W, H, filter_small, filter_large)
+
     def run(seed_guess):
         dgr._last_instances.clear()
         if seed_guess is not None:
-            dgr._last_instances[(torch.cuda.current_device(), 4000, W, H)] = seed_guess
+            dgr._last_instances[key] = seed_guess
         out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
-        return out, pc, m2, dgr._last_instances[(torch.cuda.current_device(), 4000, W, H)]
+        return out, pc, m2, dgr._last_instances[key]
     ref, pref, mref, D = run(None)
     assert D > 0
     for guess in (1, max(D // 2, 1), D, 10 * D):
