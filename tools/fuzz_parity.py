@@ -24,8 +24,9 @@ for it in range(N):
     fade = rng.choice([0.0, 0.5, 1.0])
     gran = rng.choice([0, 1, 2])
     bwd_gen = rng.choice([0, 1, 2])
+    fwd_var = rng.choice([0, 0, 1, 3, 4])
     seed = rng.randint(0, 10 ** 6)
-    cfg = dict(P=P, W=W, H=H, deg=deg, ms=ms, fade=fade, gran=gran, bwd_gen=bwd_gen, seed=seed)
+    cfg = dict(P=P, W=W, H=H, deg=deg, ms=ms, fade=fade, gran=gran, bwd_gen=bwd_gen, fwd_var=fwd_var, seed=seed)
     try:
         sc, cam = small_scene(P, W, H, seed, sh_degree=deg, multiscale=ms,
                               **({"scale_k": 0.004 * 1920.0 / max(W, 8) * 0.3} if ms else {}))
@@ -34,10 +35,12 @@ for it in range(N):
         dL = scenes.grad_seed(W, H, seed % 97)
         pg = dgr._C.lib.msgs_set_blend_granularity(gran)
         pb = dgr._C.lib.msgs_set_backward_generation(bwd_gen)
+        pf = dgr._C.lib.msgs_set_forward_variant(fwd_var)
         try:
             out, pc, m2 = hip_render(sc, cam, st, bg, dL)
         finally:
             dgr._C.lib.msgs_set_blend_granularity(pg)
+            dgr._C.lib.msgs_set_forward_variant(pf)
             dgr._C.lib.msgs_set_backward_generation(pb)
         orc = oc.rasterize(pc.seen, cam, st, bg)
         og = oc.backward(orc, dL)
