@@ -26,6 +26,8 @@ Output: ONE JSON line on rank 0 (see the driver contract in the task statement) 
 timed on this box's host cores on a bounded sample).
 """
 import argparse
+import contextlib
+import gc
 import json
 import math
 import os
@@ -41,6 +43,26 @@ for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd",
 # hipIpcGetMemHandle (already exported on the driver's boxes; kept here for any other launcher)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+# thread pools sized for the CPUs this container may USE (its cgroup quota), not the ones it can see: with one OpenMP thread
+# per visible CPU (128 on a 256-CPU box granted 16) the quota is spent spinning and the kernel parks the whole process —
+# the kernel-launching thread included — for 15-70 ms at a time (hostinfo.py; profiles/r3_notes.md "host stalls")
+from hostinfo import limit_thread_pools, usable_cpus  # noqa: E402
+HOST_THREADS = limit_thread_pools()
+
+
+@contextlib.contextmanager
+def quiet_gc():
+    """Timed regions run with Python's cyclic garbage collector paused (collected right before): a full collection of this
+    process's heap takes 30-70 ms and lands, at a position fixed by the allocation count, inside some timed window of ~10 ms
+    (seen as a 5.9 ms 'step' at one pyramid level; tools/diag_level_jitter2.py).  Interpreter housekeeping, not part of a step."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _self_launch_if_needed():
@@ -107,7 +129,7 @@ def cpu_baseline(scenes, scene, settings, W, H, runs=2):
     cam = scenes.front_camera(W, H)
     bg = torch.zeros(3)
     dL = scenes.grad_seed(W, H, 2)
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()                  # affinity ∩ cgroup quota (16 of the 256 visible CPUs on the MI355X boxes)
 
     d_ref = [None]
 
@@ -128,10 +150,11 @@ def cpu_baseline(scenes, scene, settings, W, H, runs=2):
             "single_thread": {"value": round(W * H / 1e6 / one[0], 4), "cores": 1, "seconds": round(one[0], 2),
                               "fwd_s": round(one[1], 2), "bwd_s": round(one[2], 2)},
             "instances_reference_duplication": d_ref[0],
-            "scaling_note": f"a checker, not a tuned baseline: {cores} cores are only {one[0] / dt:.1f}x one thread "
-                            "(double atomics in the backward, serial sort stages)",
+            "scaling_note": f"a checker, not a tuned baseline: {cores} threads are {one[0] / dt:.1f}x one thread "
+                            "(double atomics in the backward, serial sort stages); cores = the CPUs this container may "
+                            f"use (cgroup quota), of {os.cpu_count()} visible",
             "sample": f"the whole workload (same scene, settings, {W}x{H}), forward+backward, float32 "
-                      f"C++/OpenMP oracle: all {cores} host cores (best of {runs} runs) and one thread (one run)"}
+                      f"C++/OpenMP oracle: the {cores} usable host cores (best of {runs} runs) and one thread (one run)"}
 
 
 def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
@@ -147,11 +170,13 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        return round(1e3 * (time.perf_counter() - t) / steps, 4)
+        with quiet_gc():
+            t = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+        return round(1e3 * dt / steps, 4)
 
     fb, on, off, sizes, vis = [], [], [], [], []
     aa = dict(filter_small=True, filter_large=True, fade_size=1.0)
@@ -173,7 +198,42 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
         sizes.append([W, H])
     for p_ in pc.parameters():
         p_.grad = None
-    return ({"levels": sizes, "ms": fb, "rendered_gaussians": vis,
+    # Informational, NOT the BASELINE scene: the same model after MS-GS's own bookkeeping has seen it.  The C3 recipe (SURVEY
+    # 8(d)) gives min_pixel_sizes to half of the level-0 Gaussians only; in a trained MS-GS model update_pixel_sizes
+    # (scene/gaussian_model.py:663-686) has given one to every level-0 Gaussian that was ever visible — its smallest observed
+    # footprint at level 0 — which is what lets filter_small drop them at the coarser levels.  Here: every level-0 Gaussian
+    # carries 0.8 x its level-0 pixel size of this camera; the inserted coarse-level Gaussians are untouched.
+    trained = None
+    try:
+        cam0 = scenes.front_camera(1920, 1080).to(dev)
+        with torch.no_grad():
+            ps0 = render(cam0, pc, PIPE, bg, **plain)["pixel_sizes"]
+        keep_min = pc.min_pixel_sizes
+        lvl0 = pc.max_pixel_sizes < 0                  # level-0 Gaussians: no max_pixel_sizes in the C3 recipe
+        pc.min_pixel_sizes = torch.where(lvl0 & (ps0 > 0), 0.8 * ps0, keep_min).contiguous()
+        fb2, vis2 = [], []
+        for k in range(7):
+            W, H = int(1920 / 2 ** k), int(1080 / 2 ** k)
+            cam = scenes.front_camera(W, H).to(dev)
+            dL = scenes.grad_seed(W, H, 40 + k).to(dev)
+
+            def train_step2():
+                for p_ in pc.parameters():
+                    p_.grad = None
+                render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+            fb2.append(timed(train_step2))
+            with torch.no_grad():
+                vis2.append(int((render(cam, pc, PIPE, bg, **settings)["radii"] > 0).sum().item()))
+        pc.min_pixel_sizes = keep_min
+        for p_ in pc.parameters():
+            p_.grad = None
+        trained = {"ms": fb2, "rendered_gaussians": vis2,
+                   "what": "informational, not the BASELINE scene: the same model with min_pixel_sizes on EVERY level-0 Gaussian "
+                           "(0.8 x its level-0 pixel size), as MS-GS's update_pixel_sizes leaves a trained model — the case the "
+                           "filters and the compacting sort are built for"}
+    except Exception as e:      # informational only
+        trained = {"error": repr(e)}
+    return ({"levels": sizes, "ms": fb, "rendered_gaussians": vis, "with_min_pixel_sizes_on_every_level0_gaussian": trained,
              "what": "render() + backward() per pyramid level k = 0..6 of the C3 scene, training settings"},
             {"levels": sizes, "filters_on": on, "filters_off": off,
              "what": "forward-only render() under no_grad per pyramid level (viewer.py:67-81 convention): filters_on = "
@@ -194,11 +254,13 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t) / steps
+        with quiet_gc():
+            t = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+        return 1e3 * dt / steps
 
     model = SyntheticGaussians(scene, dev)
     opt = FusedAdam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
@@ -350,16 +412,17 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t = time.perf_counter()
-        for k in range(n):
-            fn(k)
-        if drain is not None:
-            drain()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
+        with quiet_gc():
+            t = time.perf_counter()
+            for k in range(n):
+                fn(k)
+            if drain is not None:
+                drain()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -490,6 +553,9 @@ def main():
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "timing_note": "Python's cyclic GC is collected before and paused during every timed region (a full collection of this "
+                       f"process takes 30-70 ms); OMP/MKL/torch intra-op pools = {HOST_THREADS} threads (the container's CPU "
+                       f"quota is {usable_cpus()} of {os.cpu_count()} visible CPUs)",
         "config": {"workload": (
             ("C3 (BASELINE configs[2]): 1M Gaussians, 1920x1080, SH3, multi-scale fields, filter_small+filter_large, "
              "fade 0; frozen seeded scene scenes.config('C3') [SCALE_K 0.004: D/P = 9.6 instances per Gaussian by the "
@@ -660,11 +726,12 @@ def main():
                 for _ in range(args.warmup):
                     fused_step()
                 torch.cuda.synchronize()
-                tf = time.perf_counter()
-                for _ in range(args.steps):
-                    fused_step()
-                torch.cuda.synchronize()
-                tf = (time.perf_counter() - tf) / args.steps
+                with quiet_gc():
+                    tf = time.perf_counter()
+                    for _ in range(args.steps):
+                        fused_step()
+                    torch.cuda.synchronize()
+                    tf = (time.perf_counter() - tf) / args.steps
                 result["fused_path"] = {"ms_per_step": round(1e3 * tf, 4), "value": round(W * H / 1e6 / tf, 3),
                                         "unit": "Mpixels/s", "entry": "GaussianRasterizer.forward_raw"}
             except Exception as e:

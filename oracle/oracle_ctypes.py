@@ -136,6 +136,35 @@ class OracleResult:
         return int(lib().msgs_oracle_evaluated_pairs(self.state))
 
 
+def _usable_cpus():
+    """affinity mask ∩ cgroup CPU quota (a container may see 256 CPUs and be granted 16: OpenMP's default of one thread
+    per visible CPU then spends the quota spinning and the kernel parks the process for the rest of every 100 ms period)"""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.floor(int(q) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                n = min(n, max(1, q // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def _threads(num_threads):
+    """0 = every CPU this process may use (not every CPU it can see)"""
+    return int(num_threads) if num_threads and num_threads > 0 else _usable_cpus()
+
+
 def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_precomp=False,
               cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0):
     """Forward on a scenes.Scene.  Returns OracleResult with .color/.acc_pixel_size/.depth/.radii/
@@ -178,7 +207,7 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     r.borderline = torch.zeros(H, W, dtype=torch.uint8)
     rc = L.msgs_oracle_forward(C.byref(v), C.byref(g), _ptr(r.color), _ptr(r.acc_pixel_size), _ptr(r.depth),
                                _ptr(r.radii), _ptr(r.pixel_sizes), _ptr(r.borderline), C.byref(r.state),
-                               int(num_threads))
+                               _threads(num_threads))
     if rc != 0:
         raise RuntimeError(f"msgs_oracle_forward failed: {rc}")
     r._keep = [t, v, g]
@@ -211,7 +240,7 @@ def backward(r, dL_dcolor, num_threads=0, want_sums2d=False):
                _ptr(out["opacities"]), _ptr(out.get("scales")), _ptr(out.get("rotations")),
                _ptr(out.get("cov3D_precomp")), None, None, None)
     sums = torch.zeros(P, 9, dtype=torch.float64) if want_sums2d else None
-    rc = L.msgs_oracle_backward_ex(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), int(num_threads),
+    rc = L.msgs_oracle_backward_ex(r.state, C.byref(r.view), C.byref(r.g), _ptr(dl), C.byref(gr), _threads(num_threads),
                                    _ptr(sums))
     if rc != 0:
         raise RuntimeError(f"msgs_oracle_backward failed: {rc}")

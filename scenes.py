@@ -19,6 +19,12 @@ from typing import Optional
 import numpy as np
 import torch
 
+try:                                   # every harness that draws a scene: thread pools sized for the container's CPU quota
+    from hostinfo import limit_thread_pools
+    limit_thread_pools(reserve=0)
+except ImportError:                    # ms-gs_amd/host not on the path (the scene generator itself does not need it)
+    pass
+
 SCALE_K = 0.004
 SCALE_SIGMA = 0.6
 OFFSCREEN = 1.15

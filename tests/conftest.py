@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd",
         sys.path.insert(0, p)
 
 
+# thread pools sized for the container's CPU quota, not the host's CPU count (hostinfo.py): the GPU boxes show 256 CPUs and
+# grant 16 — an oversized pool gets the whole process parked by the cgroup for most of every 100 ms period
+from hostinfo import limit_thread_pools  # noqa: E402
+limit_thread_pools(reserve=0)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
