@@ -151,65 +151,11 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     const ViewParams vp = make_view_params(view);
     const Timer tm{timing, s};
 
-    // The instance count D comes back through pinned, device-mapped host words per host thread that a kernel writes itself
-    // and this thread polls: no copy command, no interrupt-driven wait (a blocking hipStreamSynchronize wakes up tens of
-    // microseconds after the data landed).  Words {0,1,2} = {D, flags, ticket} are written by the scan's middle kernel, where
-    // the grand total of the ordered counts is final; words {4,5} = {D, ticket} by K1 itself (EarlyCount): in the default
-    // configuration the host returns with D when K1 ENDS — depth sort, scan and the speculative stage 2 are queued behind it
-    // and nothing on the host waits for them.  The scan's words then only cross-check the early count (next call at the
-    // latest).  MSGS_NO_EARLY_COUNT=1: wait for the scan's words as before.  MSGS_BLOCKING_SYNC=1, or a failed pinned
-    // allocation: a 16-byte copy + hipStreamSynchronize.
-    static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
-    static const bool no_early = [] { const char* e = getenv("MSGS_NO_EARLY_COUNT"); return e && e[0] == '1'; }();
-    static thread_local uint64_t* t_host = nullptr;
-    static thread_local uint64_t* t_host_dev = nullptr;
-    static thread_local uint64_t t_ticket = 0;
-    static thread_local bool t_tried = false;
-    // K1's self-cleaning counter word: 8 bytes of device memory per (host thread, device), the only device memory this
-    // library owns (allocated and zeroed on the first forward of that thread on that device, never freed)
-    constexpr int MAX_DEVICES = 64;
-    static thread_local unsigned long long* t_ctr[MAX_DEVICES] = {};
-    static thread_local uint64_t t_prev_ticket = 0, t_prev_total = 0;      // last early count, for the cross-check
-    if (!blocking && !t_tried) {
-        t_tried = true;
-        void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
-            void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
-                t_host = (uint64_t*)h;
-                t_host_dev = (uint64_t*)d;
-                t_host[2] = 0;
-                t_host[5] = 0;
-            } else {
-                (void)hipHostFree(h);
-            }
-        }
-        (void)hipGetLastError();
-    }
-    const bool polled = !blocking && t_host != nullptr;
-    const uint64_t ticket = ++t_ticket;
-    const bool classic = use_classic_sort();
-    EarlyCount ec{nullptr, nullptr, 0};
-    if (polled && classic && !no_early && !view->debug) {
-        int dev = -1;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES) {
-            if (t_ctr[dev] == nullptr) {
-                void* c = nullptr;
-                if (hipMalloc(&c, 64) == hipSuccess) {
-                    if (hipMemset(c, 0, 64) == hipSuccess) t_ctr[dev] = (unsigned long long*)c;
-                    else (void)hipFree(c);
-                }
-                (void)hipGetLastError();
-            }
-            if (t_ctr[dev] != nullptr) ec = EarlyCount{t_ctr[dev], (unsigned long long*)(t_host_dev + 4), ticket};
-        }
-    }
-
     // K1 also clears the depth sort's group-sum table (saves a fill launch)
     ZeroJob zj1{nullptr, 0, nullptr, 0};
     const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
     tm.begin(MSGS_K_PREPROCESS);
-    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, ec));
+    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1));
     tm.end(MSGS_K_PREPROCESS);
     if ((rc = debug_sync(view, s))) return rc;
 
@@ -220,6 +166,36 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                              (uint32_t*)(geom + GL.nvalid)));
     tm.end(MSGS_K_DEPTH_SORT);
     if ((rc = debug_sync(view, s))) return rc;
+
+    // The instance count D comes back through three pinned, device-mapped host words per host thread {D, flags,
+    // ticket} that a kernel writes itself and this thread polls: no copy command, no interrupt-driven wait (a blocking
+    // hipStreamSynchronize wakes up tens of microseconds after the data landed, and until stage 2 is launched the GPU
+    // idles).  In the default sort/scan configuration the scan's middle kernel — where the grand total is final —
+    // writes them, so the host learns D while the last stage-1 kernel still runs.  MSGS_BLOCKING_SYNC=1, or a failed
+    // pinned allocation, falls back to a 16-byte copy + hipStreamSynchronize.
+    static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
+    static thread_local uint64_t* t_host = nullptr;
+    static thread_local uint64_t* t_host_dev = nullptr;
+    static thread_local uint64_t t_ticket = 0;
+    static thread_local bool t_tried = false;
+    if (!blocking && !t_tried) {
+        t_tried = true;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                t_host = (uint64_t*)h;
+                t_host_dev = (uint64_t*)d;
+                t_host[2] = 0;
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    const bool polled = !blocking && t_host != nullptr;
+    const uint64_t ticket = ++t_ticket;
+    const bool classic = use_classic_sort();
     uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
     uint64_t* status_dev = total_dev + 2;
     uint32_t* clamped_dev = (uint32_t*)(total_dev + 5);       // min(D, capacity) for a speculative stage 2
@@ -244,32 +220,6 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                                 spec->scratch2, spec->scratch2_bytes, spec->image, spec->image_bytes,
                                                 spec->out_color, spec->out_acc_ps, spec->out_depth, spec->grad_records,
                                                 spec->grad_records_bytes, timing, stream, clamped_dev);
-    if (ec.ctr != nullptr) {
-        // D from K1; the scan's words (this call's if they have landed already, else the previous call's) must agree with
-        // the early counts — a counter word left dirty by an aborted launch would otherwise go unnoticed
-        volatile uint64_t* hv = t_host;
-        uint64_t spins = 0;
-        while (hv[5] != ticket) {
-            if ((++spins & 0xFFFF) == 0) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q != hipErrorNotReady && q != hipSuccess) return (int)q;
-                if (q == hipSuccess && hv[5] != ticket) return MSGS_ERR_INTERNAL;
-            }
-        }
-        const uint64_t total = hv[4];
-        const uint64_t seen_a = hv[2], seen_total = hv[0], seen_flags = hv[1], seen_b = hv[2];
-        bool ok = true;
-        if (seen_a == seen_b && seen_a != 0) {
-            if (seen_a == ticket) ok = seen_total == total && seen_flags == 0;
-            else if (seen_a == t_prev_ticket) ok = (seen_total == t_prev_total || seen_total == total) && seen_flags == 0;
-        }
-        t_prev_ticket = ticket;
-        t_prev_total = total;
-        if (!ok) return MSGS_ERR_INTERNAL;
-        if (total > 0xFFFFFFFFull) return MSGS_ERR_TOO_MANY;
-        *num_instances_host = (int64_t)total;
-        return MSGS_OK;
-    }
     if (polled) {
         volatile uint64_t* hv = t_host;
         uint64_t spins = 0;

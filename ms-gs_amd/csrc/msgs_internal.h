@@ -318,18 +318,9 @@ inline ViewParams make_view_params(const msgs_view_t* v) {
 // separate fill launches in front of the radix sorts and the tile-range pass
 struct ZeroJob { uint32_t* p0; size_t n0; uint32_t* p1; size_t n1; };
 
-// K1 publishes the instance count D = sum of the per-Gaussian tile counts itself, so that the host learns it when K1 ends
-// instead of after the depth sort and the scan (which only ORDER the same counts).  ctr: one device word {blocks done << 40 |
-// running sum}, zero on entry; every block adds (1 << 40) + its sum with one returning atomic, the block that completes the
-// count stores zero back (self-cleaning: the word is ready for the next launch) and writes host[0] = D, host[1] = ticket
-// (pinned, device-mapped host words).  ctr == nullptr: off.
-struct EarlyCount { unsigned long long* ctr; unsigned long long* host; unsigned long long ticket; };
-constexpr int EARLY_COUNT_SHIFT = 40;
-
 // preprocess.hip
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0},
-                             EarlyCount ec = EarlyCount{nullptr, nullptr, 0});
+                             char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s, bool textbook = false);

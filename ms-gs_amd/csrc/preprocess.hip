@@ -358,10 +358,9 @@ template <bool SPLIT_ROWS>
 __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gaussians_t g,
                                                          int32_t* __restrict__ radii,
                                                          float* __restrict__ pixel_sizes,
-                                                         char* __restrict__ geom, ZeroJob zj, EarlyCount ec) {
+                                                         char* __restrict__ geom, ZeroJob zj) {
     __shared__ float s_rows[4][64 * (SPLIT_ROWS ? ROW_LDS : HALF_LDS)];
     __shared__ uint8_t s_idx[4][64];
-    __shared__ uint32_t s_tiles[4];
     const int P = g.P;
     {   // housekeeping for the depth sort that follows: clear its group-sum table (one word per thread)
         const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
@@ -551,26 +550,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         key[i] = out_key;
         flags[i] = out_flags;
         weight[i] = out_weight;
-    }
-    // ---- the instance count D, published by the block that completes it (EarlyCount, msgs_internal.h) ----
-    if (ec.ctr != nullptr) {
-        uint32_t wsum = out_tiles;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, off);
-        if (lane == 0) s_tiles[wv] = wsum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long mine = (1ull << EARLY_COUNT_SHIFT) +
-                                            ((unsigned long long)s_tiles[0] + s_tiles[1] + s_tiles[2] + s_tiles[3]);
-            const unsigned long long after = atomicAdd(ec.ctr, mine) + mine;
-            if ((after >> EARLY_COUNT_SHIFT) == (unsigned long long)gridDim.x) {
-                __hip_atomic_store(ec.ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                volatile unsigned long long* host = ec.host;
-                host[0] = after & ((1ull << EARLY_COUNT_SHIFT) - 1ull);
-                __threadfence_system();
-                host[1] = ec.ticket;
-            }
-        }
     }
 }
 
@@ -989,14 +968,12 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s, ZeroJob zj, EarlyCount ec) {
+                             char* geom, hipStream_t s, ZeroJob zj) {
     if (g.P == 0) return hipSuccess;
     if (g.raw_params != 0 && g.shs == nullptr)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
-                           ec);
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
     else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
-                           ec);
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
     return hipGetLastError();
 }
 
