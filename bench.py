@@ -46,8 +46,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # thread pools sized for the CPUs this container may USE (its cgroup quota), not the ones it can see: with one OpenMP thread
 # per visible CPU (128 on a 256-CPU box granted 16) the quota is spent spinning and the kernel parks the whole process —
 # the kernel-launching thread included — for 15-70 ms at a time (hostinfo.py; profiles/r3_notes.md "host stalls")
-from hostinfo import limit_thread_pools, usable_cpus  # noqa: E402
-HOST_THREADS = limit_thread_pools()
+from hostinfo import limit_thread_pools, usable_cpus  # noqa: E402  (the pools are sized after the launch decision below)
 
 
 @contextlib.contextmanager
@@ -85,9 +84,11 @@ def _self_launch_if_needed():
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
+    # the ranks share this container's CPU quota (torch.distributed.run gives its workers OMP_NUM_THREADS=1 for the same reason)
+    per_rank = os.environ.get("OMP_NUM_THREADS", str(max(1, usable_cpus() // n - 1)))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=per_rank, MKL_NUM_THREADS=per_rank)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     out, _ = procs[0].communicate()
@@ -100,6 +101,7 @@ def _self_launch_if_needed():
 
 if __name__ == "__main__":
     _self_launch_if_needed()
+HOST_THREADS = limit_thread_pools()
 
 import numpy as np
 import torch
