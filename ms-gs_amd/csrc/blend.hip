@@ -440,7 +440,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
 // the chip; (ii) every wave classifies the batch against its OWN block and compacts in the same pass (lanes = records) — no mask
 // array, one barrier less per batch; (iii) the next batch's records travel in registers while the current one is walked.
 // Same arithmetic per pixel in the same order: results are bit-identical to blend_forward_kernel.
-template <int WAVES>
+// SB = side of the sub-block a wave owns: 4 (lanes 0..15, sixteen sub-blocks per tile) or 2 (lanes 0..3, sixty-four per tile — the
+// entry chain of a wave is what bounds this regime, and a 2x2 block is reached by fewer entries still; the list is staged and
+// classified per workgroup as before, so the waves per workgroup grow with the sub-block count).
+template <int WAVES, int SB = 4>
 __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewPara
                                                             uint32_t* __restrict__ n_contrib,
                                                             uint4* __restrict__ clear_ptr, size_t clear_n16,
                                                             uint32_t* __restrict__ order_flag) {
-    constexpr int T = 64 * WAVES, G = 16 / WAVES;
+    constexpr int PER_ROW = TILE / SB, NSB = PER_ROW * PER_ROW, LANES = SB * SB;
+    constexpr int T = 64 * WAVES, G = NSB / WAVES;
     constexpr int R = (BATCH + T - 1) / T;               // records a thread stages per batch
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
     __shared__ __attribute__((aligned(16))) uint32_t s_list[WAVES][BATCH + LIST_PAD];
@@ -463,12 +467,12 @@ __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewPara
     const int tile = blockIdx.x / G, grp = blockIdx.x % G;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int sb = grp * WAVES + w;                       // this wave's 4x4 sub-block of the tile
-    const int px = tx * TILE + (sb & 3) * 4 + (lane & 3);
-    const int py = ty * TILE + (sb >> 2) * 4 + ((lane >> 2) & 3);
-    const bool inside = lane < 16 && px < vp.W && py < vp.H;     // lanes 16..63 idle: this variant buys latency, not throughput
+    const int sb = grp * WAVES + w;                       // this wave's SB x SB sub-block of the tile
+    const int px = tx * TILE + (sb % PER_ROW) * SB + (lane % SB);
+    const int py = ty * TILE + (sb / PER_ROW) * SB + ((lane / SB) % SB);
+    const bool inside = lane < LANES && px < vp.W && py < vp.H;  // the other lanes idle: this variant buys latency, not throughput
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)(tx * TILE + (sb & 3) * 4), by0 = (float)(ty * TILE + (sb >> 2) * 4);
+    const float bx0 = (float)(tx * TILE + (sb % PER_ROW) * SB), by0 = (float)(ty * TILE + (sb / PER_ROW) * SB);
     const uint2 range = ranges[tile];
     const int len = (int)(range.y - range.x);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -509,7 +513,8 @@ __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewPara
                 const float4 r0 = s_r0[e];
                 const float C = s_r1[e].x, tau2 = s_r2[e].w;
                 hit = !(tau2 > -1.0e38f) ||
-                      levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + 3.0f, by0, by0 + 3.0f);
+                      levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + (float)(SB - 1), by0,
+                                         by0 + (float)(SB - 1));
             }
             const uint64_t b = __ballot(hit);
             if (hit) s_list[w][cnt + __popcll(b & lt_mask)] = (uint32_t)(e << 4);
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
 // sub-block (lanes 0..15), WAVES per workgroup, 16 / WAVES workgroups per tile; same per-pixel arithmetic in the same order as
 // blend_backward_kernel; one atomic per (sub-block, Gaussian, component).  A workgroup walks the tile's list back from the last
 // entry ITS pixels blended.
-template <int WAVES>
+template <int WAVES, int SB = 4>
 __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                              const uint32_t* __restrict__ ids,
                                                              const uint2* __restrict__ ranges,
@@ -710,7 +715,8 @@ __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewPar
                                                              const uint32_t* __restrict__ n_contrib,
                                                              const float* __restrict__ dL_dcolor,
                                                              grad_acc_t* __restrict__ grad_rec) {
-    constexpr int T = 64 * WAVES, G = 16 / WAVES;
+    constexpr int PER_ROW = TILE / SB, NSB = PER_ROW * PER_ROW, LANES = SB * SB;
+    constexpr int T = 64 * WAVES, G = NSB / WAVES;
     constexpr int R = (BATCH + T - 1) / T;               // records a thread stages per batch
     __shared__ float4 s_r0[BATCH], s_r1[BATCH];
     __shared__ float s_b[BATCH], s_tau[BATCH];
@@ -721,12 +727,12 @@ __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewPar
     const int tile = blockIdx.x / G, grp = blockIdx.x % G;
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int sb = grp * WAVES + w;                       // this wave's 4x4 sub-block of the tile
-    const int px = tx * TILE + (sb & 3) * 4 + (lane & 3);
-    const int py = ty * TILE + (sb >> 2) * 4 + ((lane >> 2) & 3);
-    const bool inside = lane < 16 && px < vp.W && py < vp.H;     // lanes 16..63 idle (see blend_forward_fine_kernel)
+    const int sb = grp * WAVES + w;                       // this wave's SB x SB sub-block of the tile
+    const int px = tx * TILE + (sb % PER_ROW) * SB + (lane % SB);
+    const int py = ty * TILE + (sb / PER_ROW) * SB + ((lane / SB) % SB);
+    const bool inside = lane < LANES && px < vp.W && py < vp.H;  // the other lanes idle (see blend_forward_fine_kernel)
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)(tx * TILE + (sb & 3) * 4), by0 = (float)(ty * TILE + (sb >> 2) * 4);
+    const float bx0 = (float)(tx * TILE + (sb % PER_ROW) * SB), by0 = (float)(ty * TILE + (sb / PER_ROW) * SB);
     const uint2 range = ranges[tile];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const size_t N = (size_t)vp.W * vp.H;
@@ -792,7 +798,8 @@ __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewPar
                 const float4 r0 = s_r0[e];
                 const float C = s_r1[e].x, tau2 = s_tau[e];
                 hit = !(tau2 > -1.0e38f) ||
-                      levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + 3.0f, by0, by0 + 3.0f);
+                      levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + (float)(SB - 1), by0,
+                                         by0 + (float)(SB - 1));
             }
             const uint64_t bal = __ballot(hit);
             if (hit) s_list[w][cnt + __popcll(bal & lt_mask)] = (uint16_t)e;
@@ -1240,24 +1247,37 @@ int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen
 // blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
 static std::atomic<int> g_granularity{[] { const char* e = getenv("MSGS_BLEND_GRANULARITY"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_blend_granularity(int mode) { return g_granularity.exchange(mode == 1 || mode == 2 ? mode : 0); }
-// workgroups per tile of the fine-grained kernels (MSGS_FINE_SPLIT = 1 | 2 | 4 | 8 | 16 forces one).  Measured on the pyramid of the
-// C3 scene (forward / backward us at 135, 40, 12, 2 tiles; profiles/r3_notes.md): G = 1: 105/184, 139/228, 146/241, 132/224;
-// G = 2: 87/152, 114/192, 115/194, 100/175; G = 4: 87/140, 111/180, 108/182, 98/166; G = 8: 112/151, 133/190, 138/188, 117/166;
-// G = 16: 152/164, 158/198, 149/176, 130/162 — four workgroups of four waves per tile at every level: beyond that every workgroup
-// stages and classifies the tile's whole list with too few threads.
-static int fine_split(int tiles) {
-    static const int forced = [] { const char* e = getenv("MSGS_FINE_SPLIT"); const int v = e ? atoi(e) : 0;
-                                   return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }();
-    if (forced) return forced;
-    return tiles < 768 ? 4 : 1;          // (>= 768 tiles only when the fine kernels are forced: one workgroup per tile fills the chip)
+// Shape of the fine-grained kernels: the sub-block side SB a wave owns (4 | 2 | 1 -> 16 | 64 | 256 waves per tile) and the
+// number G of workgroups a tile's waves are split over (every workgroup stages and classifies the tile's whole list).
+// MSGS_FINE_SB = 1 | 2 | 4 and MSGS_FINE_SPLIT = 1 .. 64 force them.  Measured on the pyramid of the C3 scene, forward / backward
+// us at 135, 40, 12, 2 tiles (profiles/r3_notes.md):
+//   SB 4: G = 1: 105/184, 139/228, 146/241, 132/224;  G = 2: 87/152, 114/192, 115/194, 100/175;  G = 4: 87/140, 111/180, 108/182,
+//         98/166;  G = 8: 112/151, 133/190, 138/188, 117/166;  G = 16: 152/164, 158/198, 149/176, 130/162
+//   SB 2: G = 4: 156/251, 104/140, 100/133, 95/129;  G = 8: 128/181, 85/122, 83/117, 75/107;  G = 16: 122/168, 82/111, 82/107,
+//         74/98;  G = 32: 167/207, 115/130, 104/108, 91/97
+//   SB 1: G = 16: 329/368, 139/152, 82/94, 76/89;  G = 32: 277/330, 120/130, 73/86, 65/81;  G = 64: 246/304, 112/131, 71/84, 62/74
+// i.e. the best shape keeps 2000-3000 waves in flight: 4x4 blocks down to ~64 tiles, 2x2 blocks down to ~16, single pixels below.
+struct FineShape { int sb, g; };
+static FineShape fine_shape(int tiles) {
+    static const int forced_sb = [] { const char* e = getenv("MSGS_FINE_SB"); const int v = e ? atoi(e) : 0;
+                                      return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+    static const int forced_g = [] { const char* e = getenv("MSGS_FINE_SPLIT"); const int v = e ? atoi(e) : 0;
+                                     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0; }();
+    FineShape f;
+    f.sb = forced_sb ? forced_sb : (tiles <= 16 ? 1 : (tiles <= 64 ? 2 : 4));
+    const int dflt = f.sb == 1 ? 64 : (f.sb == 2 ? 16 : (tiles < 768 ? 4 : 1));   // (>= 768 tiles only when forced: one workgroup
+    f.g = forced_g ? forced_g : dflt;                                               //  per tile fills the chip)
+    return f;
 }
-template <int WAVES, class... Args>
+template <int WAVES, int SB = 4, class... Args>
 static void launch_fine_fwd(int tiles, hipStream_t s, Args... args) {
-    hipLaunchKernelGGL((blend_forward_fine_kernel<WAVES>), dim3(tiles * (16 / WAVES)), dim3(64 * WAVES), 0, s, args...);
+    constexpr int NSB = (TILE / SB) * (TILE / SB);
+    hipLaunchKernelGGL((blend_forward_fine_kernel<WAVES, SB>), dim3(tiles * (NSB / WAVES)), dim3(64 * WAVES), 0, s, args...);
 }
-template <int WAVES, class... Args>
+template <int WAVES, int SB = 4, class... Args>
 static void launch_fine_bwd(int tiles, hipStream_t s, Args... args) {
-    hipLaunchKernelGGL((blend_backward_fine_kernel<WAVES>), dim3(tiles * (16 / WAVES)), dim3(64 * WAVES), 0, s, args...);
+    constexpr int NSB = (TILE / SB) * (TILE / SB);
+    hipLaunchKernelGGL((blend_backward_fine_kernel<WAVES, SB>), dim3(tiles * (NSB / WAVES)), dim3(64 * WAVES), 0, s, args...);
 }
 static bool use_fine(int tiles, int max_tiles) {
     const int g = g_granularity.load();
@@ -1365,13 +1385,19 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     uint32_t* order_flag = tile_last ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tile_last) +
                                                                    align256(4 * (size_t)tiles)) + tiles : nullptr;
     auto fine = [&] {            // few tiles (low pyramid levels): one wave per 4x4 sub-block, the tile split over G workgroups
-        switch (fine_split(tiles)) {
-            case 1: launch_fine_fwd<16>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
-            case 2: launch_fine_fwd<8>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
-            case 4: launch_fine_fwd<4>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
-            case 8: launch_fine_fwd<2>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
-            default: launch_fine_fwd<1>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib, cp, cn, order_flag); break;
+        const FineShape f = fine_shape(tiles);
+#define MSGS_FINE_FWD(WAVES, SB) launch_fine_fwd<WAVES, SB>(tiles, s, vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, \
+                                                            n_contrib, cp, cn, order_flag)
+        if (f.sb == 1) {                      // single pixels: 256 waves per tile
+            if (f.g >= 64) MSGS_FINE_FWD(4, 1); else if (f.g == 32) MSGS_FINE_FWD(8, 1); else MSGS_FINE_FWD(16, 1);
+        } else if (f.sb == 2) {               // 2x2 sub-blocks: 64 waves per tile
+            if (f.g >= 32) MSGS_FINE_FWD(2, 2); else if (f.g == 16) MSGS_FINE_FWD(4, 2); else if (f.g == 8) MSGS_FINE_FWD(8, 2);
+            else MSGS_FINE_FWD(16, 2);
+        } else {                              // 4x4 sub-blocks: 16 waves per tile
+            if (f.g >= 16) MSGS_FINE_FWD(1, 4); else if (f.g == 8) MSGS_FINE_FWD(2, 4); else if (f.g == 4) MSGS_FINE_FWD(4, 4);
+            else if (f.g == 2) MSGS_FINE_FWD(8, 4); else MSGS_FINE_FWD(16, 4);
         }
+#undef MSGS_FINE_FWD
     };
     if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))
         fine();
@@ -1400,14 +1426,20 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD)))
-        switch (fine_split(tiles)) {
-            case 1: launch_fine_bwd<16>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
-            case 2: launch_fine_bwd<8>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
-            case 4: launch_fine_bwd<4>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
-            case 8: launch_fine_bwd<2>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
-            default: launch_fine_bwd<1>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec); break;
+    if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD))) {
+        const FineShape f = fine_shape(tiles);
+#define MSGS_FINE_BWD(WAVES, SB) launch_fine_bwd<WAVES, SB>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec)
+        if (f.sb == 1) {
+            if (f.g >= 64) MSGS_FINE_BWD(4, 1); else if (f.g == 32) MSGS_FINE_BWD(8, 1); else MSGS_FINE_BWD(16, 1);
+        } else if (f.sb == 2) {
+            if (f.g >= 32) MSGS_FINE_BWD(2, 2); else if (f.g == 16) MSGS_FINE_BWD(4, 2); else if (f.g == 8) MSGS_FINE_BWD(8, 2);
+            else MSGS_FINE_BWD(16, 2);
+        } else {
+            if (f.g >= 16) MSGS_FINE_BWD(1, 4); else if (f.g == 8) MSGS_FINE_BWD(2, 4); else if (f.g == 4) MSGS_FINE_BWD(4, 4);
+            else if (f.g == 2) MSGS_FINE_BWD(8, 4); else MSGS_FINE_BWD(16, 4);
         }
+#undef MSGS_FINE_BWD
+    }
     else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec, tile_order);

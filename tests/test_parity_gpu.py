@@ -277,12 +277,13 @@ def test_forward_capacity_guess_paths_give_identical_results():
         assert rel_err(pc._xyz.grad, pref._xyz.grad) <= 1e-4 and rel_err(m2, mref) <= 1e-4
 
 
-def test_blend_granularities_agree():
-    """The fine-grained kernels (sixteen waves per tile, 4x4 sub-blocks) evaluate every pixel with the same arithmetic in
+@pytest.mark.parametrize("W,H", [(203, 117), (120, 67), (43, 29)])
+def test_blend_granularities_agree(W, H):
+    """The fine-grained kernels (one wave per 4x4 / 2x2 / 1x1 pixel sub-block: 104, 40 and 6 tiles select the three shapes,
+    blend.hip fine_shape) evaluate every pixel with the same arithmetic in
     the same order as the quadrant-per-wave kernels: forward outputs bit-identical, gradients equal up to the float32 partial sums the
     waves form over their pixels (the cross-tile accumulation is exact).  Ragged image (W, H not multiples of 16 or 4), multi-scale filters on, non-zero background."""
     import diff_gaussian_rasterization as dgr
-    W, H = 203, 117
     sc, cam = small_scene(6000, W, H, 57, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.2)
     st = dict(filter_small=True, filter_large=True, fade_size=0.0)
     bg = torch.tensor([0.2, 0.5, 0.1])
