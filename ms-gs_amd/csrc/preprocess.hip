@@ -292,6 +292,29 @@ __device__ __forceinline__ float act_rotation(const msgs_gaussians_t& g, int i, 
 // 64*45 floats, moved with full-width float4 loads.
 // (lrow: the LDS row of THIS lane's Gaussian i — its lane number, or lane & 31 when 32 Gaussians are staged at a time;
 //  wave_first / nrow then describe the staged run)
+// Half rows of the SAME concatenated layout for a SPARSE set of the wave's Gaussians, straight from the split dc / rest leaves
+// (K1 colours only the Gaussians that survived the culls, 56 % at C3): idx[0..nlisted) = wave-local row numbers; eight lanes serve
+// one listed row with 12-byte loads (a rest row is 180 bytes, 4-byte aligned), eight rows per instruction.  half 0 = coefficients
+// 0..7 = [dc | rest 0..20], half 1 = coefficients 8..15 = rest 21..44; LDS rows of HALF_LDS floats as in coop_load_rows_part.
+typedef float msgs_f3 __attribute__((ext_vector_type(3)));
+typedef msgs_f3 __attribute__((aligned(4))) msgs_f3_u;
+__device__ __forceinline__ void coop_load_split_half_listed(float* lds_rows, const float* dc, const float* rest, int wave_first,
+                                                            const uint8_t* idx, int nlisted, int half, int lane) {
+    const int sub = lane >> 3, c = lane & 7;
+    for (int it = 0; it * 8 < nlisted; ++it) {
+        const int slot = it * 8 + sub;
+        if (slot < nlisted) {
+            const int sl = idx[slot];
+            const size_t gi = (size_t)wave_first + sl;
+            float* d = lds_rows + sl * HALF_LDS + 3 * c;
+            // half 0: lane c holds coefficient c (c = 0: dc); half 1: coefficient 8 + c
+            const float* src = (half == 0 && c == 0) ? dc + gi * 3 : rest + gi * 45 + 3 * (8 * half + c - 1);
+            const msgs_f3 v = *reinterpret_cast<const msgs_f3_u*>(src);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z;
+        }
+    }
+}
+
 __device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const float* dc, const float* rest, int i,
                                                      bool in_range, int wave_first, int nrow, int lane, int lrow) {
     if (in_range) {
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                                                          int32_t* __restrict__ radii,
                                                          float* __restrict__ pixel_sizes,
                                                          char* __restrict__ geom, ZeroJob zj) {
-    __shared__ float s_rows[4][64 * (SPLIT_ROWS ? ROW_LDS : HALF_LDS)];
+    __shared__ float s_rows[4][64 * HALF_LDS];
     __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
     {   // housekeeping for the depth sort that follows: clear its group-sum table (one word per thread)
@@ -451,18 +474,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         dirx = dx / len; diry = dy / len; dirz = dz / len;
     }
-    if (split_in) {
-        const int wave_first = blockIdx.x * blockDim.x + wv * 64;
-        const int nrow = min(64, P - wave_first);
-        if (nrow > 0 && __ballot(alive) != 0)
-            coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range, wave_first, nrow, lane, lane);
-        wave_lds_fence();
-        if (alive) {
-            const float* sh = (const float*)&s_rows[wv][lane * ROW_LDS];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c] = sh_channel(vp.sh_degree, sh, c, dirx, diry, dirz);
-        }
-    } else if (staged_sh) {
+    if (split_in || staged_sh) {
         const uint64_t need = __ballot(alive);
         if (alive) s_idx[wv][__popcll(need & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         const int wave_first = blockIdx.x * blockDim.x + wv * 64;
@@ -472,8 +484,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         const int n4_total = sh_row_float4s(vp.sh_degree);
         for (int half = 0; half * HALF_F4 < n4_total; ++half) {
             wave_lds_fence();                              // s_idx visible / previous half consumed
-            coop_load_rows_part(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(need),
-                                half * HALF_F4, min(HALF_F4, n4_total - half * HALF_F4), lane);
+            if (split_in) {
+                if (need != 0)
+                    coop_load_split_half_listed(s_rows[wv], g.features_dc, g.features_rest, wave_first, s_idx[wv], __popcll(need),
+                                                half, lane);
+            } else {
+                coop_load_rows_part(s_rows[wv], g.shs + (size_t)wave_first * ROW_F, s_idx[wv], __popcll(need),
+                                    half * HALF_F4, min(HALF_F4, n4_total - half * HALF_F4), lane);
+            }
             wave_lds_fence();
             if (alive) {
                 const float* row = (const float*)&s_rows[wv][lane * HALF_LDS];
