@@ -315,6 +315,25 @@ __device__ __forceinline__ void coop_load_split_half_listed(float* lds_rows, con
     }
 }
 
+// Whole rows [dc(3) | rest(45)] of the listed Gaussians (K9: the rendered ones) into LDS rows of ROW_LDS floats: sixteen lanes
+// serve one row with 12-byte loads (fifteen on the rest row, one on dc), four rows per instruction.  idx[0..nlisted) = wave-local
+// row numbers, LDS row = number - row0.
+__device__ __forceinline__ void coop_load_split_rows_listed(float* lds_rows, const float* dc, const float* rest, int wave_first,
+                                                            const uint8_t* idx, int nlisted, int lane, int row0) {
+    const int sub = lane >> 4, c = lane & 15;
+    for (int it = 0; it * 4 < nlisted; ++it) {
+        const int slot = it * 4 + sub;
+        if (slot < nlisted) {
+            const int sl = idx[slot];
+            const size_t gi = (size_t)wave_first + sl;
+            float* d = lds_rows + (sl - row0) * ROW_LDS + 3 * c;
+            const float* src = c == 0 ? dc + gi * 3 : rest + gi * REST_F + 3 * (c - 1);
+            const msgs_f3 v = *reinterpret_cast<const msgs_f3_u*>(src);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z;
+        }
+    }
+}
+
 __device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const float* dc, const float* rest, int i,
                                                      bool in_range, int wave_first, int nrow, int lane, int lrow) {
     if (in_range) {
@@ -617,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
     const bool factored_sh = raw && grads.dL_dfeatures_dc == nullptr;
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
-    if (staged_sh && !split_in) {            // list of the rendered lanes, ascending: the rows to fetch from the concatenated tensor
+    if (staged_sh) {                         // list of the rendered lanes, ascending: the rows to fetch
         if (rendered) s_idx[wv][__popcll(live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
     }
     uint32_t fl = 0;
@@ -861,7 +880,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
             wave_lds_fence();                                              // s_idx visible / previous run stored
             if (split_in) {
                 if (live_h != 0)
-                    coop_load_split_rows(s_rows[wv], g.features_dc, g.features_rest, i, in_range && mine, first, nrow, lane, lrow);
+                    coop_load_split_rows_listed(s_rows[wv], g.features_dc, g.features_rest, wave_first,
+                                                s_idx[wv] + __popcll(live & ((1ull << row0) - 1ull)), __popcll(live_h), lane, row0);
             } else {
                 coop_load_rows(s_rows[wv], g.shs + (size_t)wave_first * ROW_F,
                                s_idx[wv] + __popcll(live & ((1ull << row0) - 1ull)), __popcll(live_h), sh_row_float4s(deg),
