@@ -51,10 +51,11 @@ from hostinfo import limit_thread_pools, usable_cpus  # noqa: E402  (the pools a
 
 @contextlib.contextmanager
 def quiet_gc():
-    """Timed regions run with Python's cyclic garbage collector paused (collected right before): a full collection of this
-    process's heap takes 30-70 ms and lands, at a position fixed by the allocation count, inside some timed window of ~10 ms
-    (seen as a 5.9 ms 'step' at one pyramid level; tools/diag_level_jitter2.py).  Interpreter housekeeping, not part of a step."""
-    gc.collect()
+    """Timed regions run with Python's cyclic garbage collector paused: a full collection of this process's heap takes 30-70 ms
+    and lands, at a position fixed by the allocation count, inside some timed window of ~10 ms (seen as a 5.9 ms 'step' at one
+    pyramid level; tools/diag_level_jitter2.py).  Interpreter housekeeping, not part of a step.  The collection itself is done by
+    settle_gc() BEFORE the warm-up steps, never between warm-up and timing: a 35 ms pause there lets the GPU clock down and the
+    first timed steps pay for the ramp (measured: +0.07 ms per step over a 20-step region)."""
     was = gc.isenabled()
     gc.disable()
     try:
@@ -62,6 +63,12 @@ def quiet_gc():
     finally:
         if was:
             gc.enable()
+
+
+def settle_gc():
+    """collect now (ahead of a warm-up loop) and leave the collector off until the process ends"""
+    gc.collect()
+    gc.disable()
 
 
 def _self_launch_if_needed():
@@ -106,6 +113,13 @@ HOST_THREADS = limit_thread_pools()
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from hostinfo import single_thread_backward  # noqa: E402
+# one GPU per process: autograd's backward runs on the calling thread (no hand-off to the device thread; hostinfo.py).
+# MSGS_BENCH_MT_BACKWARD=1 keeps torch's default for an A/B.
+SINGLE_THREAD_BACKWARD = os.environ.get("MSGS_BENCH_MT_BACKWARD", "0") != "1"
+if SINGLE_THREAD_BACKWARD:
+    single_thread_backward()
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -169,6 +183,7 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
     from gaussian_renderer import PIPE, render
 
     def timed(fn):
+        settle_gc()
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
@@ -253,6 +268,7 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
     out = {}
 
     def timed(fn):
+        settle_gc()
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
@@ -470,6 +486,7 @@ def main():
                 out["render"].backward(dL)
                 fb_bucket.all_reduce(average_over=world)
                 return out
+    settle_gc()
     for _ in range(args.warmup):
         step()
     elapsed = timed_region(lambda k: step(timers.get(k)), args.steps)
@@ -555,9 +572,11 @@ def main():
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "timing_note": "Python's cyclic GC is collected before and paused during every timed region (a full collection of this "
-                       f"process takes 30-70 ms); OMP/MKL/torch intra-op pools = {HOST_THREADS} threads (the container's CPU "
-                       f"quota is {usable_cpus()} of {os.cpu_count()} visible CPUs)",
+        "timing_note": "Python's cyclic GC is collected before the warm-up of and paused during every timed region (a full collection "
+                       f"of this process takes 30-70 ms); OMP/MKL/torch intra-op pools = {HOST_THREADS} threads (the container's CPU "
+                       f"quota is {usable_cpus()} of {os.cpu_count()} visible CPUs); autograd backward "
+                       + ("on the calling thread (torch.autograd.set_multithreading_enabled(False))" if SINGLE_THREAD_BACKWARD
+                          else "on autograd's device thread (torch default)"),
         "config": {"workload": (
             ("C3 (BASELINE configs[2]): 1M Gaussians, 1920x1080, SH3, multi-scale fields, filter_small+filter_large, "
              "fade 0; frozen seeded scene scenes.config('C3') [SCALE_K 0.004: D/P = 9.6 instances per Gaussian by the "
@@ -725,6 +744,7 @@ def main():
                     for p_ in pc.parameters():
                         p_.grad = None
                     render_fused(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+                settle_gc()
                 for _ in range(args.warmup):
                     fused_step()
                 torch.cuda.synchronize()

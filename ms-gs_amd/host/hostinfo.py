@@ -45,3 +45,14 @@ def limit_thread_pools(reserve=2):
     except ImportError:
         pass
     return n
+
+
+def single_thread_backward():
+    """Run autograd's backward on the calling thread (torch.autograd.set_multithreading_enabled(False), process-wide).
+
+    With one GPU per process there is exactly one device thread to hand the graph to, so nothing runs in parallel anyway; the
+    hand-off itself costs 0.10-0.14 ms per step on small scenes (C1 0.55 -> 0.41 ms, C2 0.57 -> 0.46 ms) and the device
+    thread's wake-up occasionally takes a scheduler tick (2.6-4.8 ms, ~1 % of the steps on the shared MI355X boxes:
+    profiles/r3_notes.md).  A caller-side setting: one line at the top of train.py for a drop-in user."""
+    import torch
+    torch.autograd.set_multithreading_enabled(False)

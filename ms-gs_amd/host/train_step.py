@@ -25,7 +25,10 @@ def fused_train_iteration(model, optimizer, cam, gt_image, pipe, bg, *, lambda_d
     loss, Ll1 = l1_ssim_loss(pkg["render"], gt_image, lambda_dssim)
     if loss_multiplier != 1.0:                      # train.py:212-215 (0.1 on the coarser levels)
         loss = loss * loss_multiplier
-    loss.backward()
+    # one device, one graph: run the backward on THIS thread instead of handing it to autograd's device thread (the
+    # hand-off costs 0.1 ms per iteration on small scenes and, on a busy host, an occasional 4 ms wake-up: hostinfo.py)
+    with torch.autograd.set_multithreading_enabled(False):
+        loss.backward()
     with torch.no_grad():
         update_training_stats(model, pkg["viewspace_points"], pkg["radii"], pkg["pixel_sizes"], reso_lvl,
                               base_mask=base_mask, update_pixel_sizes=update_pixel_sizes, densify=densify)

@@ -83,6 +83,8 @@ _wrap_py(dgr, "_grad_out", "grad_out")
 _wrap_py(dgr, "_take_backward_scratch", "scratch")
 
 gc.collect(); gc.disable()
+if os.environ.get("DIAG_SINGLE_THREAD_BACKWARD") == "1":
+    torch.autograd.set_multithreading_enabled(False)     # backward on the calling thread (no hand-off to the device thread)
 sc, cam, st = scenes.config("C3")
 pc = SyntheticGaussians(sc, "cuda", requires_grad=True)
 bg = torch.zeros(3, device="cuda")

@@ -6,6 +6,8 @@ for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd",
     sys.path.insert(0, p)
 import time
 import torch, scenes
+if os.environ.get("MSGS_BENCH_MT_BACKWARD", "0") != "1":      # as bench.py: backward on the calling thread
+    torch.autograd.set_multithreading_enabled(False)
 from parity_utils import PIPE
 from gaussian_renderer import render, render_fused
 from synthetic_model import SyntheticGaussians

@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch, scenes
+if os.environ.get("MSGS_BENCH_MT_BACKWARD", "0") != "1":      # as bench.py: backward on the calling thread
+    torch.autograd.set_multithreading_enabled(False)
 import diff_gaussian_rasterization as dgr
 from parity_utils import PIPE
 from gaussian_renderer import render
@@ -19,7 +21,7 @@ def step(t=None):
     out = render(camd, pc, PIPE, bg, **st); out["render"].backward(dL); return out
 for _ in range(3): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-K = 10
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 tm = dgr._C.KernelTimer()
 for _ in range(K): out = step(tm)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K

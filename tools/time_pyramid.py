@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch, scenes
+if os.environ.get("MSGS_BENCH_MT_BACKWARD", "0") != "1":      # as bench.py: backward on the calling thread
+    torch.autograd.set_multithreading_enabled(False)
 import diff_gaussian_rasterization as dgr
 from parity_utils import PIPE
 from gaussian_renderer import render, render_fused
