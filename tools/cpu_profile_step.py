@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch, scenes
+if os.environ.get("MSGS_BENCH_MT_BACKWARD", "0") != "1":
+    torch.autograd.set_multithreading_enabled(False)
 from parity_utils import PIPE, small_scene
 from gaussian_renderer import render, render_fused
 from synthetic_model import SyntheticGaussians
@@ -21,4 +23,4 @@ torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t) / 200 * 1e3
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(32)
