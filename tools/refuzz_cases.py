@@ -6,10 +6,9 @@ import torch, scenes
 import diff_gaussian_rasterization as dgr
 from oracle import oracle_ctypes as oc
 from parity_utils import check_backward, check_forward, hip_render, small_scene
-cfgs = [dict(P=9000, W=180, H=42, deg=1, ms=True, fade=0.5, gran=2, bwd_gen=1, fwd_var=4, seed=869634),
-        dict(P=1500, W=69, H=121, deg=3, ms=False, fade=1.0, gran=2, bwd_gen=1, fwd_var=0, seed=892520),
-        dict(P=9000, W=22, H=181, deg=0, ms=True, fade=0.5, gran=0, bwd_gen=1, fwd_var=0, seed=264900),
-        dict(P=64, W=12, H=127, deg=3, ms=True, fade=0.5, gran=0, bwd_gen=0, fwd_var=4, seed=964987)]
+cfgs = [{'P': 1500, 'W': 244, 'H': 144, 'deg': 3, 'ms': True, 'fade': 0.0, 'gran': 2, 'bwd_gen': 1, 'fwd_var': 1, 'seed': 382961}, {'P': 1500, 'W': 4, 'H': 42, 'deg': 2, 'ms': True, 'fade': 0.5, 'gran': 2, 'bwd_gen': 0, 'fwd_var': 0, 'seed': 580118}, {'P': 1500, 'W': 90, 'H': 6, 'deg': 2, 'ms': True, 'fade': 0.0, 'gran': 1, 'bwd_gen': 0, 'fwd_var': 1, 'seed': 712484}, {'P': 200, 'W': 169, 'H': 100, 'deg': 1, 'ms': False, 'fade': 0.0, 'gran': 0, 'bwd_gen': 0, 'fwd_var': 4, 'seed': 786351}, {'P': 4001, 'W': 85, 'H': 1, 'deg': 0, 'ms': True, 'fade': 0.5, 'gran': 0, 'bwd_gen': 0, 'fwd_var': 0, 'seed': 273227}, {'P': 9000, 'W': 96, 'H': 18, 'deg': 2, 'ms': True, 'fade': 1.0, 'gran': 2, 'bwd_gen': 1, 'fwd_var': 3, 'seed': 184164}, {'P': 9000, 'W': 64, 'H': 38, 'deg': 3, 'ms': False, 'fade': 0.5, 'gran': 2, 'bwd_gen': 0, 'fwd_var': 0, 'seed': 862210}, {'P': 9000, 'W': 165, 'H': 16, 'deg': 0, 'ms': True, 'fade': 0.0, 'gran': 1, 'bwd_gen': 2, 'fwd_var': 3, 'seed': 236629}, {'P': 777, 'W': 213, 'H': 49, 'deg': 1, 'ms': True, 'fade': 0.0, 'gran': 2, 'bwd_gen': 1, 'fwd_var': 0, 'seed': 322324}, {'P': 9000, 'W': 45, 'H': 43, 'deg': 3, 'ms': False, 'fade': 1.0, 'gran': 0, 'bwd_gen': 0, 'fwd_var': 3, 'seed': 578901}, {'P': 4001, 'W': 130, 'H': 156, 'deg': 1, 'ms': True, 'fade': 0.5, 'gran': 1, 'bwd_gen': 1, 'fwd_var': 0, 'seed': 582595}, {'P': 777, 'W': 32, 'H': 106, 'deg': 1, 'ms': True, 'fade': 1.0, 'gran': 2, 'bwd_gen': 2, 'fwd_var': 1, 'seed': 985935}, {'P': 9000, 'W': 39, 'H': 124, 'deg': 0, 'ms': False, 'fade': 0.5, 'gran': 0, 'bwd_gen': 0, 'fwd_var': 0, 'seed': 475100}, {'P': 1500, 'W': 43, 'H': 10, 'deg': 3, 'ms': True, 'fade': 0.5, 'gran': 1, 'bwd_gen': 1, 'fwd_var': 0, 'seed': 228898}, {'P': 9000, 'W': 21, 'H': 161, 'deg': 0, 'ms': True, 'fade': 0.5, 'gran': 1, 'bwd_gen': 0, 'fwd_var': 4, 'seed': 39893}, {'P': 9000, 'W': 35, 'H': 37, 'deg': 0, 'ms': True, 'fade': 0.0, 'gran': 2, 'bwd_gen': 2, 'fwd_var': 4, 'seed': 80942}, {'P': 4001, 'W': 227, 'H': 196, 'deg': 2, 'ms': False, 'fade': 0.0, 'gran': 2, 'bwd_gen': 0, 'fwd_var': 0, 'seed': 80418}, {'P': 9000, 'W': 84, 'H': 120, 'deg': 2, 'ms': False, 'fade': 1.0, 'gran': 1, 'bwd_gen': 0, 'fwd_var': 4, 'seed': 611980}, {'P': 777, 'W': 213, 'H': 196, 'deg': 2, 'ms': False, 'fade': 0.5, 'gran': 0, 'bwd_gen': 2, 'fwd_var': 0, 'seed': 198570}, {'P': 9000, 'W': 22, 'H': 181, 'deg': 0, 'ms': True, 'fade': 0.5, 'gran': 0, 'bwd_gen': 1, 'fwd_var': 0, 'seed': 264900}, {'P': 4001, 'W': 98, 'H': 139, 'deg': 2, 'ms': True, 'fade': 1.0, 'gran': 2, 'bwd_gen': 1, 'fwd_var': 0, 'seed': 120739}]
+if len(sys.argv) > 1:
+    cfgs = [c for c in cfgs if str(c['seed']) in sys.argv[1:]]
 for c in cfgs:
     for variant in ("as drawn", "round-2 kernels only"):
         gran, bwd_gen, fwd_var = (c["gran"], c["bwd_gen"], c["fwd_var"]) if variant == "as drawn" else (1, 1, 1)
