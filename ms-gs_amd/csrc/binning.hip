@@ -18,11 +18,12 @@ namespace {
 // [offs[first], offs[last] + tiles[last]).  When that range fits the LDS stage (the normal case: ~4 tiles
 // per Gaussian) every thread deposits its pairs in LDS and the block streams the stage out with fully
 // coalesced stores; otherwise (huge Gaussians) threads store straight to global memory.
-// LDS stage in pairs: 3072 (24 KB) for light scenes, 6144 (48 KB) when a block of 256 Gaussians emits more than that on
-// average (D > 8 P): at C5 (11 tiles per Gaussian) the larger stage halves the kernel (0.68 -> 0.34 ms), at C3 (4 per
-// Gaussian) the smaller one is 4 us faster (occupancy)
+// LDS stage in pairs: 3072 for light scenes, 12288 when a block of 256 Gaussians emits more than the small stage on average
+// (D > 8 P; C5: 11 tiles per Gaussian, 20 per rendered one).  The kernel is latency-bound and its occupancy is set by the
+// stage, so a staged pair is 3 bytes, not 8: the tile id as KeyT (16 bits whenever the grid has fewer than 65535 tiles) and
+// the owner's thread number (8 bits; the 256 Gaussian ids of the block sit in LDS once).
 
-template <int EMIT_STAGE>
+template <int EMIT_STAGE, typename KeyT>
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids,
                                                    int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev) {
@@ -32,8 +33,9 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
         for (size_t t = t0; t < zj.n0; t += nt) zj.p0[t] = 0u;
         for (size_t t = t0; t < zj.n1; t += nt) zj.p1[t] = 0u;
     }
-    __shared__ uint32_t s_keys[EMIT_STAGE];
-    __shared__ uint32_t s_ids[EMIT_STAGE];
+    __shared__ KeyT s_keys[EMIT_STAGE];
+    __shared__ uint8_t s_own[EMIT_STAGE];
+    __shared__ uint32_t s_gi[256];
     __shared__ int64_t s_range[2];
     const GeomLayout L(P);
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     int64_t off = 0;
     // the count of rank r is the difference of consecutive scanned offsets (coalesced; no gather of tiles[order[r]])
     if (r < V) { gi = order[r]; off = offs[r]; count = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - off); }
+    s_gi[threadIdx.x] = gi;
     if (threadIdx.x == 0) s_range[0] = off;
     if (r == rlast) s_range[1] = min((int64_t)off + count, D);
     __syncthreads();
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
             if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi)) continue;
             for (int tx = tlo; tx <= thi && off < end; ++tx) {
                 const uint32_t k = (uint32_t)(ty * vp.gx + tx);
-                if (staged) { s_keys[off - blk_lo] = k; s_ids[off - blk_lo] = gi; }
+                if (staged) { s_keys[off - blk_lo] = (KeyT)k; s_own[off - blk_lo] = (uint8_t)threadIdx.x; }
                 else { keys[off] = k; ids[off] = gi; }
                 ++off;
             }
@@ -80,28 +83,52 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
         // count >= emitted by construction (larger margin in the count): park the surplus slots on the sentinel tile
         for (; off < end; ++off) {
             const uint32_t k = (uint32_t)(vp.gx * vp.gy);
-            if (staged) { s_keys[off - blk_lo] = k; s_ids[off - blk_lo] = gi; }
+            if (staged) { s_keys[off - blk_lo] = (KeyT)k; s_own[off - blk_lo] = (uint8_t)threadIdx.x; }
             else { keys[off] = k; ids[off] = gi; }
         }
     }
     if (!staged) return;
     __syncthreads();
     for (int i = threadIdx.x; i < (int)blk_len; i += blockDim.x) {
-        keys[blk_lo + i] = s_keys[i];
-        ids[blk_lo + i] = s_ids[i];
+        keys[blk_lo + i] = (uint32_t)s_keys[i];
+        ids[blk_lo + i] = s_gi[s_own[i]];
     }
 }
 
+// four consecutive keys per thread (one 16-byte load); the neighbours across thread boundaries come from the adjacent lanes, across
+// wave boundaries from memory.  (One key per thread with three 4-byte loads ran at 1.5 TB/s: 14 us at C3, 150 us at C5.)
 __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ keys, int64_t D,
                                                      uint2* __restrict__ ranges, int num_tiles,
                                                      const uint32_t* __restrict__ D_dev) {
     if (D_dev) D = (int64_t)*D_dev;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= D) return;
-    const uint32_t t = keys[i];
-    if (t >= (uint32_t)num_tiles) return;
-    if (i == 0 || keys[i - 1] != t) ranges[t].x = (uint32_t)i;
-    if (i == D - 1 || keys[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
+    const int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = threadIdx.x & 63;
+    const bool full = i0 + 3 < D;
+    uint32_t k[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (full) {
+        const uint4 v = *reinterpret_cast<const uint4*>(keys + i0);
+        k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j < D) k[j] = keys[i0 + j];
+    }
+    // key in front of k[0] / behind k[3] (every lane takes part in the shuffles)
+    uint32_t prev = (uint32_t)__shfl_up((int)k[3], 1), next = (uint32_t)__shfl_down((int)k[0], 1);
+    if (i0 >= D) return;
+    if (lane == 0) prev = i0 > 0 ? keys[i0 - 1] : 0xFFFFFFFFu;
+    if (lane == 63) next = i0 + 4 < D ? keys[i0 + 4] : 0xFFFFFFFFu;
+    const uint32_t nt = (uint32_t)num_tiles;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + j;
+        if (i >= D) break;
+        const uint32_t t = k[j];
+        if (t >= nt) continue;
+        const uint32_t before = j == 0 ? prev : k[j - 1];
+        const uint32_t after = (j == 3 || i + 1 >= D) ? (j == 3 ? next : 0xFFFFFFFFu) : k[j + 1];
+        if (i == 0 || before != t) ranges[t].x = (uint32_t)i;
+        if (i == D - 1 || after != t) ranges[t].y = (uint32_t)(i + 1);
+    }
 }
 
 }  // namespace
@@ -109,10 +136,15 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids, int64_t D,
                        hipStream_t s, ZeroJob zj, const uint32_t* D_dev) {
     if (P == 0 || D == 0) return hipSuccess;     // (callers fold a ZeroJob in only when D > 0)
-    if (D > 8 * (int64_t)P)
-        hipLaunchKernelGGL((emit_kernel<6144>), dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
-    else
-        hipLaunchKernelGGL((emit_kernel<3072>), dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+    const bool narrow = vp.gx * vp.gy < 65535;        // tile ids and the sentinel (= number of tiles) fit 16 bits
+    const dim3 grid((P + 255) / 256), block(256);
+    if (D > 8 * (int64_t)P) {
+        if (narrow) hipLaunchKernelGGL((emit_kernel<12288, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+        else hipLaunchKernelGGL((emit_kernel<6144, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+    } else {
+        if (narrow) hipLaunchKernelGGL((emit_kernel<3072, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+        else hipLaunchKernelGGL((emit_kernel<3072, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+    }
     return hipGetLastError();
 }
 
@@ -123,7 +155,7 @@ hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num
         if (e != hipSuccess) return e;
     }
     if (D == 0) return hipSuccess;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys, D, ranges, num_tiles, D_dev);
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 1023) / 1024)), dim3(256), 0, s, keys, D, ranges, num_tiles, D_dev);
     return hipGetLastError();
 }
 
