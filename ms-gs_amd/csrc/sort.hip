@@ -238,9 +238,26 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
 // was 112 + 60 rows = 176 KB per block, more bytes than the keys the block moves).  A kernel of its own: folding it into the
 // histogram kernel's last-arriving block needs a device-scope release fence in EVERY block, which on this part writes the
 // L2 back each time (measured: the tile sort of 55 M pairs 1.15 -> 3.8 ms).
-__global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ gsum, int ngroups) {
-    __shared__ uint32_t s_wv[4];
+// Blocks 0 .. ngroups-1 of the same launch turn the block histograms of their group into exclusive in-group prefixes (per digit,
+// in place): a scatter block then reads ONE histogram row and ONE group row instead of walking the rows of the earlier blocks of
+// its group (on average 15.5 KB of table per 32 KB of keys and values, and a chain of dependent loads).
+__global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ gsum, int ngroups,
+                                                         uint32_t* __restrict__ hist, int gsize, int64_t nblocks) {
     const int d = threadIdx.x;
+    if ((int)blockIdx.x < ngroups) {
+        const int64_t first = (int64_t)blockIdx.x * gsize;
+        const int rows = (int)min((int64_t)gsize, nblocks - first);
+        uint32_t* q = hist + first * 256 + d;
+        uint32_t run = 0;
+#pragma unroll 8
+        for (int k = 0; k < rows; ++k) {
+            const uint32_t v = q[(int64_t)k * 256];
+            q[(int64_t)k * 256] = run;
+            run += v;
+        }
+        return;
+    }
+    __shared__ uint32_t s_wv[4];
     uint32_t tot = 0;
 #pragma unroll 8
     for (int k = 0; k < ngroups; ++k) tot += gsum[(int64_t)k * 256 + d];
@@ -305,14 +322,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
     {   // digit d = threadIdx.x: global base of this block's run of digit d
         const uint32_t d = threadIdx.x;
         if (gsum && gsum_is_base) {
-            // the histogram kernel's last block already turned the group sums into bases (large inputs)
+            // group_scan_kernel turned the group sums into bases and the block histograms into in-group prefixes (large inputs)
             const int g = blockIdx.x / gsize;
-            uint32_t before = gsum[(int64_t)g * 256 + d];
-            const int nin = (int)(blockIdx.x - (int64_t)g * gsize);
-            const uint32_t* hrow = hist_scanned + ((int64_t)g * gsize) * 256 + d;
-#pragma unroll 8
-            for (int k = 0; k < nin; ++k) before += hrow[(int64_t)k * 256];
-            gbase = before;
+            gbase = gsum[(int64_t)g * 256 + d] + hist_scanned[(int64_t)blockIdx.x * 256 + d];
         } else if (gsum) {
             // base = (keys with a smaller digit) + (same digit in earlier groups) + (same digit in earlier blocks of
             // this group); hist_scanned holds the RAW block histograms here
@@ -684,6 +696,14 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s) {
 // geometry of the grouped radix pass (shared by the sort and by the callers that clear its tables ahead of time)
 constexpr int64_t SCANNED_MIN_BLOCKS = 4096;     // from here on the histogram kernel's last block scans the group sums
 constexpr int SCANNED_GSIZE = 32;
+// EXPERIMENT: MSGS_SORT_TILE_PASSES=n forces n passes for sorts of fewer than 32 bits (the tile sort)
+static int passes_for(int begin_bit, int end_bit) {
+    static const int forced = [] { const char* e = getenv("MSGS_SORT_TILE_PASSES"); return e ? atoi(e) : 0; }();
+    int passes = (end_bit - begin_bit + 7) / 8;
+    if (forced >= passes && forced <= 4 && end_bit - begin_bit < 32) passes = forced;
+    return passes;
+}
+
 struct GroupGeom {
     bool big, mid, scanned;
     int items, gsize, ngroups;
@@ -718,7 +738,7 @@ struct GroupGeom {
 // does radix_sort_pairs(n, bits) honour a device-side element count?  (the grouped, staged configurations do)
 bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit) {
     if (n <= 0) return false;
-    int passes = (end_bit - begin_bit + 7) / 8;
+    int passes = passes_for(begin_bit, end_bit);
     if (passes < 1) passes = 1;
     static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
     static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
@@ -728,7 +748,7 @@ bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit) {
 
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {
     if (n <= 0) return false;
-    int passes = (end_bit - begin_bit + 7) / 8;
+    int passes = passes_for(begin_bit, end_bit);
     if (passes < 1) passes = 1;
     static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
     static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
@@ -783,7 +803,7 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
     uint32_t* vals_alt = reinterpret_cast<uint32_t*>(scratch + L.vals_alt);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + L.hist);
     uint64_t* partials = reinterpret_cast<uint64_t*>(scratch + L.partials);
-    int passes = (end_bit - begin_bit + 7) / 8;
+    int passes = passes_for(begin_bit, end_bit);
     if (passes < 1) passes = 1;
     const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
     // grouped variant of the spin-free path (default): group sums live behind the block-histogram table
@@ -846,7 +866,7 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
             if (big && G.scanned) {
                 hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
                                    np);
-                hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(256), 0, s, gs, ngroups);
+                hipLaunchKernelGGL(group_scan_kernel, dim3((unsigned)ngroups + 1), dim3(256), 0, s, gs, ngroups, hist, gsize, nb);
                 hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
                                    mask, nb, hist, gs, gsize, ngroups, true, np, (uint32_t*)nullptr);
             } else if (big) {
