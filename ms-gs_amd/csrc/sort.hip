@@ -214,12 +214,25 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (ITEMS % 4 == 0 && chunk_base + (int64_t)SORT_THREADS * ITEMS <= n) {
+        // a full chunk: the block only needs the chunk's digit counts, whatever thread sees which key — 16-byte loads
+        const uint4* kv = reinterpret_cast<const uint4*>(keys + chunk_base);
 #pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-        if (i < n) {
-            const uint32_t k = keys[i];
-            if (!DROP || k != 0xFFFFFFFFu) atomicAdd(&s_hist[(k >> shift) & mask], 1u);
+        for (int r = 0; r < ITEMS / 4; ++r) {
+            const uint4 v = kv[r * SORT_THREADS + threadIdx.x];
+            const uint32_t k4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!DROP || k4[j] != 0xFFFFFFFFu) atomicAdd(&s_hist[(k4[j] >> shift) & mask], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
+            if (i < n) {
+                const uint32_t k = keys[i];
+                if (!DROP || k != 0xFFFFFFFFu) atomicAdd(&s_hist[(k >> shift) & mask], 1u);
+            }
         }
     }
     __syncthreads();
