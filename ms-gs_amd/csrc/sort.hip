@@ -709,7 +709,7 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s) {
 // geometry of the grouped radix pass (shared by the sort and by the callers that clear its tables ahead of time)
 constexpr int64_t SCANNED_MIN_BLOCKS = 4096;     // from here on the histogram kernel's last block scans the group sums
 constexpr int SCANNED_GSIZE = 32;
-// EXPERIMENT: MSGS_SORT_TILE_PASSES=n forces n passes for sorts of fewer than 32 bits (the tile sort)
+// MSGS_SORT_TILE_PASSES=n forces n passes for sorts of fewer than 32 bits (the tile sort): A/B of digit width against passes
 static int passes_for(int begin_bit, int end_bit) {
     static const int forced = [] { const char* e = getenv("MSGS_SORT_TILE_PASSES"); return e ? atoi(e) : 0; }();
     int passes = (end_bit - begin_bit + 7) / 8;
