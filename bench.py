@@ -180,7 +180,7 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
       pyramid_ms          render() + backward() per level, training settings (filters on, fade 0)
       render_forward_ms   forward-only render() under no_grad: "filters_on" = the viewer's --anti_alias (filter_small =
                           filter_large = True, fade_size 1.0: viewer.py:59-72), "filters_off" = render.py's defaults"""
-    from gaussian_renderer import PIPE, render
+    from gaussian_renderer import PIPE, render, render_fused
 
     def timed(fn):
         settle_gc()
@@ -195,7 +195,7 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
             dt = time.perf_counter() - t
         return round(1e3 * dt / steps, 4)
 
-    fb, on, off, sizes, vis = [], [], [], [], []
+    fb, on, off, sizes, vis, fused_fb, fused_on = [], [], [], [], [], [], []
     aa = dict(filter_small=True, filter_large=True, fade_size=1.0)
     plain = dict(filter_small=False, filter_large=False, fade_size=1.0)
     for k in range(7):
@@ -208,7 +208,14 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
                 p_.grad = None
             render(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
         fb.append(timed(train_step))
+
+        def fused_train_step():
+            for p_ in pc.parameters():
+                p_.grad = None
+            render_fused(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
+        fused_fb.append(timed(fused_train_step))
         with torch.no_grad():
+            fused_on.append(timed(lambda: render_fused(cam, pc, PIPE, bg, **aa)))
             on.append(timed(lambda: render(cam, pc, PIPE, bg, **aa)))
             off.append(timed(lambda: render(cam, pc, PIPE, bg, **plain)))
             vis.append(int((render(cam, pc, PIPE, bg, **settings)["radii"] > 0).sum().item()))
@@ -250,11 +257,14 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
                            "filters and the compacting sort are built for"}
     except Exception as e:      # informational only
         trained = {"error": repr(e)}
-    return ({"levels": sizes, "ms": fb, "rendered_gaussians": vis, "with_min_pixel_sizes_on_every_level0_gaussian": trained,
-             "what": "render() + backward() per pyramid level k = 0..6 of the C3 scene, training settings"},
-            {"levels": sizes, "filters_on": on, "filters_off": off,
+    return ({"levels": sizes, "ms": fb, "rendered_gaussians": vis, "render_fused_ms": fused_fb,
+             "with_min_pixel_sizes_on_every_level0_gaussian": trained,
+             "what": "render() + backward() per pyramid level k = 0..6 of the C3 scene, training settings; render_fused_ms = the "
+                     "same through the raw-parameter entry (activations and SH concatenation inside the kernels)"},
+            {"levels": sizes, "filters_on": on, "filters_off": off, "render_fused_filters_on": fused_on,
              "what": "forward-only render() under no_grad per pyramid level (viewer.py:67-81 convention): filters_on = "
-                     "--anti_alias (both filters, fade_size 1.0), filters_off = render.py defaults"})
+                     "--anti_alias (both filters, fade_size 1.0), filters_off = render.py defaults; render_fused_filters_on = "
+                     "the raw-parameter entry with the viewer's filters"})
 
 
 def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup):
