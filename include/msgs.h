@@ -25,9 +25,16 @@
  * `num_rendered` read the reference's forward performs).
  *
  * Threading: re-entrant (forward is called from the Python main thread, backward from PyTorch's
- * autograd thread).  Not stateless: three PROCESS-WIDE mode flags (msgs_set_deterministic,
- * msgs_set_backward_generation, msgs_set_blend_granularity; the last two only choose between kernels
- * that give the same results) and one 64-byte pinned status block per calling host thread.
+ * autograd thread).  Not stateless:
+ *   - four PROCESS-WIDE mode flags: msgs_set_deterministic, msgs_set_backward_generation, msgs_set_blend_granularity,
+ *     msgs_set_forward_variant (the last three only choose between kernels that give the same results);
+ *   - environment switches latched on first use (process-wide, for A/B measurements; every one only selects between
+ *     code paths with the same results): MSGS_BLOCKING_SYNC, MSGS_NO_SPECULATIVE_STAGE2, MSGS_BWD_LPT,
+ *     MSGS_SORT_TILE_PASSES, MSGS_SORT_NO_COMPACT, MSGS_SORT_ONESWEEP, MSGS_SORT_SCAN_TABLE, MSGS_SORT_DIRECT_SCATTER,
+ *     MSGS_FINE_SB, MSGS_FINE_SPLIT (full list with meanings: INTEGRATION.md §3);
+ *   - one 64-byte pinned status block per calling host thread for the calls that WAIT for the instance count
+ *     (msgs_forward, msgs_forward_stage1), and one per msgs_status_t handle for msgs_forward_launch /
+ *     msgs_forward_finish — any number of forwards may be in flight from one host thread on any streams, one per handle.
  *
  * Return value: 0 = MSGS_OK; < 0 = invalid argument / capacity (MSGS_ERR_*); > 0 = hipError_t.
  */
@@ -41,7 +48,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 7
+#define MSGS_ABI_VERSION 8
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -305,6 +312,28 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int
                  float* out_color, float* out_acc_pixel_size, float* out_depth, void* grad_records,
                  size_t grad_records_bytes, int64_t* num_instances_host, int32_t* stage2_done,
                  const msgs_timing_t* timing, void* stream);
+
+/* ---- forward without the host wait: several views in flight from one host thread -------------------------------------
+ * msgs_forward splits into msgs_forward_launch (everything msgs_forward enqueues: stage 1 and — on capacity-sized buffers
+ * — stage 2, nothing waited for) and msgs_forward_finish (the wait for the instance count).  Between the two the caller
+ * may launch other forwards (each on its own msgs_status_t and its own buffers, on the same or on other streams) and
+ * backwards of finished views: the reference's multi-view loops (/root/reference/train.py:282-299,337-341 insertion sweeps,
+ * :488-496 evaluation, render.py:37-49, render_traj.py:99-105) and the views of one optimizer step are independent, so two
+ * views on two streams let the instruction-bound blend kernels of one run beside the HBM- / latency-bound kernels of the
+ * other.  A handle owns one 64-byte pinned status block; create it once and reuse it launch after launch.
+ * msgs_forward_finish: *stage2_done = 1 when stage 2 ran on the launch's buffers (D <= their capacity); 0 when the caller
+ * has to call msgs_forward_stage2 on buffers sized for *num_instances_host (no guess yet, debug mode, or the scene outgrew
+ * the guess) on the same stream — exactly msgs_forward's contract.  Every buffer passed to the launch stays owned by the
+ * caller and must outlive the work enqueued on `stream`. */
+typedef struct msgs_status msgs_status_t;
+int msgs_status_create(msgs_status_t** out);
+int msgs_status_destroy(msgs_status_t* status);
+int msgs_forward_launch(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int32_t* radii, float* pixel_sizes,
+                        void* geom, size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning,
+                        size_t binning_bytes, void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes,
+                        float* out_color, float* out_acc_pixel_size, float* out_depth, void* grad_records,
+                        size_t grad_records_bytes, msgs_status_t* status, const msgs_timing_t* timing, void* stream);
+int msgs_forward_finish(msgs_status_t* status, int64_t* num_instances_host, int32_t* stage2_done);
 
 /* msgs_preprocess_only: the per-Gaussian stage alone (frustum cull, multi-scale filters, projection) — radii and
  * pixel_sizes exactly as msgs_forward_stage1 writes them, without sorting, binning or blending.  For the camera

@@ -5,6 +5,7 @@
 #include "msgs_internal.h"
 
 #include <atomic>
+#include <new>
 
 #include <cstring>
 
@@ -132,13 +133,65 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                         size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
                         size_t grad_records_bytes, const msgs_timing_t* timing, void* stream, const uint32_t* D_dev);
 
-int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
-                        void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
-                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream, SpecStage2* spec) {
+// The instance count D comes back through three pinned, device-mapped host words {D, flags, ticket} that a kernel writes
+// itself and the host polls: no copy command, no interrupt-driven wait (a blocking hipStreamSynchronize wakes up tens of
+// microseconds after the data landed, and until stage 2 is launched the GPU idles).  In the default sort/scan configuration
+// the scan's middle kernel — where the grand total is final — writes them, so the host learns D while the last stage-1
+// kernel still runs.  MSGS_BLOCKING_SYNC=1, or a failed pinned allocation, falls back to a 16-byte copy +
+// hipStreamSynchronize.  msgs_forward / msgs_forward_stage1 use one block per calling host thread (they wait before they
+// return); msgs_forward_launch takes the block of the caller's msgs_status_t, so that any number of forwards can be in
+// flight from one thread, one per handle.
+struct StatusBlock {
+    uint64_t* host = nullptr;
+    uint64_t* dev = nullptr;
+    uint64_t ticket = 0;
+    bool tried = false;
+    void ensure() {
+        if (tried) return;
+        tried = true;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                host = (uint64_t*)h;
+                dev = (uint64_t*)d;
+                host[2] = 0;
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+        tried = false;
+    }
+};
+
+// a stage 1 whose instance count has not been read back yet
+struct PendingCount {
+    bool active = false;
+    bool polled = false;
+    hipStream_t stream = nullptr;
+    uint64_t ticket = 0;
+    volatile uint64_t* host = nullptr;
+    const uint64_t* status_dev = nullptr;   // device copy of {D, flags}: the fallback when the flag never lands
+};
+
+static bool blocking_sync() {
+    static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
+    return blocking;
+}
+
+// Launches K1, the depth sort and the scan — and, with `spec`, stage 2 right behind them — WITHOUT waiting for D.
+int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+                          void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
+                          const msgs_timing_t* timing, void* stream, SpecStage2* spec, StatusBlock& sb,
+                          PendingCount& pend) {
+    pend.active = false;
     int rc = check_inputs(view, g);
     if (rc) return rc;
-    if (!num_instances_host) return MSGS_ERR_INVALID_ARG;
-    *num_instances_host = 0;
     const int P = g->P;
     if (P == 0) return MSGS_OK;
     if (!radii || !pixel_sizes || !geom_v || !scratch_v) return MSGS_ERR_INVALID_ARG;
@@ -167,45 +220,22 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     tm.end(MSGS_K_DEPTH_SORT);
     if ((rc = debug_sync(view, s))) return rc;
 
-    // The instance count D comes back through three pinned, device-mapped host words per host thread {D, flags,
-    // ticket} that a kernel writes itself and this thread polls: no copy command, no interrupt-driven wait (a blocking
-    // hipStreamSynchronize wakes up tens of microseconds after the data landed, and until stage 2 is launched the GPU
-    // idles).  In the default sort/scan configuration the scan's middle kernel — where the grand total is final —
-    // writes them, so the host learns D while the last stage-1 kernel still runs.  MSGS_BLOCKING_SYNC=1, or a failed
-    // pinned allocation, falls back to a 16-byte copy + hipStreamSynchronize.
-    static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
-    static thread_local uint64_t* t_host = nullptr;
-    static thread_local uint64_t* t_host_dev = nullptr;
-    static thread_local uint64_t t_ticket = 0;
-    static thread_local bool t_tried = false;
-    if (!blocking && !t_tried) {
-        t_tried = true;
-        void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
-            void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
-                t_host = (uint64_t*)h;
-                t_host_dev = (uint64_t*)d;
-                t_host[2] = 0;
-            } else {
-                (void)hipHostFree(h);
-            }
-        }
-        (void)hipGetLastError();
-    }
-    const bool polled = !blocking && t_host != nullptr;
-    const uint64_t ticket = ++t_ticket;
+    if (!blocking_sync()) sb.ensure();
+    const bool polled = !blocking_sync() && sb.host != nullptr;
+    const uint64_t ticket = ++sb.ticket;
     const bool classic = use_classic_sort();
     uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
     uint64_t* status_dev = total_dev + 2;
     uint32_t* clamped_dev = (uint32_t*)(total_dev + 5);       // min(D, capacity) for a speculative stage 2
-    if (spec && !classic) spec = nullptr;                     // (the look-back scan variant does not write it)
-    uint64_t host_status[2] = {0, 0};
+    if (spec && !classic) {                                   // (the look-back scan variant does not write it):
+        spec->capacity = 0;                                   // tell the caller that stage 2 was NOT launched
+        spec = nullptr;
+    }
 
     tm.begin(MSGS_K_SCAN);
     HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
-                               classic ? status_dev : nullptr, classic && polled ? t_host_dev : nullptr, ticket,
+                               classic ? status_dev : nullptr, classic && polled ? sb.dev : nullptr, ticket,
                                (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
                                spec ? (uint64_t)spec->capacity : 0));
     tm.end(MSGS_K_SCAN);
@@ -213,22 +243,39 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
         const SortScratch SSL(P);
         HIP_TRY(launch_collect_status(total_dev, (const uint32_t*)(scratch + SL.sort + SSL.hist) + 4 * 256 + 4,
                                       (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
-                                      status_dev, polled ? t_host_dev : nullptr, ticket, s));
+                                      status_dev, polled ? sb.dev : nullptr, ticket, s));
     }
-    if (spec)       // stage 2 goes out NOW, sized for the capacity; the GPU runs it while the host waits for D below
+    pend.active = true;
+    pend.polled = polled;
+    pend.stream = s;
+    pend.ticket = ticket;
+    pend.host = sb.host;
+    pend.status_dev = status_dev;
+    if (spec)       // stage 2 goes out NOW, sized for the capacity; the GPU runs it while the host waits for D
         spec->launched_rc = forward_stage2_impl(view, g, geom_v, geom_bytes, spec->capacity, spec->binning, spec->binning_bytes,
                                                 spec->scratch2, spec->scratch2_bytes, spec->image, spec->image_bytes,
                                                 spec->out_color, spec->out_acc_ps, spec->out_depth, spec->grad_records,
                                                 spec->grad_records_bytes, timing, stream, clamped_dev);
-    if (polled) {
-        volatile uint64_t* hv = t_host;
+    return MSGS_OK;
+}
+
+// Waits until the count of `pend` has landed (polls the pinned words; falls back to a device copy + synchronise).
+int forward_stage1_wait(PendingCount& pend, int64_t* num_instances_host) {
+    *num_instances_host = 0;
+    if (!pend.active) return MSGS_OK;             // P == 0
+    pend.active = false;
+    hipStream_t s = pend.stream;
+    uint64_t host_status[2] = {0, 0};
+    if (pend.polled) {
+        volatile uint64_t* hv = pend.host;
+        const uint64_t ticket = pend.ticket;
         uint64_t spins = 0;
         while (hv[2] != ticket) {
             if ((++spins & 0xFFFF) == 0) {                 // every 65536 polls: has the stream failed or finished?
                 const hipError_t q = hipStreamQuery(s);
                 if (q != hipErrorNotReady && q != hipSuccess) return (int)q;
                 if (q == hipSuccess && hv[2] != ticket) {  // finished without the flag: fall back to the device copy
-                    HIP_TRY(hipMemcpyAsync(host_status, status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipMemcpyAsync(host_status, pend.status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
                     break;
                 }
@@ -236,7 +283,7 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
         }
         if (hv[2] == ticket) { host_status[0] = hv[0]; host_status[1] = hv[1]; }
     } else {
-        HIP_TRY(hipMemcpyAsync(host_status, status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(host_status, pend.status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     const uint64_t total = host_status[0];
@@ -244,6 +291,23 @@ int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int3
     if (total > 0xFFFFFFFFull) return MSGS_ERR_TOO_MANY;
     *num_instances_host = (int64_t)total;
     return MSGS_OK;
+}
+
+StatusBlock& thread_status_block() {
+    static thread_local StatusBlock sb;           // (never freed: 64 bytes of pinned memory per calling host thread)
+    return sb;
+}
+
+int forward_stage1_impl(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
+                        void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
+                        int64_t* num_instances_host, const msgs_timing_t* timing, void* stream, SpecStage2* spec) {
+    if (!num_instances_host) return MSGS_ERR_INVALID_ARG;
+    *num_instances_host = 0;
+    PendingCount pend;
+    int rc = forward_stage1_launch(view, g, radii, pixel_sizes, geom_v, geom_bytes, scratch_v, scratch_bytes, timing, stream,
+                                   spec, thread_status_block(), pend);
+    if (rc) return rc;
+    return forward_stage1_wait(pend, num_instances_host);
 }
 
 // largest D with bytes_of(D) <= bytes (bytes_of monotone); 0 if none
@@ -269,6 +333,94 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                timing, stream, nullptr);
 }
 
+// speculative stage 2 on the caller's buffers: possible when they hold at least 4096 instances, the view is not in debug
+// mode and the sort geometry can take its count from a device word (MSGS_NO_SPECULATIVE_STAGE2=1: never)
+static bool prepare_spec(const msgs_view_t* view, const msgs_gaussians_t* g, void* binning, size_t binning_bytes, void* scratch2,
+                         size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color, float* out_acc_ps,
+                         float* out_depth, void* grad_records, size_t grad_records_bytes, SpecStage2& spec) {
+    static const bool no_spec = [] { const char* e = getenv("MSGS_NO_SPECULATIVE_STAGE2"); return e && e[0] == '1'; }();
+    if (no_spec || view->debug || g->P <= 0 || !binning || !scratch2 || !image || !out_color || !out_acc_ps || !out_depth ||
+        view->image_width <= 0 || view->image_height <= 0)
+        return false;
+    const int W0 = view->image_width, H0 = view->image_height;
+    const int64_t cb = max_instances_for(binning_bytes, [&](int64_t d) { return msgs_binning_bytes(d, W0, H0); });
+    const int64_t cs = max_instances_for(scratch2_bytes, [&](int64_t d) { return msgs_stage2_scratch_bytes(d, W0, H0); });
+    const int64_t cap = cb < cs ? cb : cs;
+    const int tiles0 = ((W0 + TILE - 1) / TILE) * ((H0 + TILE - 1) / TILE);
+    if (cap < 4096 || !radix_sort_supports_device_count(cap, 0, tile_bits(tiles0))) return false;
+    spec.capacity = cap;
+    spec.binning = binning; spec.binning_bytes = binning_bytes;
+    spec.scratch2 = scratch2; spec.scratch2_bytes = scratch2_bytes;
+    spec.image = image; spec.image_bytes = image_bytes;
+    spec.out_color = out_color; spec.out_acc_ps = out_acc_ps; spec.out_depth = out_depth;
+    spec.grad_records = grad_records; spec.grad_records_bytes = grad_records_bytes;
+    spec.launched_rc = MSGS_OK;
+    return true;
+}
+
+}  // extern "C"
+
+// the handle of msgs_forward_launch / msgs_forward_finish: its own pinned status block + the launch it is waiting for
+struct msgs_status {
+    StatusBlock sb;
+    PendingCount pend;
+    bool launched = false;       // a msgs_forward_launch has not been finished yet
+    bool stage2_launched = false;
+    int64_t capacity = 0;
+    int launched_rc = MSGS_OK;
+};
+
+extern "C" {
+
+int msgs_status_create(msgs_status_t** out) {
+    if (!out) return MSGS_ERR_INVALID_ARG;
+    *out = new (std::nothrow) msgs_status();
+    if (!*out) return (int)hipErrorOutOfMemory;
+    if (!blocking_sync()) (*out)->sb.ensure();
+    return MSGS_OK;
+}
+
+int msgs_status_destroy(msgs_status_t* st) {
+    if (!st) return MSGS_OK;
+    if (st->launched && st->pend.active) (void)hipStreamSynchronize(st->pend.stream);   // a kernel may still write the block
+    st->sb.release();
+    delete st;
+    return MSGS_OK;
+}
+
+int msgs_forward_launch(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes, void* geom,
+                        size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
+                        void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
+                        float* out_acc_ps, float* out_depth, void* grad_records, size_t grad_records_bytes,
+                        msgs_status_t* status, const msgs_timing_t* timing, void* stream) {
+    if (!view || !g || !status) return MSGS_ERR_INVALID_ARG;
+    if (status->launched) return MSGS_ERR_INVALID_ARG;          // one launch per handle at a time
+    SpecStage2 spec{};
+    const bool use_spec = prepare_spec(view, g, binning, binning_bytes, scratch2, scratch2_bytes, image, image_bytes, out_color,
+                                       out_acc_ps, out_depth, grad_records, grad_records_bytes, spec);
+    int rc = forward_stage1_launch(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, timing, stream,
+                                   use_spec ? &spec : nullptr, status->sb, status->pend);
+    if (rc) return rc;
+    status->launched = true;
+    status->stage2_launched = use_spec && spec.capacity > 0;
+    status->capacity = spec.capacity;
+    status->launched_rc = status->stage2_launched ? spec.launched_rc : MSGS_OK;
+    return MSGS_OK;
+}
+
+int msgs_forward_finish(msgs_status_t* status, int64_t* num_instances_host, int32_t* stage2_done) {
+    if (!status || !num_instances_host || !stage2_done) return MSGS_ERR_INVALID_ARG;
+    *stage2_done = 0;
+    *num_instances_host = 0;
+    if (!status->launched) return MSGS_ERR_INVALID_ARG;
+    status->launched = false;
+    int rc = forward_stage1_wait(status->pend, num_instances_host);
+    if (rc) return rc;
+    if (status->stage2_launched && status->launched_rc != MSGS_OK) return status->launched_rc;
+    if (status->stage2_launched && *num_instances_host <= status->capacity) *stage2_done = 1;
+    return MSGS_OK;
+}
+
 int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes, void* geom,
                  size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
                  void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
@@ -277,34 +429,16 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
     if (!stage2_done) return MSGS_ERR_INVALID_ARG;
     *stage2_done = 0;
     if (!view || !g) return MSGS_ERR_INVALID_ARG;
-    // speculative stage 2 on the caller's buffers (MSGS_NO_SPECULATIVE_STAGE2=1: wait for D first, as before)
-    static const bool no_spec = [] { const char* e = getenv("MSGS_NO_SPECULATIVE_STAGE2"); return e && e[0] == '1'; }();
     SpecStage2 spec{};
-    bool use_spec = false;
-    if (!no_spec && !view->debug && g->P > 0 && binning && scratch2 && image && out_color && out_acc_ps && out_depth &&
-        view->image_width > 0 && view->image_height > 0) {
-        const int W0 = view->image_width, H0 = view->image_height;
-        const int64_t cb = max_instances_for(binning_bytes, [&](int64_t d) { return msgs_binning_bytes(d, W0, H0); });
-        const int64_t cs = max_instances_for(scratch2_bytes, [&](int64_t d) { return msgs_stage2_scratch_bytes(d, W0, H0); });
-        const int64_t cap = cb < cs ? cb : cs;
-        const int tiles0 = ((W0 + TILE - 1) / TILE) * ((H0 + TILE - 1) / TILE);
-        if (cap >= 4096 && radix_sort_supports_device_count(cap, 0, tile_bits(tiles0))) {
-            spec.capacity = cap;
-            spec.binning = binning; spec.binning_bytes = binning_bytes;
-            spec.scratch2 = scratch2; spec.scratch2_bytes = scratch2_bytes;
-            spec.image = image; spec.image_bytes = image_bytes;
-            spec.out_color = out_color; spec.out_acc_ps = out_acc_ps; spec.out_depth = out_depth;
-            spec.grad_records = grad_records; spec.grad_records_bytes = grad_records_bytes;
-            spec.launched_rc = MSGS_OK;
-            use_spec = true;
-        }
-    }
+    bool use_spec = prepare_spec(view, g, binning, binning_bytes, scratch2, scratch2_bytes, image, image_bytes, out_color,
+                                 out_acc_ps, out_depth, grad_records, grad_records_bytes, spec);
     int rc = forward_stage1_impl(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, num_instances_host,
                                  timing, stream, use_spec ? &spec : nullptr);
     if (rc) return rc;
+    if (use_spec && spec.capacity == 0) use_spec = false;      // stage 1 declined the speculative launch: sequential route
     const int64_t D = *num_instances_host;
     const int W = view->image_width, H = view->image_height;
-    if (use_spec && spec.capacity > 0 && spec.launched_rc != MSGS_OK) return spec.launched_rc;
+    if (use_spec && spec.launched_rc != MSGS_OK) return spec.launched_rc;
     if (use_spec && D <= spec.capacity) {       // the normal case: stage 2 already ran (is running) on these buffers
         *stage2_done = 1;
         return MSGS_OK;

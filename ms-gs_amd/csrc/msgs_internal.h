@@ -360,8 +360,8 @@ hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* 
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
                          bool pre_zeroed = false, const uint32_t* D_dev = nullptr);
 int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value
-int set_blend_granularity(int mode);
-int set_forward_variant(int v);           // blend.hip: 0 = default, 1 quadrant lists, 2 tile, 3 | 4 strip lists; returns the previous      // blend.hip: 0 = by tile count, 1 = coarse, 2 = fine (16 waves per tile)
+int set_blend_granularity(int mode);      // blend.hip: 0 = by tile count, 1 = coarse, 2 = fine (16 waves per tile)
+int set_forward_variant(int v);           // blend.hip: 0 = default, 1 quadrant lists, 2 tile, 3 | 4 strip lists; returns the previous
 // blend.hip, deterministic backward: scratch = [grad_rec | inst_grad | sort buffers]
 struct DetScratch {
     size_t grad_rec, inst_grad, keys, keys_s, entry, sort, total;

@@ -756,7 +756,7 @@ bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit) {
     static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
     static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
     const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
-    return !onesweep && !scan_table && passes <= 4 && staged;
+    return use_classic_sort() && !onesweep && !scan_table && passes <= 4 && staged;
 }
 
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {

@@ -27,7 +27,8 @@ import torch.nn as nn
 
 from . import _backend as _C
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
+           "deferred_forward"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -283,12 +284,115 @@ def _a256(n):
     return (int(n) + 255) & ~255
 
 
+# ---- deferred forwards: several views in flight from one host thread (include/msgs.h msgs_forward_launch / _finish) ----
+# Inside `with deferred_forward() as pending:` every forward of this package only LAUNCHES (stage 1 and, on buffers sized
+# from the instance-count guess, stage 2) and returns its output tensors at once — valid in stream order, like any
+# asynchronous kernel result — without waiting for the instance count.  The wait happens in _PendingForward.resolve():
+# when the view's backward starts, when the caller resolves the entries of `pending`, or at the end of the `with` block,
+# whichever comes first.  If a scene outgrew its guess, resolve() redoes stage 2 on exact buffers on the view's stream
+# (the outputs are overwritten in place, stream-ordered behind the truncated result).  A consumer that reads an output
+# on ANOTHER stream, or on the host, must resolve the view first.  host/multi_view.py builds the two-stream pipelines
+# on top of this.
+_deferred = threading.local()
+
+_status_pool = []
+_status_lock = threading.Lock()
+
+
+def _take_status():
+    with _status_lock:
+        if _status_pool:
+            return _status_pool.pop()
+    h = C.c_void_p()
+    _C.check(_C.lib.msgs_status_create(C.byref(h)), "msgs_status_create")
+    return h
+
+
+def _give_status(h):
+    with _status_lock:
+        _status_pool.append(h)
+
+
+class deferred_forward:
+    """Context manager; yields the list the forwards' _PendingForward objects are appended to (in call order)."""
+
+    def __enter__(self):
+        self.prev = getattr(_deferred, "pending", None)
+        _deferred.pending = self.list = []
+        return self.list
+
+    def __exit__(self, *exc):
+        _deferred.pending = self.prev
+        for p_ in self.list:
+            if exc[0] is None:
+                p_.resolve()
+            else:
+                p_.abandon()
+        return False
+
+
+class _PendingForward:
+    """State of one launched forward: resolve() -> (geom, binning, image, D), waiting for the count if nobody has yet."""
+
+    def __init__(self, call, status, stream, key, guess, geom, binning, image, outs, grad_rec, keep):
+        self.call, self.status, self.stream, self.key, self.guess = call, status, stream, key, guess
+        self.geom, self.binning, self.image, self.outs, self.grad_rec, self.keep = geom, binning, image, outs, grad_rec, keep
+        self.state = None
+        self.lock = threading.Lock()
+
+    def resolve(self):
+        with self.lock:
+            if self.state is not None:
+                return self.state
+            lib, call = _C.lib, self.call
+            D, done = C.c_int64(0), C.c_int32(0)
+            status, self.status = self.status, None
+            try:
+                _C.check(lib.msgs_forward_finish(status, C.byref(D), C.byref(done)), "msgs_forward_finish")
+            finally:
+                _give_status(status)
+            D = int(D.value)
+            guess = self.guess
+            _last_instances[self.key] = max(D, (guess + D) // 2) if guess is not None else D
+            if not done.value:                          # first frame of this shape, or the scene grew past the margin
+                dev, W, H = call.device, call.W, call.H
+                color, acc_ps, depth = self.outs
+                with _on_device(dev), torch.cuda.stream(self.stream):
+                    self.binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
+                    scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
+                    grad_rec = self.grad_rec
+                    _C.check(lib.msgs_forward_stage2(call.view_ref, call.g_ref, _ptr(self.geom), self.geom.numel(), D,
+                                                     _ptr(self.binning), self.binning.numel(), _ptr(scratch2),
+                                                     scratch2.numel(), _ptr(self.image), self.image.numel(), _ptr(color),
+                                                     _ptr(acc_ps), _ptr(depth), _ptr(grad_rec),
+                                                     grad_rec.numel() if grad_rec is not None else 0, _C.timer_ptr(),
+                                                     C.c_void_p(self.stream.cuda_stream)), "msgs_forward_stage2")
+                    del scratch2
+            self.state = (self.geom, self.binning, self.image, D)
+            self.outs = self.grad_rec = None
+            return self.state
+
+    def abandon(self):
+        """the caller's block raised: finish the wait (the handle must not be reused while a kernel can still write its
+        status words) and swallow secondary errors"""
+        try:
+            self.resolve()
+        except Exception:
+            pass
+
+
+def _resolve(state):
+    return state.resolve() if isinstance(state, _PendingForward) else state
+
+
 def _forward_impl(call, grad_rec=None):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
     key = (dev.index, P, W, H, call.view.filter_small, call.view.filter_large)
+    pending = getattr(_deferred, "pending", None)
     with _on_device(dev):
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        cur = torch.cuda.current_stream(dev)
+        stream = C.c_void_p(cur.cuda_stream)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         pixel_sizes = torch.empty(P, dtype=torch.float32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -308,6 +412,23 @@ def _forward_impl(call, grad_rec=None):
         tmp = _bytes(_a256(n_s1) + n_s2, dev)
         scratch1 = tmp[:n_s1]
         scratch2 = tmp[_a256(n_s1):] if n_s2 else None
+        if pending is not None:
+            # launch only; the temporaries go back to the caching allocator at once, which hands them out again in THIS
+            # stream's order only (blocks are bound to the stream they were allocated on)
+            status = _take_status()
+            try:
+                _C.check(lib.msgs_forward_launch(call.view_ref, call.g_ref, _ptr(radii), _ptr(pixel_sizes),
+                                                 _ptr(geom), n_geom, _ptr(scratch1), n_s1,
+                                                 _ptr(binning), n_bin, _ptr(scratch2), n_s2,
+                                                 _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),
+                                                 _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
+                                                 status, _C.timer_ptr(), stream), "msgs_forward_launch")
+            except Exception:
+                _give_status(status)
+                raise
+            state = _PendingForward(call, status, cur, key, guess, geom, binning, image, (color, acc_ps, depth), grad_rec, keep)
+            pending.append(state)
+            return color, acc_ps, depth, radii, pixel_sizes, state
         D, done = C.c_int64(0), C.c_int32(0)
         _C.check(lib.msgs_forward(call.view_ref, call.g_ref, _ptr(radii), _ptr(pixel_sizes),
                                   _ptr(geom), n_geom, _ptr(scratch1), n_s1,
@@ -373,7 +494,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         call = ctx.call
         if grad_color is None:
             grad_color = torch.zeros(3, call.H, call.W, dtype=torch.float32, device=call.device)
-        geom, binning, image, D = ctx.state
+        geom, binning, image, D = _resolve(ctx.state)
         dev, P, K = call.device, call.P, call.K
         lib = _C.lib
         with _on_device(dev):
@@ -492,7 +613,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         call = ctx.call
         if grad_color is None:
             grad_color = torch.zeros(3, call.H, call.W, dtype=torch.float32, device=call.device)
-        geom, binning, image, D = ctx.state
+        geom, binning, image, D = _resolve(ctx.state)
         dev, P = call.device, call.P
         lib = _C.lib
         m2_shape, dc_shape, rest_shape, op_shape = ctx.shapes

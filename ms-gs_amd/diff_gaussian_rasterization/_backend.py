@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -108,6 +108,15 @@ def _load():
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, vp, sz, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
+    lib.msgs_status_create.restype = C.c_int
+    lib.msgs_status_create.argtypes = [C.POINTER(vp)]
+    lib.msgs_status_destroy.restype = C.c_int
+    lib.msgs_status_destroy.argtypes = [vp]
+    lib.msgs_forward_launch.restype = C.c_int
+    lib.msgs_forward_launch.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
+                                        vp, vp, vp, vp, sz, vp, C.POINTER(Timing), vp]
+    lib.msgs_forward_finish.restype = C.c_int
+    lib.msgs_forward_finish.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.msgs_preprocess_only.restype = C.c_int
     lib.msgs_preprocess_only.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp]
     lib.msgs_forward_stage2.restype = C.c_int
@@ -175,7 +184,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
            "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
-           "msgs_blend_lane_stats", "msgs_backward_per_gaussian", "msgs_set_forward_variant")
+           "msgs_blend_lane_stats", "msgs_backward_per_gaussian", "msgs_set_forward_variant",
+           "msgs_status_create", "msgs_status_destroy", "msgs_forward_launch", "msgs_forward_finish")
 
 
 def check(rc, where):
