@@ -139,6 +139,16 @@ typedef struct msgs_grads {
     int32_t scratch_is_clear;  /* non-zero: the first msgs_backward_scratch_bytes(P) bytes of `scratch` were handed to the
                                 * forward of THIS view as grad_records (it cleared them during the blend) and nothing has
                                 * written them since: msgs_backward skips its own fill launch.  0: msgs_backward clears them */
+    int32_t accumulate;        /* non-zero: ADD this view's gradients to what the output tensors hold (dL_dmeans3D, dL_dshs /
+                                * dL_dfeatures_*, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D), leaving the
+                                * rows of Gaussians this view did not render untouched — the views of one optimizer step
+                                * accumulate into ONE gradient bucket without zero rows and without a separate accumulation
+                                * pass (the reference's autograd does `param.grad += view_grad`: 3 x 236 B per Gaussian and
+                                * view at SH degree 3).  dL_dmeans2D stays per view (always stored).  The first view of a step
+                                * is called with 0 (it initialises every row).  Not with sh_coeffs != 16 on the reference API. */
+    void* wait_before_accumulate; /* optional hipEvent_t: the per-Gaussian kernel waits for it — the `accumulated` event of the
+                                * previous view into the same tensors when that view ran on ANOTHER stream */
+    void* accumulated;         /* optional hipEvent_t recorded behind the per-Gaussian kernel */
 } msgs_grads_t;
 
 /* Optional per-kernel timing (bench.py's roofline leg).  The caller owns the events; the library

@@ -565,6 +565,10 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     // raw modes: either both SH gradient tensors, or neither plus dL_dcolors (factored SH gradient, msgs.h)
     if (g->raw_params && (!grads->dL_dfeatures_dc != !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
     if (g->raw_params && !grads->dL_dfeatures_dc && !grads->dL_dcolors) return MSGS_ERR_INVALID_ARG;
+    // accumulate mode is implemented on the staged SH rows (K = 16) and not for the factored SH gradient
+    if (grads->accumulate && ((g->shs && !g->raw_params && view->sh_coeffs != 16) ||
+                              (g->raw_params && !grads->dL_dfeatures_dc)))
+        return MSGS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const char* geom = (const char*)geom_v;
     const char* binning = (const char*)binning_v;

@@ -239,23 +239,28 @@ __device__ __forceinline__ void coop_load_rows_part(float* lds_rows, const float
 }
 
 // rows 0..nrow of the wave are stored to g_rows (all 12 float4 of every row); a row whose bit in
-// `live` is clear, and every float at or beyond nfloat, is written as zero
+// `live` is clear, and every float at or beyond nfloat, is written as zero.
+// acc (msgs_grads_t::accumulate): live rows are ADDED to what g_rows holds, the other rows are not touched
 __device__ __forceinline__ void coop_store_rows(const float* lds_rows, float* g_rows, int nrow, uint64_t live,
-                                                int nfloat, int lane) {
+                                                int nfloat, int lane, bool acc) {
     constexpr int n4 = ROW_F / 4, rpi = 64 / n4;            // 12 float4 per row, 5 rows per instruction
     const int sub = lane / n4, c = lane - sub * n4;
     for (int it = 0; it * rpi < nrow; ++it) {
         const int row = it * rpi + sub;
         if (sub < rpi && row < nrow) {
+            const bool on = (live >> row) & 1ull;
+            if (acc && !on) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((live >> row) & 1ull) {
+            if (on) {
                 const float* sp = lds_rows + row * ROW_LDS + 4 * c;
                 v.x = 4 * c + 0 < nfloat ? sp[0] : 0.f;
                 v.y = 4 * c + 1 < nfloat ? sp[1] : 0.f;
                 v.z = 4 * c + 2 < nfloat ? sp[2] : 0.f;
                 v.w = 4 * c + 3 < nfloat ? sp[3] : 0.f;
             }
-            *reinterpret_cast<float4*>(g_rows + (size_t)row * ROW_F + 4 * c) = v;
+            float4* dst = reinterpret_cast<float4*>(g_rows + (size_t)row * ROW_F + 4 * c);
+            if (acc) { const float4 o = *dst; v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w; }
+            *dst = v;
         }
     }
 }
@@ -361,31 +366,48 @@ __device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const floa
 }
 
 // inverse: gradient rows from LDS to the split dc / rest gradient tensors (zeros for rows not in `live` and for
-// coefficients beyond the active degree)
+// coefficients beyond the active degree).  acc: live rows are ADDED to the tensors, the others not touched.
 __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, float* d_dc, float* d_rest, int i,
                                                       bool in_range, int wave_first, int nrow, uint64_t live,
-                                                      int nfloat, int lane, int lrow) {
+                                                      int nfloat, int lane, int lrow, bool acc = false) {
     if (in_range) {
         const bool on = (live >> lrow) & 1ull;
+        if (!acc) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = on ? lds_rows[lrow * ROW_LDS + c] : 0.f;
+            for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = on ? lds_rows[lrow * ROW_LDS + c] : 0.f;
+        } else if (on) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = d_dc[3 * (size_t)i + c] + lds_rows[lrow * ROW_LDS + c];
+        }
     }
     float* dst = d_rest + (size_t)wave_first * REST_F;
     const int nflat = nrow * REST_F;
     for (int base = 0; base < nflat; base += 256) {
         const int f0 = base + lane * 4;
         float v[4];
+        bool on[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = min(f0 + j, nflat - 1);
             const int row = f / REST_F, k = f - row * REST_F;
-            v[j] = (((live >> row) & 1ull) && 3 + k < nfloat) ? lds_rows[row * ROW_LDS + 3 + k] : 0.f;
+            on[j] = (live >> row) & 1ull;
+            v[j] = (on[j] && 3 + k < nfloat) ? lds_rows[row * ROW_LDS + 3 + k] : 0.f;
         }
         if (f0 + 3 < nflat) {
-            *reinterpret_cast<float4*>(dst + f0) = make_float4(v[0], v[1], v[2], v[3]);
+            float4* d4 = reinterpret_cast<float4*>(dst + f0);
+            if (!acc) {
+                *d4 = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (on[0] || on[3]) {             // four consecutive floats span at most two rows
+                const float4 o = *d4;
+                *d4 = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (f0 + j < nflat) dst[f0 + j] = v[j];
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < nflat) {
+                    if (!acc) dst[f0 + j] = v[j];
+                    else if (on[j]) dst[f0 + j] = dst[f0 + j] + v[j];
+                }
         }
     }
 }
@@ -634,6 +656,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
     // factored SH gradient (view-parallel exchange, msgs_sh_grad_from_views): dL/dSH of one view is the outer product
     // basis(direction) x dL/drgb, so only the (clamp-masked) dL/drgb is delivered and the 192-byte rows are not written
     const bool factored_sh = raw && grads.dL_dfeatures_dc == nullptr;
+    // accumulate (several views of one optimizer step into one gradient bucket): add to what the gradient tensors hold and
+    // leave the rows of Gaussians this view did not render alone — no zero rows, no separate accumulation pass
+    const bool accum = grads.accumulate != 0;
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
     if (staged_sh) {                         // list of the rendered lanes, ascending: the rows to fetch
@@ -896,19 +921,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
             wave_lds_fence();
             if (raw)
                 coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range && mine, first,
-                                      nrow, live_h, nfloat, lane, lrow);
+                                      nrow, live_h, nfloat, lane, lrow, accum);
             else
-                coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)first * ROW_F, nrow, live_h, nfloat, lane);
+                coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)first * ROW_F, nrow, live_h, nfloat, lane, accum);
         }
     } else if (do_colour) {
+        // (direct per-thread rows, K != 16: accumulate mode is not offered on this path — msgs_backward refuses it)
         float* dsh = grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr;
         if (rendered) colour_backward(g.shs + (size_t)3 * K * i, dsh);
         else if (dsh) for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
     }
     if (!in_range) return;
 
-    if (grads.dL_dmeans3D) { grads.dL_dmeans3D[3 * i] = dmean[0]; grads.dL_dmeans3D[3 * i + 1] = dmean[1]; grads.dL_dmeans3D[3 * i + 2] = dmean[2]; }
+    // the screen-space gradient is per view (viewspace_points.grad of THIS render, scene/gaussian_model.py:698-701): stored
     if (grads.dL_dmeans2D) { grads.dL_dmeans2D[3 * i] = g2x; grads.dL_dmeans2D[3 * i + 1] = g2y; grads.dL_dmeans2D[3 * i + 2] = 0.f; }
+    if (accum) {
+        if (!rendered) return;
+        if (grads.dL_dmeans3D) {
+            float* d = grads.dL_dmeans3D + 3 * (size_t)i;
+            d[0] = d[0] + dmean[0]; d[1] = d[1] + dmean[1]; d[2] = d[2] + dmean[2];
+        }
+        if (grads.dL_dopacities) grads.dL_dopacities[i] = grads.dL_dopacities[i] + dopac;
+        if (grads.dL_dcolors && !factored_sh) {
+            float* d = grads.dL_dcolors + 3 * (size_t)i;
+            d[0] = d[0] + dcolr[0]; d[1] = d[1] + dcolr[1]; d[2] = d[2] + dcolr[2];
+        }
+        if (grads.dL_dscales) {
+            float* d = grads.dL_dscales + 3 * (size_t)i;
+            d[0] = d[0] + dscale[0]; d[1] = d[1] + dscale[1]; d[2] = d[2] + dscale[2];
+        }
+        if (grads.dL_drotations) {
+            float4* d = reinterpret_cast<float4*>(grads.dL_drotations) + i;
+            const float4 o = *d;
+            *d = make_float4(o.x + dq[0], o.y + dq[1], o.z + dq[2], o.w + dq[3]);
+        }
+        if (grads.dL_dcov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) grads.dL_dcov3D[6 * (size_t)i + k] = grads.dL_dcov3D[6 * (size_t)i + k] + dcov[k];
+        }
+        return;
+    }
+    if (grads.dL_dmeans3D) { grads.dL_dmeans3D[3 * i] = dmean[0]; grads.dL_dmeans3D[3 * i + 1] = dmean[1]; grads.dL_dmeans3D[3 * i + 2] = dmean[2]; }
     if (grads.dL_dopacities) grads.dL_dopacities[i] = dopac;
     if (grads.dL_dcolors && !factored_sh) { grads.dL_dcolors[3 * i] = dcolr[0]; grads.dL_dcolors[3 * i + 1] = dcolr[1]; grads.dL_dcolors[3 * i + 2] = dcolr[2]; }
     if (grads.dL_dscales) { grads.dL_dscales[3 * i] = dscale[0]; grads.dL_dscales[3 * i + 1] = dscale[1]; grads.dL_dscales[3 * i + 2] = dscale[2]; }
@@ -1034,9 +1087,17 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
             if (e != hipSuccess) return e;
         }
     }
+    // several views into one gradient bucket from different streams: this kernel reads and writes the bucket, so it
+    // waits for the previous view's kernel (its `accumulated` event) and signals its own end
+    if (grads.wait_before_accumulate) {
+        hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)grads.wait_before_accumulate, 0);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
                        grad_rec, grads);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && grads.accumulated) e = hipEventRecord((hipEvent_t)grads.accumulated, s);
+    return e;
 }
 
 hipError_t launch_sh_grad_from_views(int P, int n_views, int deg, const float* means3D, const float* campos,

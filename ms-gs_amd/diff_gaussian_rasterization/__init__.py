@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import _backend as _C
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "deferred_forward"]
+           "deferred_forward", "GradAccumulator", "set_grad_accumulator"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -571,11 +571,87 @@ def set_grad_sinks(mapping, sh_factor=None, factors_ready=None):
             _grad_sinks[id(leaf)] = (weakref.ref(leaf), dest)
 
 
+class GradAccumulator:
+    """One gradient bucket for ALL views of an optimizer step (include/msgs.h, msgs_grads_t::accumulate).
+
+    While installed (set_grad_accumulator), the backward of the raw / chained entries writes the leaf gradients straight into
+    this object's tensors — the first view of a step stores every row, the later ones ADD their rendered rows inside the
+    per-Gaussian kernel — and returns None for the leaves, so autograd runs no `param.grad += g` passes (six kernels and
+    3 x 236 bytes per Gaussian and view at SH degree 3) and the kernel writes no zero rows for Gaussians a view did not
+    render.  The sums are formed in the order of the backward calls, like autograd's: same bits.  Views may run on
+    different streams: each backward waits for the previous one's kernel through an event.  finish() hands the bucket to
+    the parameters' .grad (call it on the stream that will consume the gradients)."""
+
+    def __init__(self, leaves):
+        self.leaves = list(leaves)
+        for t in self.leaves:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
+                raise ValueError("GradAccumulator: leaves must be contiguous float32 tensors on a HIP device")
+        self.dest = None
+        self.count = 0
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in self.events:                       # torch creates the HIP event on the first record()
+            e.record(torch.cuda.current_stream(self.leaves[0].device))
+        self.last = None
+        self.lock = threading.Lock()
+
+    def begin_step(self):
+        """fresh (uninitialised) tensors: the first backward of the step writes every row"""
+        self.dest = [torch.empty_like(t) for t in self.leaves]
+        self.count = 0
+        self.last = None
+
+    def _take(self, leaves):
+        """(destinations in the order of `leaves`, accumulate flag, event to wait for or None, event to record)"""
+        with self.lock:
+            if self.dest is None:
+                self.begin_step()
+            by_id = {id(t): d for t, d in zip(self.leaves, self.dest)}
+            try:
+                dests = [by_id[id(t)] for t in leaves]
+            except KeyError:
+                raise ValueError("GradAccumulator: the call's parameters are not the tensors it was built for "
+                                 "(densification re-creates them: build a new accumulator)") from None
+            acc, wait = self.count > 0, self.last
+            rec = self.events[self.count & 1]
+            self.count += 1
+            self.last = rec
+            return dests, acc, wait, rec
+
+    def finish(self):
+        """param.grad = bucket (or += when a gradient is already there); the current stream waits for the last view"""
+        if self.dest is None or self.count == 0:
+            return
+        if self.last is not None:
+            torch.cuda.current_stream(self.leaves[0].device).wait_event(self.last)
+        for t, d in zip(self.leaves, self.dest):
+            if t.grad is None:
+                t.grad = d
+            else:
+                t.grad += d
+        self.dest = None
+        self.count = 0
+        self.last = None
+
+
+_accumulator = [None]
+
+
+def set_grad_accumulator(acc):
+    """Install (or, with None, remove) the GradAccumulator the following forwards of the raw / chained entries snapshot.
+    Returns the previous one."""
+    prev = _accumulator[0]
+    _accumulator[0] = acc
+    return prev
+
+
 def _snapshot_sinks(ctx, leaves):
     """Called in forward (the caller's thread): the sinks registered for THIS call travel on its ctx, so that the
     backward — which runs on autograd's worker thread — never reads module state another thread may be changing."""
     ctx.sinks = tuple(_grad_sinks.get(id(t)) for t in leaves)
     ctx.sh_factor = (_sh_factor_sink[0], _sh_factor_sink[1])
+    ctx.accum = _accumulator[0]
+    ctx.leaves = leaves if ctx.accum is not None else None
 
 
 def _grad_out(hit, shape, dev):
@@ -625,20 +701,32 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             factor, ready = ctx.sh_factor
             if factor is not None and (factor.device != dev or factor.shape[0] != P):
                 raise ValueError("sh_factor sink does not match this model (device / number of Gaussians)")
-            g_xyz = _grad_out(kx, (P, 3), dev)
-            g_dc = g_rest = None
-            if factor is None:
-                g_dc, g_rest = _grad_out(kdc, dc_shape, dev), _grad_out(krest, rest_shape, dev)
-            g_opac, g_scal, g_rot = _grad_out(kop, op_shape, dev), _grad_out(ksc, (P, 3), dev), _grad_out(krot, (P, 4), dev)
+            accum = getattr(ctx, "accum", None)
+            acc_flag, ev_wait, ev_rec = 0, None, None
+            if accum is not None:
+                if factor is not None:
+                    raise ValueError("GradAccumulator and the factored SH gradient cannot be combined")
+                (g_xyz, g_dc, g_rest, g_opac, g_scal, g_rot), acc, wait, rec = accum._take(ctx.leaves)
+                acc_flag = 1 if acc else 0
+                ev_wait = C.c_void_p(wait.cuda_event) if wait is not None else None
+                ev_rec = C.c_void_p(rec.cuda_event)
+            else:
+                g_xyz = _grad_out(kx, (P, 3), dev)
+                g_dc = g_rest = None
+                if factor is None:
+                    g_dc, g_rest = _grad_out(kdc, dc_shape, dev), _grad_out(krest, rest_shape, dev)
+                g_opac, g_scal, g_rot = _grad_out(kop, op_shape, dev), _grad_out(ksc, (P, 3), dev), _grad_out(krot, (P, 4), dev)
             scratch, is_clear = _take_backward_scratch(ctx, P, D, dev)
             grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, _ptr(factor), _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
                              _ptr(g_dc), _ptr(g_rest),
                              C.c_void_p(ready.cuda_event) if (factor is not None and ready is not None) else None,
-                             is_clear)
+                             is_clear, acc_flag, ev_wait, ev_rec)
             _C.check(lib.msgs_backward(call.view_ref, call.g_ref, _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
                                        _C.timer_ptr(), stream), "msgs_backward")
+        if accum is not None:               # the leaf gradients live in the accumulator: nothing for autograd to add
+            return (None, g_m2.view(m2_shape), None, None, None, None, None, None, None, None, None, None, None)
         return (g_xyz, g_m2.view(m2_shape), g_dc, g_rest, g_opac, g_scal, g_rot, None, None, None, None, None, None)
 
 

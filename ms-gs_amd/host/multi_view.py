@@ -16,8 +16,9 @@ HIP streams from one host thread:
     in a backward (blend backward, per-Gaussian backward);
   * the model's getters (exp / sigmoid / normalize / cat, /root/reference/scene/gaussian_model.py:127-153) are evaluated
     ONCE per sweep and shared by its views (`share_getters`), instead of once per render() call;
-  * gradients of all views accumulate into the parameters' .grad (autograd's accumulation, stream-safe), i.e. one
-    gradient bucket per optimizer step.
+  * the views' gradients are summed INSIDE the per-Gaussian backward kernel into one bucket that becomes the parameters'
+    .grad (diff_gaussian_rasterization.GradAccumulator): no `param.grad += g` passes after every view (six kernels,
+    0.11 ms per view at 1 M Gaussians) and no zero rows for Gaussians a view did not render.
 
 Results are bit-identical to rendering the same views one after the other on one stream
 (tests/test_multi_view_gpu.py): every view runs the same kernels on its own buffers; only their interleaving on the
@@ -29,6 +30,8 @@ import diff_gaussian_rasterization as dgr
 from gaussian_renderer import render as _render
 
 _GETTERS = ("get_features", "get_opacity", "get_scaling", "get_rotation")
+# the leaf parameters of the reference's GaussianModel (/root/reference/scene/gaussian_model.py:53-58)
+LEAF_NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 
 
 class SharedGetters:
@@ -59,9 +62,13 @@ class SharedGetters:
 
 
 class ViewPipeline:
-    """Two (or more) HIP streams + the launch order that keeps a forward and a backward in flight together.
+    """View lanes (one HIP stream each) + the launch order that keeps a forward and a backward in flight together.
 
-    priorities: optional per-stream priorities (torch convention: lower = more urgent, 0 default, -1 high)."""
+    n_streams: 2 by default; 3 lanes measured 2-3 % faster for fwd+bwd at 1 M Gaussians / 1080p and 3 % slower forward-only.
+    priorities: optional per-lane stream priorities (torch convention: lower = more urgent).
+    What was measured and NOT kept (profiles/r4_notes.md): the blend kernels of every lane on low-priority streams of their
+    own (no effect on who gets free wave slots, +20-40 us of event fences per kernel), and CU-masked blend streams that keep
+    a few CUs per XCD free for the other lanes' kernels (cross-queue fences of masked queues cost hundreds of us)."""
 
     def __init__(self, device, n_streams=2, priorities=None):
         self.device = torch.device(device)
@@ -138,8 +145,15 @@ class ViewPipeline:
         return out
 
     # -- forward + backward ----------------------------------------------------------------------------------------
-    def train_views(self, cams, pc, pipe, bg_color, backward_fn, render_fn=_render, share_getters=True, **settings):
+    def train_views(self, cams, pc, pipe, bg_color, backward_fn, render_fn=_render, share_getters=True,
+                    accumulate_in_kernel=True, **settings):
         """render() + backward of every view of one optimizer step; gradients accumulate into the parameters' .grad.
+
+        accumulate_in_kernel: the views' leaf gradients are summed inside the per-Gaussian backward kernel into one bucket
+        (diff_gaussian_rasterization.GradAccumulator) that becomes .grad at the end, instead of autograd's
+        `param.grad += g` passes after every view (same order of additions, same bits); it applies to the calls the op
+        recognises as the reference's getters or that use the raw-parameter entry — any other call is accumulated by
+        autograd as usual.
 
         backward_fn(i, pkg) is called in view i's stream context once the view is resolved and must run the view's
         backward (e.g. `loss_of(pkg["render"], gt[i]).backward()` or `pkg["render"].backward(dL[i])`); its return value
@@ -148,25 +162,39 @@ class ViewPipeline:
         n = len(cams)
         ns = len(self.streams)
         model = self._model(pc, share_getters)
+        acc = prev_acc = None
+        if accumulate_in_kernel and n > 1:
+            acc = dgr.GradAccumulator([getattr(pc, name) for name in LEAF_NAMES])
+            acc.begin_step()                      # allocated on the caller's stream, ahead of the fork
+            prev_acc = dgr.set_grad_accumulator(acc)
         cur = self._fork()
         out = [None] * n
         pkgs = [None] * n
-        with dgr.deferred_forward() as pending:
-            def launch(i):
-                with torch.cuda.stream(self.streams[i % ns]):
-                    before = len(pending)
-                    pkgs[i] = (render_fn(cams[i], model, pipe, bg_color, **settings), pending[before:])
-            if n:
-                launch(0)
-            for i in range(n):
-                if i + 1 < n:
-                    launch(i + 1)
-                pkg, mine = pkgs[i]
-                pkgs[i] = None
-                for p_ in mine:
-                    p_.resolve()
-                with torch.cuda.stream(self.streams[i % ns]):
-                    out[i] = backward_fn(i, pkg)
-                del pkg
+        try:
+            with dgr.deferred_forward() as pending:
+                def launch(i):
+                    with torch.cuda.stream(self.streams[i % ns]):
+                        before = len(pending)
+                        pkgs[i] = (render_fn(cams[i], model, pipe, bg_color, **settings), pending[before:])
+                if n:
+                    launch(0)
+                for i in range(n):
+                    if i + 1 < n:
+                        launch(i + 1)
+                    pkg, mine = pkgs[i]
+                    pkgs[i] = None
+                    for p_ in mine:
+                        p_.resolve()
+                    with torch.cuda.stream(self.streams[i % ns]):
+                        out[i] = backward_fn(i, pkg)
+                    del pkg
+        finally:
+            if acc is not None:
+                dgr.set_grad_accumulator(prev_acc)
         self._join(cur)
+        if acc is not None:
+            acc.finish()
+        for o in out:
+            if isinstance(o, dict):
+                self._hand_over(o, cur)
         return out

@@ -42,7 +42,8 @@ class Grads(C.Structure):
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p),
-                ("scratch_is_clear", C.c_int32)]
+                ("scratch_is_clear", C.c_int32), ("accumulate", C.c_int32),
+                ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p)]
 
 
 def build(force=False):

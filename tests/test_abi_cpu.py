@@ -35,7 +35,8 @@ def test_struct_layouts_match_header():
     from oracle import oracle_ctypes as oc
     assert C.sizeof(dgr._C.View) == 12 * 4 + 4 * 8 == C.sizeof(oc.View)
     assert C.sizeof(dgr._C.Gaussians) == 8 + 15 * 8 == C.sizeof(oc.Gaussians)
-    assert C.sizeof(dgr._C.Grads) == 12 * 8 == C.sizeof(oc.Grads) and dgr._C.Grads.scratch_is_clear.offset == 88
+    assert C.sizeof(dgr._C.Grads) == 14 * 8 == C.sizeof(oc.Grads) and dgr._C.Grads.scratch_is_clear.offset == 88
+    assert dgr._C.Grads.accumulate.offset == 92 and dgr._C.Grads.wait_before_accumulate.offset == 96
     assert dgr._C.View.bg.offset == 48 and dgr._C.Gaussians.means3D.offset == 8
     assert [f[0] for f in dgr._C.View._fields_] == [f[0] for f in oc.View._fields_]
 

@@ -35,9 +35,9 @@ def _serial_train(sc, cams, dLs, bg, st=ST):
     return pc, outs, m2
 
 
-@pytest.mark.parametrize("share_getters", [False, True])
+@pytest.mark.parametrize("share_getters,accumulate_in_kernel", [(False, False), (True, True), (True, False), (False, True)])
 @pytest.mark.parametrize("n_streams", [2, 3])
-def test_train_views_equals_the_serial_loop_bit_for_bit(share_getters, n_streams):
+def test_train_views_equals_the_serial_loop_bit_for_bit(share_getters, accumulate_in_kernel, n_streams):
     import diff_gaussian_rasterization as dgr
     from multi_view import ViewPipeline
     from synthetic_model import SyntheticGaussians
@@ -56,7 +56,8 @@ def test_train_views_equals_the_serial_loop_bit_for_bit(share_getters, n_streams
             pkg["render"].backward(dLs[i])
             kept.append(pkg)
             return pkg["viewspace_points"]
-        vs = pipe.train_views(cams, pc, PIPE, bg, bwd, share_getters=share_getters, **ST)
+        vs = pipe.train_views(cams, pc, PIPE, bg, bwd, share_getters=share_getters, accumulate_in_kernel=accumulate_in_kernel,
+                              **ST)
         torch.cuda.synchronize()
         for i, (o, r) in enumerate(zip(kept, ref_outs)):
             for k in OUT_KEYS:

@@ -24,7 +24,8 @@ pc = SyntheticGaussians(sc, "cuda", requires_grad=True)
 bg = torch.zeros(3, device="cuda")
 dL = scenes.grad_seed(W, H, 5).to("cuda")
 prio = [int(x) for x in os.environ["MSGS_TV_PRIO"].split(",")] if "MSGS_TV_PRIO" in os.environ else None
-pipe = ViewPipeline("cuda", n_streams=len(prio) if prio else 2, priorities=prio)
+lanes = int(os.environ.get("MSGS_TV_LANES", "2"))
+pipe = ViewPipeline("cuda", n_streams=len(prio) if prio else lanes, priorities=prio)
 import gc
 
 
