@@ -49,24 +49,27 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 from hostinfo import limit_thread_pools, usable_cpus  # noqa: E402  (the pools are sized after the launch decision below)
 
 
+_GC_DEFAULT = gc.isenabled()
+
+
 @contextlib.contextmanager
 def quiet_gc():
     """Timed regions run with Python's cyclic garbage collector paused: a full collection of this process's heap takes 30-70 ms
     and lands, at a position fixed by the allocation count, inside some timed window of ~10 ms (seen as a 5.9 ms 'step' at one
     pyramid level; tools/diag_level_jitter2.py).  Interpreter housekeeping, not part of a step.  The collection itself is done by
     settle_gc() BEFORE the warm-up steps, never between warm-up and timing: a 35 ms pause there lets the GPU clock down and the
-    first timed steps pay for the ramp (measured: +0.07 ms per step over a 20-step region)."""
-    was = gc.isenabled()
+    first timed steps pay for the ramp (measured: +0.07 ms per step over a 20-step region).  The collector is switched back on
+    when the region ends (host memory must not grow across the many timed loops of one run)."""
     gc.disable()
     try:
         yield
     finally:
-        if was:
+        if _GC_DEFAULT:
             gc.enable()
 
 
 def settle_gc():
-    """collect now (ahead of a warm-up loop) and leave the collector off until the process ends"""
+    """collect now (ahead of a warm-up loop) and keep the collector off until the following timed region (quiet_gc) ends"""
     gc.collect()
     gc.disable()
 
@@ -98,12 +101,42 @@ def _self_launch_if_needed():
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=per_rank, MKL_NUM_THREADS=per_rank)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
-    sys.stdout.write(out or "")
+    # supervise every rank: a rank that dies before or inside a collective leaves its peers waiting in the rendezvous or in
+    # RCCL until the process-group timeout — on the first failure (or after MSGS_BENCH_TIMEOUT seconds) the others are stopped
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("MSGS_BENCH_TIMEOUT", "3600"))
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for i, p_ in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p_.poll()
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else 124
+            for i, p_ in enumerate(procs):          # fresh children of this process: stopping them is safe
+                if codes[i] is None:
+                    p_.terminate()
+            t_kill = time.time() + 10.0
+            for i, p_ in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p_.wait(timeout=max(0.1, t_kill - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p_.kill()
+                        codes[i] = p_.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5.0)
+    sys.stdout.write("".join(c for c in chunks if c))
     sys.stdout.flush()
-    bad = [c for c in codes if c != 0]
-    raise SystemExit(bad[0] if bad else 0)
+    if failed is not None:
+        print(f"[bench launcher] a rank exited with status {failed}; the other ranks were stopped", file=sys.stderr)
+        raise SystemExit(failed)
+    raise SystemExit(0)
 
 
 if __name__ == "__main__":
@@ -267,6 +300,67 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
                      "the raw-parameter entry with the viewer's filters"})
 
 
+def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8, rounds=5):
+    """ms per view of sweeps over `views` views of the same model with two of them in flight (ViewPipeline: the forward of view
+    i+1 enqueued before the backward of view i on the other stream, no host wait for the instance counts, getters once per sweep,
+    gradients summed inside the per-Gaussian backward kernel), against the same sweep done the reference's way — one view after
+    the other on one stream (train.py:282-299,337-341,488-496; the views of one optimizer step at C4 on fewer than 8 GPUs)."""
+    from gaussian_renderer import PIPE, render, render_fused
+    from multi_view import ViewPipeline
+    cams = [cam] * views
+    pipe = ViewPipeline(cam.world_view_transform.device, n_streams=2)
+
+    def zero():
+        for p_ in pc.parameters():
+            p_.grad = None
+
+    def timed(fn):
+        settle_gc()
+        for _ in range(max(1, warmup // 2)):
+            fn()
+        torch.cuda.synchronize()
+        with quiet_gc():
+            t = time.perf_counter()
+            for _ in range(rounds):
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+        return round(1e3 * dt / rounds / views, 4)
+
+    bwd = lambda i, pkg: pkg["render"].backward(dL)
+
+    def serial(fn):
+        zero()
+        for c in cams:
+            fn(c, pc, PIPE, bg, **settings)["render"].backward(dL)
+
+    def piped(fn):
+        zero()
+        pipe.train_views(cams, pc, PIPE, bg, bwd, render_fn=fn, **settings)
+    out = {"views_per_sweep": views, "lanes": 2,
+           "serial_fwd_bwd_ms_per_view": timed(lambda: serial(render)),
+           "fwd_bwd_ms_per_view": timed(lambda: piped(render)),
+           "fused_serial_fwd_bwd_ms_per_view": timed(lambda: serial(render_fused)),
+           "fused_fwd_bwd_ms_per_view": timed(lambda: piped(render_fused))}
+    zero()
+    with torch.no_grad():
+        out["serial_forward_ms_per_view"] = timed(lambda: [render(c, pc, PIPE, bg, **settings) for c in cams])
+        out["forward_ms_per_view"] = timed(lambda: pipe.render_views(cams, pc, PIPE, bg, **settings))
+        out["fused_forward_ms_per_view"] = timed(lambda: pipe.render_views(cams, pc, PIPE, bg, render_fn=render_fused,
+                                                                           share_getters=False, **settings))
+    out["value_fwd_bwd"] = round(W * H / 1e6 / (out["fwd_bwd_ms_per_view"] * 1e-3), 3)
+    out["unit"] = "Mpixels/s"
+    if whole_step and whole_step.get("algorithmic_bytes"):
+        b = whole_step["algorithmic_bytes"]
+        out["whole_step"] = {"algorithmic_bytes": int(b), "GBps": round(b / (out["fwd_bwd_ms_per_view"] * 1e-3) / 1e9, 1),
+                             "frac": round(b / (out["fwd_bwd_ms_per_view"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    out["what"] = ("sweeps over 8 copies of the C3 view, ms per view: the serial loop (one stream, gradients accumulated by autograd "
+                   "over the sweep) vs host/multi_view.ViewPipeline (two lanes, deferred forwards, getters once per sweep, gradients "
+                   "summed inside the per-Gaussian backward); bit-identical results (tests/test_multi_view_gpu.py); informational — "
+                   "`value` stays one view per step")
+    return out
+
+
 def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup):
     import torch.nn.functional as F
     from gaussian_renderer import render
@@ -345,6 +439,8 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python3 bench.py --gpus N` (the script "
                          "starts its own ranks) or under torch.distributed.run with --nproc-per-node N")
+    if os.environ.get("MSGS_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        raise SystemExit(3)        # rehearsal of a rank that dies before the rendezvous (tests/test_bench_launcher_cpu.py)
     if os.environ.get("MSGS_BENCH_LAUNCH_ONLY") == "1":
         # rehearsal of the rank start-up alone (tests/test_bench_launcher_cpu.py, no GPU): rendezvous over gloo, one
         # collective, rank 0 prints a JSON line the parent has to relay
@@ -522,6 +618,30 @@ def main():
                     "min_ms": round(ts_[0], 4), "p90_ms": round(ts_[44], 4),
                     "how": "median of 50 steps, HIP events on the compute stream around each step"}
 
+    # the same K steps with the host settings a drop-in train.py gets WITHOUT the two caller-side lines of INTEGRATION.md 1.1:
+    # Python's collector on, autograd's backward on its device thread (the thread pools stay sized to the CPU quota: that cannot
+    # be undone inside this process) — so that what the tuned settings are worth is visible next to `value`
+    default_host = None
+    if world == 1:
+        try:
+            if SINGLE_THREAD_BACKWARD:
+                torch.autograd.set_multithreading_enabled(True)
+            gc.enable()
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            t_ = (time.perf_counter() - t_) / args.steps
+            default_host = {"ms_per_step": round(1e3 * t_, 4), "value": round(W * H / 1e6 / t_, 3), "unit": "Mpixels/s",
+                            "what": "the timed loop again with Python's GC enabled and torch's default multithreaded autograd "
+                                    "(backward on the device thread)"}
+        finally:
+            if SINGLE_THREAD_BACKWARD:
+                torch.autograd.set_multithreading_enabled(False)
+
     # N > 1, informational ("with and without the all-reduce"), the same K steps with
     #   (a) the dense exchange serialised after each view: ONE flat all-reduce of the 59 floats / Gaussian
     #   (b) that dense all-reduce overlapped with the rendering of the NEXT view (two buckets; an optimizer step then
@@ -566,6 +686,32 @@ def main():
         pipe.drain()
         tp = timed_region(step_pipe, args.steps, drain=pipe.drain) / args.steps
         dgr.set_grad_sinks(None)
+        # an optimizer step that covers ALL 8 views of C4: every rank renders its 8 / N views with two in flight
+        # (multi_view.ViewPipeline, gradients summed in the per-Gaussian backward straight into the flat bucket) and the dense
+        # bucket crosses the ranks once per step (view_parallel.MultiViewStepExchange)
+        two_views = None
+        if n_views % world == 0 and n_views // world >= 2:
+            from multi_view import ViewPipeline
+            from view_parallel import MultiViewStepExchange
+            for p_ in pc.parameters():
+                p_.grad = None
+            mine = [cams[v] for v in range(n_views) if v % world == rank]
+            mv = MultiViewStepExchange(pc, n_views)
+            vp_ = ViewPipeline(dev, n_streams=2)
+            bwd_ = lambda i, pkg: pkg["render"].backward(dL)
+
+            def step_multi(k):
+                mv.step(vp_, mine, PIPE, bg, bwd_, **settings)
+            step_multi(0)
+            tm_ = timed_region(step_multi, args.steps) / args.steps
+            two_views = {"views_per_rank_per_step": len(mine), "ms_per_optimizer_step": round(1e3 * tm_, 4),
+                         "fwd_bwd_ms_per_view": round(1e3 * tm_ / len(mine), 4),
+                         "value": round(n_views * (W * H / 1e6) / tm_, 3), "unit": "Mpixels/s",
+                         "what": "one optimizer step over all 8 C4 views: each rank renders its 8 / N views through the two-lane "
+                                 "pipeline into one flat bucket, ONE dense all-reduce per step"}
+            for p_ in pc.parameters():
+                p_.grad = None
+            del mv, vp_
         mp = world * (W * H / 1e6)
         dense_bytes = 4 * sum(p_.numel() for p_ in pc.parameters())
         extra = {"headline_exchange": exchange_used,
@@ -608,6 +754,9 @@ def main():
 
     if world > 1:
         result["config"]["exchange"] = exchange_used
+        # which communicator carried the exchange: "nccl" IS RCCL on ROCm; rccl_ranks = its world size (None on the gloo rehearsal)
+        result["config"]["backend"] = dist.get_backend()
+        result["config"]["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else None
     if rank == 0:
         # ---- roofline of the dominant kernel (per launch, averaged over the timed steps) ----
         stats = None
@@ -733,11 +882,13 @@ def main():
                     "whole_step": whole, "per_kernel": per_kernel}
         result["roofline"] = roof
         result["median_of_50"] = median50
+        result["default_host_settings"] = default_host
         result["kernel_ms"] = kernels
         result["kernel_timing"] = (None if not timers else
                                    f"HIP events recorded by the library on {len(timers)} of the {args.steps} timed steps")
         if extra is not None:
             result["exchange"] = extra
+            result["two_views_per_rank"] = two_views
         # the reference's own measurement: render time per resolution scale (train.py:488-496,541; viewer.py:67-81)
         if world == 1 and (P, W, H) == (1_000_000, 1920, 1080) and not args.no_pyramid:
             try:
@@ -768,6 +919,13 @@ def main():
                                         "unit": "Mpixels/s", "entry": "GaussianRasterizer.forward_raw"}
             except Exception as e:
                 result["fused_path"] = {"error": repr(e)}
+            # informational: the same workload with TWO views in flight (host/multi_view.py; review item 1).  Eight copies of the
+            # C3 view per sweep, so a view is the same work as a headline step; `value` above stays one view per step.
+            try:
+                result["two_view_pipeline"] = two_view_timing(pc, cam, bg, dL, settings, W, H, args.warmup,
+                                                              (result.get("roofline") or {}).get("whole_step"))
+            except Exception as e:
+                result["two_view_pipeline"] = {"error": repr(e)}
             # informational: one whole training iteration (train.py:202-218,239-250,416-418) on the same workload —
             # render_fused + fused L1/SSIM loss + backward + statistics + FusedAdam, vs the same iteration with the
             # reference's torch composition around this rasterizer (torch loss formulation, torch.optim.Adam, masked-

@@ -582,11 +582,24 @@ class GradAccumulator:
     different streams: each backward waits for the previous one's kernel through an event.  finish() hands the bucket to
     the parameters' .grad (call it on the stream that will consume the gradients)."""
 
-    def __init__(self, leaves):
+    def __init__(self, leaves, dest=None):
+        """dest: optional destination tensors, one per leaf (e.g. the slices of a flat exchange bucket): used for every
+        step instead of fresh allocations; float32, contiguous, 16-byte aligned, the leaf's numel."""
         self.leaves = list(leaves)
         for t in self.leaves:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
                 raise ValueError("GradAccumulator: leaves must be contiguous float32 tensors on a HIP device")
+        self.fixed = None
+        if dest is not None:
+            dest = list(dest)
+            if len(dest) != len(self.leaves):
+                raise ValueError("GradAccumulator: one destination per leaf")
+            for t, d in zip(self.leaves, dest):
+                if d.dtype != torch.float32 or not d.is_contiguous() or d.numel() != t.numel() or d.device != t.device \
+                        or d.data_ptr() % 16:
+                    raise ValueError("GradAccumulator: a destination must be a contiguous, 16-byte aligned float32 tensor "
+                                     "with its leaf's numel on the leaf's device")
+            self.fixed = [d.view(t.shape) for t, d in zip(self.leaves, dest)]
         self.dest = None
         self.count = 0
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
@@ -596,8 +609,8 @@ class GradAccumulator:
         self.lock = threading.Lock()
 
     def begin_step(self):
-        """fresh (uninitialised) tensors: the first backward of the step writes every row"""
-        self.dest = [torch.empty_like(t) for t in self.leaves]
+        """fresh (uninitialised) tensors — or the caller's destinations: the first backward of the step writes every row"""
+        self.dest = self.fixed if self.fixed is not None else [torch.empty_like(t) for t in self.leaves]
         self.count = 0
         self.last = None
 
@@ -625,7 +638,7 @@ class GradAccumulator:
         if self.last is not None:
             torch.cuda.current_stream(self.leaves[0].device).wait_event(self.last)
         for t, d in zip(self.leaves, self.dest):
-            if t.grad is None:
+            if t.grad is None or t.grad.data_ptr() == d.data_ptr():
                 t.grad = d
             else:
                 t.grad += d

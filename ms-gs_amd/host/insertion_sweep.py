@@ -30,16 +30,34 @@ def view_visibility(cam, pc, pipe, bg_color, scaling_modifier=1.0, filter_small=
 
 @torch.no_grad()
 def select_insertion_sources(base_cams, next_cams, pc, pipe, bg_color, base_reso_idx=0, pixel_size_threshold=1.0,
-                             **filters):
+                             lanes=None, **filters):
     """Which base-level Gaussians become too small at the next resolution (train.py:283-315): the minimum over the
     cameras of the next-resolution pixel size, restricted to Gaussians the same camera sees at the base resolution;
-    selected = min < threshold and target_reso_lvl == base_reso_idx."""
+    selected = min < threshold and target_reso_lvl == base_reso_idx.
+    lanes: an optional multi_view.ViewPipeline — the two per-Gaussian launches of a camera pair (base and next resolution)
+    then run on its two streams side by side; the running minimum is folded on the caller's stream in camera order, so the
+    result is the same bits."""
     act = (pc.get_opacity, pc.get_scaling, pc.get_rotation)
     min_ps = torch.full_like(pc.get_min_pixel_sizes, float(pixel_size_threshold))
-    for cb, cn in zip(base_cams, next_cams):
-        base_vis, _, _ = view_visibility(cb, pc, pipe, bg_color, activated=act, **filters)
-        _, ps, _ = view_visibility(cn, pc, pipe, bg_color, activated=act, **filters)
-        min_ps = torch.where((ps > 0) & base_vis, torch.minimum(ps, min_ps), min_ps)
+    if lanes is None or len(lanes.streams) < 2:
+        for cb, cn in zip(base_cams, next_cams):
+            base_vis, _, _ = view_visibility(cb, pc, pipe, bg_color, activated=act, **filters)
+            _, ps, _ = view_visibility(cn, pc, pipe, bg_color, activated=act, **filters)
+            min_ps = torch.where((ps > 0) & base_vis, torch.minimum(ps, min_ps), min_ps)
+    else:
+        s0, s1 = lanes.streams[0], lanes.streams[1]
+        cur = lanes._fork()
+        for cb, cn in zip(base_cams, next_cams):
+            with torch.cuda.stream(s0):
+                base_vis, _, _ = view_visibility(cb, pc, pipe, bg_color, activated=act, **filters)
+            with torch.cuda.stream(s1):
+                _, ps, _ = view_visibility(cn, pc, pipe, bg_color, activated=act, **filters)
+            cur.wait_stream(s0)
+            cur.wait_stream(s1)
+            base_vis.record_stream(cur)
+            ps.record_stream(cur)
+            min_ps = torch.where((ps > 0) & base_vis, torch.minimum(ps, min_ps), min_ps)
+        lanes._join(cur)
     selected = (min_ps < pixel_size_threshold) & (pc.target_reso_lvl == base_reso_idx)
     return selected, min_ps
 

@@ -146,14 +146,15 @@ class ViewPipeline:
 
     # -- forward + backward ----------------------------------------------------------------------------------------
     def train_views(self, cams, pc, pipe, bg_color, backward_fn, render_fn=_render, share_getters=True,
-                    accumulate_in_kernel=True, **settings):
+                    accumulate_in_kernel=True, accumulator=None, **settings):
         """render() + backward of every view of one optimizer step; gradients accumulate into the parameters' .grad.
 
         accumulate_in_kernel: the views' leaf gradients are summed inside the per-Gaussian backward kernel into one bucket
         (diff_gaussian_rasterization.GradAccumulator) that becomes .grad at the end, instead of autograd's
         `param.grad += g` passes after every view (same order of additions, same bits); it applies to the calls the op
         recognises as the reference's getters or that use the raw-parameter entry — any other call is accumulated by
-        autograd as usual.
+        autograd as usual.  accumulator: a caller-owned GradAccumulator (e.g. over the slices of a flat exchange bucket,
+        view_parallel.MultiViewStepExchange) used instead of a fresh one, also for a single view.
 
         backward_fn(i, pkg) is called in view i's stream context once the view is resolved and must run the view's
         backward (e.g. `loss_of(pkg["render"], gt[i]).backward()` or `pkg["render"].backward(dL[i])`); its return value
@@ -163,8 +164,8 @@ class ViewPipeline:
         ns = len(self.streams)
         model = self._model(pc, share_getters)
         acc = prev_acc = None
-        if accumulate_in_kernel and n > 1:
-            acc = dgr.GradAccumulator([getattr(pc, name) for name in LEAF_NAMES])
+        if accumulator is not None or (accumulate_in_kernel and n > 1):
+            acc = accumulator if accumulator is not None else dgr.GradAccumulator([getattr(pc, name) for name in LEAF_NAMES])
             acc.begin_step()                      # allocated on the caller's stream, ahead of the fork
             prev_acc = dgr.set_grad_accumulator(acc)
         cur = self._fork()

@@ -144,6 +144,48 @@ class PipelinedGradExchange:
             self._finish(i)
 
 
+class MultiViewStepExchange:
+    """Gradient exchange for an optimizer step that covers k >= 2 views PER RANK (BASELINE config C4 on fewer than 8 GPUs:
+    8 / N views per GPU and step).  The rank renders its views through multi_view.ViewPipeline — two in flight, their
+    gradients summed inside the per-Gaussian backward kernel straight into the slices of ONE flat bucket
+    (diff_gaussian_rasterization.GradAccumulator over FlatGradBucket's views: no per-view zero-fill, no `grad += g` passes) —
+    and the bucket crosses the ranks ONCE per step: the dense 59-floats-per-Gaussian all-reduce is paid per step, not per
+    view, i.e. 1 / k of FlatGradBucket.all_reduce after every view.
+
+        ex = MultiViewStepExchange(model, total_views)
+        ex.step(pipeline, cams_of_this_rank, pipe, bg, backward_fn, **render_settings)   # then optimizer.step()
+
+    `model` carries the reference's leaf names (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation)."""
+
+    LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+    def __init__(self, model, total_views, group=None, make_accumulator=None):
+        """make_accumulator(leaves, dest): injection point for the CPU (gloo) tests of the exchange logic; the default is
+        diff_gaussian_rasterization.GradAccumulator (HIP, no CPU fallback)"""
+        self.model = model
+        self.group = group
+        self.total_views = int(total_views)
+        leaves = [getattr(model, n) for n in self.LEAVES]
+        self.bucket = FlatGradBucket(leaves)
+        self.bucket.detach_grads()
+        if make_accumulator is None:
+            import diff_gaussian_rasterization as dgr
+            make_accumulator = dgr.GradAccumulator
+        self.acc = make_accumulator(leaves, dest=self.bucket.views)
+
+    def step(self, pipeline, cams, pipe, bg_color, backward_fn, **kw):
+        """all views of this rank (forward + backward, gradients into the bucket), then one all-reduce; afterwards every
+        leaf's .grad is the bucket slice holding the gradient averaged over `total_views`"""
+        self.bucket.detach_grads()
+        out = pipeline.train_views(cams, self.model, pipe, bg_color, backward_fn, accumulator=self.acc, **kw)
+        for p_, v in zip(self.bucket.params, self.bucket.views):
+            if p_.grad is None or p_.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("MultiViewStepExchange: a gradient did not land in the bucket (the rasterizer was not called "
+                                   "through its raw / chained entry)")
+        self.bucket.all_reduce(group=self.group, average_over=self.total_views)
+        return out
+
+
 class FactoredGradExchange:
     """Gradient exchange for ONE view per GPU per optimizer step (BASELINE config C4: 8 views over 8 GPUs), where
     nothing can hide a dense 59-floats-per-Gaussian all-reduce (every gradient is final only after the last backward

@@ -51,3 +51,15 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_a_dead_rank_takes_the_others_down_quickly():
+    """rank 1 exits before the rendezvous: the launcher must stop rank 0 (which would otherwise wait for the
+    process-group timeout) and return the failing status"""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(MSGS_BENCH_FAIL_RANK="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert "the other ranks were stopped" in r.stderr
+    assert time.time() - t0 < 120

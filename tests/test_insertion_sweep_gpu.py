@@ -68,6 +68,10 @@ def test_insertion_sweep_matches_the_render_based_sequence():
     ref_sel = torch.logical_and(ref_min < 1, ref.target_reso_lvl == 0)
     assert torch.equal(min_ps, ref_min) and torch.equal(sel, ref_sel)
     assert 0 < sel.sum().item() < sel.numel()
+    # the same sweep with the base / next launches of every camera pair on two streams
+    from multi_view import ViewPipeline
+    sel2, min_ps2 = select_insertion_sources(base, nxt, pc, PIPE, bg, lanes=ViewPipeline("cuda"), **ST)
+    assert torch.equal(min_ps2, ref_min) and torch.equal(sel2, ref_sel)
 
     refresh_pixel_sizes(nxt, pc, 2, PIPE, bg, **ST)
     with torch.no_grad():                                          # train.py:334-338 with full renders

@@ -151,3 +151,25 @@ def test_deferred_block_resolves_on_exit_and_survives_an_exception():
         with dgr.deferred_forward() as pending:
             e = render(cams[0], pc, PIPE, bg, **ST)
         assert pending[0].resolve()[3] == 0 and int((e["radii"] > 0).sum()) == 0
+
+
+def test_multi_view_step_exchange_on_one_rank_equals_the_serial_mean():
+    """view_parallel.MultiViewStepExchange without a process group: all views of the step through the pipeline into the flat
+    bucket, averaged over the views — equal to the serial loop's accumulated gradients / views (same additions, one division)"""
+    from multi_view import ViewPipeline
+    from synthetic_model import SyntheticGaussians
+    from view_parallel import MultiViewStepExchange
+    sc, cams, dLs = _ball(n_views=4)
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    ref_pc, _, ref_m2 = _serial_train(sc, cams, dLs, bg)
+    pc = SyntheticGaussians(sc, "cuda")
+    ex = MultiViewStepExchange(pc, len(cams))
+    pipe = ViewPipeline("cuda")
+    for _ in range(2):                                    # two optimizer steps reuse the bucket
+        vs = ex.step(pipe, cams, PIPE, bg, lambda i, pkg: (pkg["render"].backward(dLs[i]), pkg["viewspace_points"])[1], **ST)
+        torch.cuda.synchronize()
+        for n, v in zip(LEAVES, ex.bucket.views):
+            assert getattr(pc, n).grad.data_ptr() == v.data_ptr(), n
+            assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad / len(cams)), n
+        for i in range(len(cams)):
+            assert torch.equal(vs[i].grad, ref_m2[i])

@@ -297,3 +297,73 @@ def test_visible_rows_exchange_equals_dense(world):
     ret = mgr.dict()
     mp.spawn(_visible_rows_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ---- an optimizer step covering several views per rank: MultiViewStepExchange (one all-reduce per step) ----
+def _multi_view_worker(rank, world, port, ret):
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ms-gs_amd", "host")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from view_parallel import MultiViewStepExchange, views_for_rank
+    torch.manual_seed(0)
+    P = 131
+    shapes = dict(_xyz=(P, 3), _features_dc=(P, 1, 3), _features_rest=(P, 15, 3), _opacity=(P, 1), _scaling=(P, 3),
+                  _rotation=(P, 4))
+    model = types.SimpleNamespace(**{n: torch.nn.Parameter(torch.randn(*s)) for n, s in shapes.items()})
+
+    class FakeAccumulator:                       # stands in for the HIP GradAccumulator: same contract, CPU tensors
+        def __init__(self, leaves, dest):
+            self.leaves, self.dest, self.count = list(leaves), [d.view(t.shape) for t, d in zip(leaves, dest)], 0
+
+        def begin_step(self):
+            self.count = 0
+
+        def add(self, grads):                    # first view of the step stores, later views accumulate (msgs_grads_t)
+            for d, g in zip(self.dest, grads):
+                if self.count == 0:
+                    d.copy_(g)
+                else:
+                    d.add_(g)
+            self.count += 1
+
+        def finish(self):
+            for t, d in zip(self.leaves, self.dest):
+                t.grad = d
+
+    class FakePipeline:                          # stands in for multi_view.ViewPipeline.train_views
+        def train_views(self, cams, pc, pipe, bg, backward_fn, accumulator=None, **kw):
+            accumulator.begin_step()
+            out = [backward_fn(i, dict(cam=c, acc=accumulator)) for i, c in enumerate(cams)]
+            accumulator.finish()
+            return out
+
+    ex = MultiViewStepExchange(model, 8, make_accumulator=FakeAccumulator)
+    mine = views_for_rank(8, rank, world)
+    leaves = [getattr(model, n) for n in MultiViewStepExchange.LEAVES]
+
+    def backward_fn(i, pkg):                     # view v contributes (v + 1) * (k + 1) to every element of leaf k
+        pkg["acc"].add([torch.full_like(t, (pkg["cam"] + 1.0) * (k + 1)) for k, t in enumerate(leaves)])
+        return pkg["cam"]
+    ok = True
+    for _ in range(2):                           # two optimizer steps: the bucket is reused
+        seen = ex.step(FakePipeline(), mine, None, None, backward_fn)
+        want = sum(v + 1.0 for v in range(8)) / 8.0
+        ok = ok and seen == mine
+        ok = ok and all(torch.allclose(t.grad, torch.full_like(t, want * (k + 1))) for k, t in enumerate(leaves))
+        ok = ok and all(t.grad.data_ptr() == v.data_ptr() for t, v in zip(leaves, ex.bucket.views))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_view_step_exchange(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_multi_view_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
