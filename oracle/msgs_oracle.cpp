@@ -39,32 +39,52 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <parallel/algorithm>
 #include <omp.h>
 
+// Precision of the arithmetic.  Default: float32 — THE checker of the parity tests (liboracle.so).  -DMSGS_ORACLE_F64 builds
+// the SAME source with every computed quantity in double (liboracle64.so): the float64 "truth" of the three-way tests
+// (HIP vs float32 oracle vs truth) at the full BASELINE sizes, where the autograd oracle (torch_oracle.py) takes minutes to
+// hours; tests/test_oracle_cpu.py checks it against that autograd oracle.  In both builds the op's INPUTS are the float32
+// arrays the HIP library receives (in_t), the tile lists are ordered by the FLOAT32 view depth (Q10), and the outputs /
+// gradients are written in `real` (the float64 build is called with double buffers through the same C signatures).
+#ifdef MSGS_ORACLE_F64
+typedef double real;
+#define RL(x) x
+#else
+typedef float real;
+#define RL(x) x##f
+#endif
+typedef float in_t;
+
 namespace {
 
 constexpr int TILE = MSGS_TILE;
-constexpr float SH_C0 = 0.28209479177387814f;
-constexpr float SH_C1 = 0.4886025119029199f;
-constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                            -1.0925484305920792f, 0.5462742152960396f};
-constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
-                            -0.5900435899266435f};
+constexpr real SH_C0 = RL(0.28209479177387814);
+constexpr real SH_C1 = RL(0.4886025119029199);
+constexpr real SH_C2[5] = {RL(1.0925484305920792), RL(-1.0925484305920792), RL(0.31539156525252005),
+                           RL(-1.0925484305920792), RL(0.5462742152960396)};
+constexpr real SH_C3[7] = {RL(-0.5900435899266435), RL(2.890611442640554), RL(-0.4570457994644658),
+                           RL(0.3731763325901154), RL(-0.4570457994644658), RL(1.445305721320277),
+                           RL(-0.5900435899266435)};
 
 struct Geom {
-    float depth, px, py;
-    float con[3], opacity;   // conic (A,B,C), effective opacity (after the fade weight)
-    float rgb[3];
-    float cov3D[6];
-    float pixel_size, weight;
+    float depth32;           // float32 view depth: the sort key (Q10) in both builds
+    real depth, px, py;
+    real con[3], opacity;   // conic (A,B,C), effective opacity (after the fade weight)
+    real rgb[3];
+    real cov3D[6];
+    real pixel_size, weight;
     int32_t radius;
     int32_t rect[4];         // minx, miny, maxx, maxy (tiles)
     uint8_t clamped[3];
     uint8_t visible;
+    uint8_t ghost;           // dropped by a multi-scale filter whose decision was within rounding of flipping: kept in the
+                             // tile lists WITHOUT blending, only to flag the pixels it would have reached
+    uint8_t filter_edge;     // pixel size within FILTER_EDGE (relative) of an active min / max threshold (fade_size == 0)
 };
 
 }  // namespace
@@ -74,12 +94,15 @@ struct msgs_oracle_state {
     std::vector<Geom> geom;
     std::vector<uint32_t> list;           // sorted Gaussian ids
     std::vector<uint32_t> range_lo, range_hi;
-    std::vector<float> final_T;
+    std::vector<real> final_T;
     std::vector<uint32_t> n_contrib;
     // flat copies for introspection
-    std::vector<float> depths, conic_opacity, rgb, means2D, cov3D;
+    std::vector<real> depths, conic_opacity, rgb, means2D, cov3D;
     std::vector<int32_t> rects;
-    std::vector<uint8_t> borderline_gauss;  // Gaussian had an alpha within rounding distance of 1/255 on some pixel
+    std::vector<uint8_t> borderline_gauss;  // Gaussian had an alpha within rounding distance of 1/255 on some pixel, or
+                                            // shares a pixel with a Gaussian whose filter decision could flip
+    std::vector<uint8_t> filter_edge;       // Gaussian's own filter decision is within rounding of flipping
+    int64_t ghost_instances = 0;
     int64_t traversed = 0;
     int64_t valid_pairs = 0;      // (pixel, Gaussian) evaluations with alpha >= 1/255 before the pixel terminated
     int64_t evaluated_pairs = 0;  // all evaluations of the reference algorithm (sum over pixels of n_contrib-ish)
@@ -90,19 +113,19 @@ namespace {
 inline uint32_t float_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 /* SH -> RGB (utils/sh_utils.py:74-100; +0.5 and clamp as gaussian_renderer/__init__.py:86-87) */
-inline void sh_to_rgb(int deg, int K, const float* sh, const float* p, const float* campos,
-                      float* rgb, uint8_t* clamped) {
-    float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
-    float len = std::sqrt(dx * dx + dy * dy + dz * dz);
-    float x = dx / len, y = dy / len, z = dz / len;
+inline void sh_to_rgb(int deg, int K, const in_t* sh, const in_t* p, const in_t* campos,
+                      real* rgb, uint8_t* clamped) {
+    real dx = (real)p[0] - (real)campos[0], dy = (real)p[1] - (real)campos[1], dz = (real)p[2] - (real)campos[2];
+    real len = std::sqrt(dx * dx + dy * dy + dz * dz);
+    real x = dx / len, y = dy / len, z = dz / len;
     (void)K;
     for (int c = 0; c < 3; ++c) {
-        auto S = [&](int k) { return sh[k * 3 + c]; };
-        float r = SH_C0 * S(0);
+        auto S = [&](int k) { return (real)sh[k * 3 + c]; };
+        real r = SH_C0 * S(0);
         if (deg > 0) {
             r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
             if (deg > 1) {
-                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                 r = r + SH_C2[0] * xy * S(4) + SH_C2[1] * yz * S(5) +
                     SH_C2[2] * (2.0f * zz - xx - yy) * S(6) + SH_C2[3] * xz * S(7) +
                     SH_C2[4] * (xx - yy) * S(8);
@@ -122,13 +145,13 @@ inline void sh_to_rgb(int deg, int K, const float* sh, const float* p, const flo
 }
 
 /* Sigma = R diag(mod s)^2 R^T, R(q) as utils/general_utils.py:85-98 (no normalisation) */
-inline void cov3d_from_scale_rot(const float* s, float mod, const float* q, float* cov) {
-    float r = q[0], x = q[1], y = q[2], z = q[3];
-    float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+inline void cov3d_from_scale_rot(const in_t* s, real mod, const in_t* q, real* cov) {
+    real r = q[0], x = q[1], y = q[2], z = q[3];
+    real R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                      {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                      {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-    float S[3] = {mod * s[0], mod * s[1], mod * s[2]};
-    float M[3][3];
+    real S[3] = {mod * s[0], mod * s[1], mod * s[2]};
+    real M[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) M[i][j] = R[i][j] * S[j];
     auto dot = [&](int i, int j) { return M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2]; };
@@ -137,73 +160,88 @@ inline void cov3d_from_scale_rot(const float* s, float mod, const float* q, floa
 }
 
 struct Cov2DCtx {
-    float T[2][3];       // J * Wr
-    float a, b, c;       // with the +0.3
-    float tx_c, ty_c, tz;
-    float x_mul, y_mul;
-    float fx, fy;
+    real T[2][3];       // J * Wr
+    real a, b, c;       // with the +0.3
+    real tx_c, ty_c, tz;
+    real x_mul, y_mul;
+    real fx, fy;
 };
 
-inline void compute_cov2d(const float* t, float fx, float fy, float tanx, float tany,
-                          const float* cov3D, const float* V, Cov2DCtx& o) {
-    float limx = 1.3f * tanx, limy = 1.3f * tany;
-    float txtz = t[0] / t[2], tytz = t[1] / t[2];
+inline void compute_cov2d(const real* t, real fx, real fy, real tanx, real tany,
+                          const real* cov3D, const in_t* V, Cov2DCtx& o) {
+    real limx = RL(1.3) * tanx, limy = RL(1.3) * tany;
+    real txtz = t[0] / t[2], tytz = t[1] / t[2];
     o.x_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
     o.y_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
     o.tx_c = std::min(limx, std::max(-limx, txtz)) * t[2];
     o.ty_c = std::min(limy, std::max(-limy, tytz)) * t[2];
     o.tz = t[2];
     o.fx = fx; o.fy = fy;
-    float J[2][3] = {{fx / t[2], 0.f, -(fx * o.tx_c) / (t[2] * t[2])},
+    real J[2][3] = {{fx / t[2], 0.f, -(fx * o.tx_c) / (t[2] * t[2])},
                      {0.f, fy / t[2], -(fy * o.ty_c) / (t[2] * t[2])}};
     // Wr[k][c] = W2C rotation (row k, col c) = V[4*c + k]
     for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 3; ++c)
-            o.T[r][c] = J[r][0] * V[4 * c + 0] + J[r][1] * V[4 * c + 1] + J[r][2] * V[4 * c + 2];
-    float S[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]},
+            o.T[r][c] = J[r][0] * (real)V[4 * c + 0] + J[r][1] * (real)V[4 * c + 1] + J[r][2] * (real)V[4 * c + 2];
+    real S[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]},
                      {cov3D[2], cov3D[4], cov3D[5]}};
-    float ST[2][3];   // ST[r][i] = sum_j S[i][j] T[r][j]
+    real ST[2][3];   // ST[r][i] = sum_j S[i][j] T[r][j]
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < 3; ++i) ST[r][i] = S[i][0] * o.T[r][0] + S[i][1] * o.T[r][1] + S[i][2] * o.T[r][2];
-    o.a = (o.T[0][0] * ST[0][0] + o.T[0][1] * ST[0][1] + o.T[0][2] * ST[0][2]) + 0.3f;
+    o.a = (o.T[0][0] * ST[0][0] + o.T[0][1] * ST[0][1] + o.T[0][2] * ST[0][2]) + RL(0.3);
     o.b = o.T[0][0] * ST[1][0] + o.T[0][1] * ST[1][1] + o.T[0][2] * ST[1][2];
-    o.c = (o.T[1][0] * ST[1][0] + o.T[1][1] * ST[1][1] + o.T[1][2] * ST[1][2]) + 0.3f;
+    o.c = (o.T[1][0] * ST[1][0] + o.T[1][1] * ST[1][1] + o.T[1][2] * ST[1][2]) + RL(0.3);
 }
 
-inline void view_point(const float* V, const float* p, float* t) {
-    t[0] = ((V[0] * p[0] + V[4] * p[1]) + V[8] * p[2]) + V[12];
-    t[1] = ((V[1] * p[0] + V[5] * p[1]) + V[9] * p[2]) + V[13];
-    t[2] = ((V[2] * p[0] + V[6] * p[1]) + V[10] * p[2]) + V[14];
+inline void view_point(const in_t* V, const in_t* p, real* t) {
+    const real x = p[0], y = p[1], z = p[2];
+    t[0] = (((real)V[0] * x + (real)V[4] * y) + (real)V[8] * z) + (real)V[12];
+    t[1] = (((real)V[1] * x + (real)V[5] * y) + (real)V[9] * z) + (real)V[13];
+    t[2] = (((real)V[2] * x + (real)V[6] * y) + (real)V[10] * z) + (real)V[14];
 }
 
-inline void proj_point(const float* M, const float* p, float* h) {
-    for (int k = 0; k < 4; ++k) h[k] = ((M[k] * p[0] + M[4 + k] * p[1]) + M[8 + k] * p[2]) + M[12 + k];
+inline void proj_point(const in_t* M, const in_t* p, real* h) {
+    const real x = p[0], y = p[1], z = p[2];
+    for (int k = 0; k < 4; ++k) h[k] = (((real)M[k] * x + (real)M[4 + k] * y) + (real)M[8 + k] * z) + (real)M[12 + k];
 }
 
 /* MS-GS pixel size (DESIGN.md SPEC M1): extent, through the centre and along the image axes, of
  * the alpha >= 1/255 level set of the low-passed 2-D Gaussian; the smaller of the two. */
-inline float pixel_size_of(float opacity, float conA, float conC) {
-    float v = 255.0f * opacity;
+inline real pixel_size_of(real opacity, real conA, real conC) {
+    real v = 255.0f * opacity;
     if (!(v > 1.0f) || !(conA > 0.f) || !(conC > 0.f)) return 0.f;
-    float ell = 2.0f * std::log(v);
-    float sx = 2.0f * std::sqrt(ell / conA);
-    float sy = 2.0f * std::sqrt(ell / conC);
+    real ell = 2.0f * std::log(v);
+    real sx = 2.0f * std::sqrt(ell / conA);
+    real sy = 2.0f * std::sqrt(ell / conC);
     return std::min(sx, sy);
 }
 
+/* The hard filters (fade_size == 0) compare the pixel size with a threshold: two float32 implementations whose sizes differ
+ * by the last bits of logf / sqrtf take different decisions when size / threshold is within FILTER_EDGE of 1 (the HIP kernel
+ * and this file agree to 1e-4 relative on pixel_sizes).  Such a Gaussian is flagged, and — rendered or not — stays in the
+ * tile lists so that every pixel it reaches (and every Gaussian blended there) is flagged too. */
+constexpr double FILTER_EDGE = 1e-4;
+inline bool filter_on_edge(const msgs_view_t* v, real size, real minps, real maxps, bool base) {
+    if (v->fade_size > 0.f) return false;                 // a ramp: continuous in the size
+    bool edge = false;
+    if (v->filter_small && !base && minps > 0.f) edge |= std::fabs((double)size / (double)minps - 1.0) < FILTER_EDGE;
+    if (v->filter_large && maxps > 0.f) edge |= std::fabs((double)size / (double)maxps - 1.0) < FILTER_EDGE;
+    return edge;
+}
+
 /* MS-GS filter weight (DESIGN.md SPEC M2-M4) */
-inline float filter_weight(const msgs_view_t* v, float size, float minps, float maxps, bool base) {
-    float w = 1.0f;
+inline real filter_weight(const msgs_view_t* v, real size, real minps, real maxps, bool base) {
+    real w = 1.0f;
     if (v->filter_small && !base && minps > 0.f && size < minps) {
         if (v->fade_size > 0.f) {
-            float rel = minps / std::max(size, 1e-30f);
-            w *= std::min(1.f, std::max(0.f, 1.f - (rel - 1.f) / v->fade_size));
+            real rel = minps / std::max<real>(size, RL(1e-30));
+            w *= std::min<real>(1.f, std::max<real>(0.f, 1.f - (rel - 1.f) / (real)v->fade_size));
         } else w = 0.f;
     }
     if (v->filter_large && maxps > 0.f && size > maxps) {
         if (v->fade_size > 0.f) {
-            float rel = size / maxps;
-            w *= std::min(1.f, std::max(0.f, 1.f - (rel - 1.f) / v->fade_size));
+            real rel = size / maxps;
+            w *= std::min<real>(1.f, std::max<real>(0.f, 1.f - (rel - 1.f) / (real)v->fade_size));
         } else w = 0.f;
     }
     return w;
@@ -212,9 +250,14 @@ inline float filter_weight(const msgs_view_t* v, float size, float minps, float 
 }  // namespace
 
 extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians_t* g,
-                                   float* out_color, float* out_acc_ps, float* out_depth,
-                                   int32_t* radii, float* pixel_sizes, uint8_t* borderline,
+                                   float* out_color_, float* out_acc_ps_, float* out_depth_,
+                                   int32_t* radii, float* pixel_sizes_, uint8_t* borderline,
                                    msgs_oracle_state_t** state_out, int num_threads) {
+    // (float64 build: the caller passes DOUBLE buffers through the float* parameters of the shared header)
+    real* out_color = reinterpret_cast<real*>(out_color_);
+    real* out_acc_ps = reinterpret_cast<real*>(out_acc_ps_);
+    real* out_depth = reinterpret_cast<real*>(out_depth_);
+    real* pixel_sizes = reinterpret_cast<real*>(pixel_sizes_);
     if (!view || !g) return MSGS_ERR_INVALID_ARG;
     if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return MSGS_ERR_INVALID_ARG;
     bool has_sr = g->scales != nullptr && g->rotations != nullptr;
@@ -228,41 +271,43 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     auto* st = new msgs_oracle_state();
     st->P = P; st->W = W; st->H = H; st->gx = gx; st->gy = gy;
     st->geom.assign(P, Geom{});
-    const float fx = W / (2.0f * view->tanfovx), fy = H / (2.0f * view->tanfovy);
-    const float* V = view->viewmatrix;
-    const float* PM = view->projmatrix;
+    const real fx = W / (2.0f * (real)view->tanfovx), fy = H / (2.0f * (real)view->tanfovy);
+    const in_t* V = view->viewmatrix;
+    const in_t* PM = view->projmatrix;
 
     // ---- K1 preprocess (App. A.1) ----
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; ++i) {
         Geom& ge = st->geom[i];
-        ge.visible = 0; ge.radius = 0; ge.pixel_size = 0.f;
+        ge.visible = 0; ge.ghost = 0; ge.filter_edge = 0; ge.radius = 0; ge.pixel_size = 0.f;
         radii[i] = 0; pixel_sizes[i] = 0.f;
-        const float* p = g->means3D + 3 * i;
-        float t[3];
+        const in_t* p = g->means3D + 3 * i;
+        real t[3];
         view_point(V, p, t);
         ge.depth = t[2];
-        if (t[2] <= 0.2f) continue;                                   // Q1
-        float h[4];
+        // Q10: the tile lists are ordered by the FLOAT32 view depth in both builds
+        ge.depth32 = ((V[2] * p[0] + V[6] * p[1]) + V[10] * p[2]) + V[14];
+        if (t[2] <= RL(0.2)) continue;                                   // Q1
+        real h[4];
         proj_point(PM, p, h);
-        float pw = 1.0f / (h[3] + 0.0000001f);                         // Q9
-        float ndc_x = h[0] * pw, ndc_y = h[1] * pw;
-        if (g->cov3D_precomp) std::memcpy(ge.cov3D, g->cov3D_precomp + 6 * i, 24);
+        real pw = 1.0f / (h[3] + RL(0.0000001));                         // Q9
+        real ndc_x = h[0] * pw, ndc_y = h[1] * pw;
+        if (g->cov3D_precomp) { for (int c = 0; c < 6; ++c) ge.cov3D[c] = g->cov3D_precomp[6 * i + c]; }
         else cov3d_from_scale_rot(g->scales + 3 * i, view->scale_modifier, g->rotations + 4 * i, ge.cov3D);
         Cov2DCtx c2;
         compute_cov2d(t, fx, fy, view->tanfovx, view->tanfovy, ge.cov3D, V, c2);
-        float det = c2.a * c2.c - c2.b * c2.b;
+        real det = c2.a * c2.c - c2.b * c2.b;
         if (det == 0.0f) continue;                                     // Q3
-        float det_inv = 1.f / det;
+        real det_inv = 1.f / det;
         ge.con[0] = c2.c * det_inv; ge.con[1] = -c2.b * det_inv; ge.con[2] = c2.a * det_inv;
-        float mid = 0.5f * (c2.a + c2.c);
-        float root = std::sqrt(std::max(0.1f, mid * mid - det));       // Q4
-        float lam1 = mid + root, lam2 = mid - root;
-        float my_radius = std::ceil(3.f * std::sqrt(std::max(lam1, lam2)));
+        real mid = 0.5f * (c2.a + c2.c);
+        real root = std::sqrt(std::max(RL(0.1), mid * mid - det));       // Q4
+        real lam1 = mid + root, lam2 = mid - root;
+        real my_radius = std::ceil(3.f * std::sqrt(std::max(lam1, lam2)));
         ge.px = ((ndc_x + 1.0f) * W - 1.0f) * 0.5f;
         ge.py = ((ndc_y + 1.0f) * H - 1.0f) * 0.5f;
         // MS-GS pixel size, written before any filtering (SPEC M1)
-        float o = g->opacities[i];
+        real o = g->opacities[i];
         ge.pixel_size = pixel_size_of(o, ge.con[0], ge.con[2]);
         pixel_sizes[i] = ge.pixel_size;
         ge.rect[0] = std::min(gx, std::max(0, (int)((ge.px - my_radius) / TILE)));
@@ -270,11 +315,16 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
         ge.rect[2] = std::min(gx, std::max(0, (int)((ge.px + my_radius + TILE - 1) / TILE)));
         ge.rect[3] = std::min(gy, std::max(0, (int)((ge.py + my_radius + TILE - 1) / TILE)));
         if ((ge.rect[2] - ge.rect[0]) * (ge.rect[3] - ge.rect[1]) == 0) continue;
-        float w = filter_weight(view, ge.pixel_size, g->min_pixel_sizes ? g->min_pixel_sizes[i] : -1.f,
-                                g->max_pixel_sizes ? g->max_pixel_sizes[i] : -1.f,
-                                g->base_mask ? g->base_mask[i] != 0 : false);
+        const real minps_i = g->min_pixel_sizes ? g->min_pixel_sizes[i] : -1.f;
+        const real maxps_i = g->max_pixel_sizes ? g->max_pixel_sizes[i] : -1.f;
+        const bool base_i = g->base_mask ? g->base_mask[i] != 0 : false;
+        real w = filter_weight(view, ge.pixel_size, minps_i, maxps_i, base_i);
+        ge.filter_edge = filter_on_edge(view, ge.pixel_size, minps_i, maxps_i, base_i) ? 1 : 0;
         ge.weight = w;
-        if (!(w > 0.f)) continue;                                      // SPEC M2/M3: dropped
+        if (!(w > 0.f)) {                                              // SPEC M2/M3: dropped
+            if (ge.filter_edge) { ge.ghost = 1; ge.opacity = o; }      // ... by a decision that could flip: listed, not blended
+            continue;
+        }
         ge.opacity = o * w;
         if (g->colors_precomp) {
             for (int c = 0; c < 3; ++c) { ge.rgb[c] = g->colors_precomp[3 * i + c]; ge.clamped[c] = 0; }
@@ -291,8 +341,9 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     std::vector<uint64_t> offs(P + 1, 0);
     for (int i = 0; i < P; ++i) {
         const Geom& ge = st->geom[i];
-        uint64_t n = ge.visible ? (uint64_t)(ge.rect[2] - ge.rect[0]) * (ge.rect[3] - ge.rect[1]) : 0;
+        uint64_t n = (ge.visible || ge.ghost) ? (uint64_t)(ge.rect[2] - ge.rect[0]) * (ge.rect[3] - ge.rect[1]) : 0;
         offs[i + 1] = offs[i] + n;
+        if (ge.ghost) st->ghost_instances += (int64_t)n;
     }
     const uint64_t D = offs[P];
     struct KV { uint64_t key; uint32_t val; };
@@ -300,12 +351,12 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int i = 0; i < P; ++i) {
         const Geom& ge = st->geom[i];
-        if (!ge.visible) continue;
+        if (!ge.visible && !ge.ghost) continue;
         uint64_t o = offs[i];
         for (int y = ge.rect[1]; y < ge.rect[3]; ++y)
             for (int x = ge.rect[0]; x < ge.rect[2]; ++x) {
                 uint64_t key = (uint64_t)(y * gx + x);
-                key = (key << 32) | float_bits(ge.depth);               // Q10
+                key = (key << 32) | float_bits(ge.depth32);               // Q10
                 kv[o++] = KV{key, (uint32_t)i};
             }
     }
@@ -325,7 +376,9 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     st->final_T.assign((size_t)W * H, 1.0f);
     st->n_contrib.assign((size_t)W * H, 0);
     st->borderline_gauss.assign(P, 0);
-    const float bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
+    st->filter_edge.assign(P, 0);
+    for (int i = 0; i < P; ++i) st->filter_edge[i] = st->geom[i].filter_edge;
+    const real bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
     int64_t traversed = 0, valid_pairs = 0, evaluated_pairs = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : traversed, valid_pairs, evaluated_pairs)
     for (int tile = 0; tile < gx * gy; ++tile) {
@@ -336,35 +389,55 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
             for (int lx = 0; lx < TILE; ++lx) {
                 const int x = tx * TILE + lx, y = ty * TILE + ly;
                 if (x >= W || y >= H) continue;
-                const float pxf = (float)x, pyf = (float)y;
-                float T = 1.0f, C[3] = {0, 0, 0}, aps = 0.f, adp = 0.f;
+                const real pxf = (real)x, pyf = (real)y;
+                real T = 1.0f, C[3] = {0, 0, 0}, aps = 0.f, adp = 0.f;
                 uint32_t contributor = 0, last = 0;
-                bool flag = false;
+                bool flag = false, taint = false;
+                uint32_t k_end = lo;
                 for (uint32_t k = lo; k < hi; ++k) {
+                    k_end = k + 1;
                     ++contributor;
-                    ++evaluated_pairs;
                     const Geom& ge = st->geom[st->list[k]];
-                    float dx = ge.px - pxf, dy = ge.py - pyf;
-                    float power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
+                    if (!ge.ghost) ++evaluated_pairs;
+                    real dx = ge.px - pxf, dy = ge.py - pyf;
+                    real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                     if (power > 0.0f) continue;
-                    float alpha = std::min(0.99f, ge.opacity * std::exp(power));        // Q6
-                    if (std::fabs(alpha * 255.0f - 1.0f) < 2e-5f) {
+                    real alpha = std::min(RL(0.99), ge.opacity * std::exp(power));        // Q6
+                    // a Gaussian whose filter decision could flip reaches this pixel: the pixel, and every Gaussian
+                    // blended here, depends on that decision
+                    if (ge.filter_edge && alpha * 255.0f >= 1.0f - RL(2e-5)) taint = true;
+                    if (ge.ghost) continue;
+                    if (std::fabs(alpha * 255.0f - 1.0f) < RL(2e-5)) {
                         flag = true;
                         uint8_t* bg_flag = &st->borderline_gauss[st->list[k]];
 #pragma omp atomic write
                         *bg_flag = 1;
                     }
-                    if (alpha < 1.0f / 255.0f) continue;                                 // Q7
+                    if (alpha < RL(1.0) / RL(255.0)) continue;                                 // Q7
                     ++valid_pairs;
-                    float test_T = T * (1 - alpha);
-                    if (std::fabs(test_T - 0.0001f) < 2e-8f) flag = true;
-                    if (test_T < 0.0001f) break;                                         // Q7: not blended
-                    float wgt = alpha * T;
+                    real test_T = T * (1 - alpha);
+                    if (std::fabs(test_T - RL(0.0001)) < RL(2e-8)) flag = true;
+                    if (test_T < RL(0.0001)) break;                                         // Q7: not blended
+                    real wgt = alpha * T;
                     for (int c = 0; c < 3; ++c) C[c] += ge.rgb[c] * wgt;
                     aps += ge.pixel_size * wgt;                                          // SPEC M6
                     adp += ge.depth * wgt;
                     T = test_T;
                     last = contributor;
+                }
+                if (taint) {
+                    flag = true;
+                    for (uint32_t k = lo; k < k_end; ++k) {
+                        const uint32_t id = st->list[k];
+                        const Geom& ge = st->geom[id];
+                        real dx = ge.px - pxf, dy = ge.py - pyf;
+                        real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        if (std::min(RL(0.99), ge.opacity * std::exp(power)) * 255.0f < 1.0f - RL(2e-5)) continue;
+                        uint8_t* bg_flag = &st->borderline_gauss[id];
+#pragma omp atomic write
+                        *bg_flag = 1;
+                    }
                 }
                 const size_t pix = (size_t)y * W + x;
                 st->final_T[pix] = T;
@@ -411,8 +484,8 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
     // result does not depend on the thread schedule beyond 1e-16 relative.
     struct Acc { double mean2D[2], conic[3], opacity, color[3]; };
     std::vector<Acc> acc(P, Acc{});
-    const float bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const real bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
+    const real ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
     // ---- K7 blend backward (App. A.3) ----
 #pragma omp parallel for schedule(dynamic, 4)
@@ -424,26 +497,27 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
                 const int x = tx * TILE + lx, y = ty * TILE + ly;
                 if (x >= W || y >= H) continue;
                 const size_t pix = (size_t)y * W + x;
-                const float pxf = (float)x, pyf = (float)y;
-                const float T_final = st->final_T[pix];
-                float T = T_final;
+                const real pxf = (real)x, pyf = (real)y;
+                const real T_final = st->final_T[pix];
+                real T = T_final;
                 const uint32_t last = st->n_contrib[pix];
-                float dL_dpixel[3];
+                real dL_dpixel[3];
                 for (int c = 0; c < 3; ++c) dL_dpixel[c] = dL_dcolor[(size_t)c * H * W + pix];
-                float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
+                real accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
                 for (uint32_t j = last; j-- > 0;) {
                     const uint32_t id = st->list[lo + j];
                     const Geom& ge = st->geom[id];
-                    float dx = ge.px - pxf, dy = ge.py - pyf;
-                    float power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
+                    if (ge.ghost) continue;
+                    real dx = ge.px - pxf, dy = ge.py - pyf;
+                    real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                     if (power > 0.0f) continue;
-                    const float G = std::exp(power);
-                    const float alpha = std::min(0.99f, ge.opacity * G);
-                    if (alpha < 1.0f / 255.0f) continue;
+                    const real G = std::exp(power);
+                    const real alpha = std::min(RL(0.99), ge.opacity * G);
+                    if (alpha < RL(1.0) / RL(255.0)) continue;
                     T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    float dcol[3];
+                    const real dchannel_dcolor = alpha * T;
+                    real dL_dalpha = 0.0f;
+                    real dcol[3];
                     for (int c = 0; c < 3; ++c) {
                         accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
                         last_color[c] = ge.rgb[c];
@@ -452,13 +526,13 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    float bg_dot = 0.f;
+                    real bg_dot = 0.f;
                     for (int c = 0; c < 3; ++c) bg_dot += bg[c] * dL_dpixel[c];
                     dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                    const float dL_dG = ge.opacity * dL_dalpha;                // Q6: through the clamp
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * ge.con[0] - gdy * ge.con[1];
-                    const float dG_ddely = -gdy * ge.con[2] - gdx * ge.con[1];
+                    const real dL_dG = ge.opacity * dL_dalpha;                // Q6: through the clamp
+                    const real gdx = G * dx, gdy = G * dy;
+                    const real dG_ddelx = -gdx * ge.con[0] - gdy * ge.con[1];
+                    const real dG_ddely = -gdy * ge.con[2] - gdx * ge.con[1];
                     Acc& a = acc[id];
                     const double v[9] = {(double)(dL_dG * dG_ddelx * ddelx_dx), (double)(dL_dG * dG_ddely * ddely_dy),
                                          (double)(-0.5f * gdx * dx * dL_dG), (double)(-0.5f * gdx * dy * dL_dG),
@@ -484,44 +558,57 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
     }
 
     // ---- K8 (2-D covariance backward) + K9 (preprocess backward), App. A.3 ----
-    const float fx = W / (2.0f * view->tanfovx), fy = H / (2.0f * view->tanfovy);
-    const float* V = view->viewmatrix;
-    const float* PM = view->projmatrix;
+    const real fx = W / (2.0f * (real)view->tanfovx), fy = H / (2.0f * (real)view->tanfovy);
+    const in_t* V = view->viewmatrix;
+    const in_t* PM = view->projmatrix;
+    // gradient outputs in `real` (float64 build: double buffers behind the float* fields of msgs_grads_t)
+    real* const G_means2D = reinterpret_cast<real*>(grads->dL_dmeans2D);
+    real* const G_opac = reinterpret_cast<real*>(grads->dL_dopacities);
+    real* const G_shs = reinterpret_cast<real*>(grads->dL_dshs);
+    real* const G_colors = reinterpret_cast<real*>(grads->dL_dcolors);
+    real* const G_scales = reinterpret_cast<real*>(grads->dL_dscales);
+    real* const G_rot = reinterpret_cast<real*>(grads->dL_drotations);
+    real* const G_cov3D = reinterpret_cast<real*>(grads->dL_dcov3D);
+    real* const G_means3D = reinterpret_cast<real*>(grads->dL_dmeans3D);
     const int K = view->sh_coeffs;
     const int deg = view->sh_degree;
+    const char* exact_env = std::getenv("MSGS_ORACLE_EXACT_DET");
+    const bool exact_det = exact_env && exact_env[0] == '1';
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; ++i) {
         const Geom& ge = st->geom[i];
-        float dmean[3] = {0, 0, 0};
-        if (grads->dL_dmeans2D) { grads->dL_dmeans2D[3 * i] = 0; grads->dL_dmeans2D[3 * i + 1] = 0; grads->dL_dmeans2D[3 * i + 2] = 0; }
-        if (grads->dL_dopacities) grads->dL_dopacities[i] = 0.f;
-        if (grads->dL_dshs) std::memset(grads->dL_dshs + (size_t)3 * K * i, 0, sizeof(float) * 3 * K);
-        if (grads->dL_dcolors) std::memset(grads->dL_dcolors + 3 * i, 0, 12);
-        if (grads->dL_dscales) std::memset(grads->dL_dscales + 3 * i, 0, 12);
-        if (grads->dL_drotations) std::memset(grads->dL_drotations + 4 * i, 0, 16);
-        if (grads->dL_dcov3D) std::memset(grads->dL_dcov3D + 6 * i, 0, 24);
-        if (grads->dL_dmeans3D) std::memset(grads->dL_dmeans3D + 3 * i, 0, 12);
+        real dmean[3] = {0, 0, 0};
+        if (G_means2D) { G_means2D[3 * i] = 0; G_means2D[3 * i + 1] = 0; G_means2D[3 * i + 2] = 0; }
+        if (G_opac) G_opac[i] = 0.f;
+        if (G_shs) std::memset(G_shs + (size_t)3 * K * i, 0, sizeof(real) * 3 * K);
+        if (G_colors) std::memset(G_colors + 3 * i, 0, 3 * sizeof(real));
+        if (G_scales) std::memset(G_scales + 3 * i, 0, 3 * sizeof(real));
+        if (G_rot) std::memset(G_rot + 4 * i, 0, 4 * sizeof(real));
+        if (G_cov3D) std::memset(G_cov3D + 6 * i, 0, 6 * sizeof(real));
+        if (G_means3D) std::memset(G_means3D + 3 * i, 0, 3 * sizeof(real));
         if (!ge.visible) continue;
         const Acc& a = acc[i];
-        const float g2x = (float)a.mean2D[0], g2y = (float)a.mean2D[1];
-        const float gA = (float)a.conic[0], gBh = (float)a.conic[1], gC = (float)a.conic[2];
-        const float* p = g->means3D + 3 * i;
+        const real g2x = (real)a.mean2D[0], g2y = (real)a.mean2D[1];
+        const real gA = (real)a.conic[0], gBh = (real)a.conic[1], gC = (real)a.conic[2];
+        const in_t* p = g->means3D + 3 * i;
 
         // -- 2-D covariance backward --
-        float t[3];
+        real t[3];
         view_point(V, p, t);
         Cov2DCtx c2;
         compute_cov2d(t, fx, fy, view->tanfovx, view->tanfovy, ge.cov3D, V, c2);
-        const float ca = c2.a, cb = c2.b, cc = c2.c;
-        const float denom = ca * cc - cb * cb;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);            // Q9
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        float dcov[6] = {0, 0, 0, 0, 0, 0};
+        const real ca = c2.a, cb = c2.b, cc = c2.c;
+        const real denom = ca * cc - cb * cb;
+        // Q9.  (MSGS_ORACLE_EXACT_DET=1 drops the 1e-7 — the exact derivative of 1 / det, what autograd forms: only for the
+        // test that checks this hand-derived backward against the autograd oracle to rounding, tests/test_oracle_cpu.py)
+        const real denom2inv = 1.0f / ((denom * denom) + (exact_det ? RL(0.0) : RL(0.0000001)));
+        real dL_da = 0, dL_db = 0, dL_dc = 0;
+        real dcov[6] = {0, 0, 0, 0, 0, 0};
         if (denom2inv != 0) {
             dL_da = denom2inv * (-cc * cc * gA + 2 * cb * cc * gBh + (denom - ca * cc) * gC);
             dL_dc = denom2inv * (-ca * ca * gC + 2 * ca * cb * gBh + (denom - ca * cc) * gA);
             dL_db = denom2inv * 2 * (cb * cc * gA - (denom + 2 * cb * cb) * gBh + ca * cb * gC);
-            const float(*T)[3] = c2.T;
+            const real(*T)[3] = c2.T;
             dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
             dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
             dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
@@ -530,28 +617,28 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
             dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
         }
         {
-            const float S[3][3] = {{ge.cov3D[0], ge.cov3D[1], ge.cov3D[2]}, {ge.cov3D[1], ge.cov3D[3], ge.cov3D[4]},
+            const real S[3][3] = {{ge.cov3D[0], ge.cov3D[1], ge.cov3D[2]}, {ge.cov3D[1], ge.cov3D[3], ge.cov3D[4]},
                                    {ge.cov3D[2], ge.cov3D[4], ge.cov3D[5]}};
-            float ST0[3], ST1[3];
+            real ST0[3], ST1[3];
             for (int k = 0; k < 3; ++k) {
                 ST0[k] = S[k][0] * c2.T[0][0] + S[k][1] * c2.T[0][1] + S[k][2] * c2.T[0][2];
                 ST1[k] = S[k][0] * c2.T[1][0] + S[k][1] * c2.T[1][1] + S[k][2] * c2.T[1][2];
             }
-            float dT0[3], dT1[3];
+            real dT0[3], dT1[3];
             for (int k = 0; k < 3; ++k) {
                 dT0[k] = 2 * ST0[k] * dL_da + ST1[k] * dL_db;
                 dT1[k] = 2 * ST1[k] * dL_dc + ST0[k] * dL_db;
             }
             // Wr[k][c] = V[4*c + k]
             auto Wr = [&](int k, int c) { return V[4 * c + k]; };
-            const float dJ00 = Wr(0, 0) * dT0[0] + Wr(0, 1) * dT0[1] + Wr(0, 2) * dT0[2];
-            const float dJ02 = Wr(2, 0) * dT0[0] + Wr(2, 1) * dT0[1] + Wr(2, 2) * dT0[2];
-            const float dJ11 = Wr(1, 0) * dT1[0] + Wr(1, 1) * dT1[1] + Wr(1, 2) * dT1[2];
-            const float dJ12 = Wr(2, 0) * dT1[0] + Wr(2, 1) * dT1[1] + Wr(2, 2) * dT1[2];
-            const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-            const float dtx = c2.x_mul * -fx * tz2 * dJ02;                                  // Q2
-            const float dty = c2.y_mul * -fy * tz2 * dJ12;
-            const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * c2.tx_c) * tz3 * dJ02 +
+            const real dJ00 = Wr(0, 0) * dT0[0] + Wr(0, 1) * dT0[1] + Wr(0, 2) * dT0[2];
+            const real dJ02 = Wr(2, 0) * dT0[0] + Wr(2, 1) * dT0[1] + Wr(2, 2) * dT0[2];
+            const real dJ11 = Wr(1, 0) * dT1[0] + Wr(1, 1) * dT1[1] + Wr(1, 2) * dT1[2];
+            const real dJ12 = Wr(2, 0) * dT1[0] + Wr(2, 1) * dT1[1] + Wr(2, 2) * dT1[2];
+            const real tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+            const real dtx = c2.x_mul * -fx * tz2 * dJ02;                                  // Q2
+            const real dty = c2.y_mul * -fy * tz2 * dJ12;
+            const real dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * c2.tx_c) * tz3 * dJ02 +
                               (2 * fy * c2.ty_c) * tz3 * dJ12;
             // dL/dp_j = sum_i W2C[i][j] dL/dt_i = sum_i V[4*j + i] dt_i
             for (int j = 0; j < 3; ++j) dmean[j] += V[4 * j + 0] * dtx + V[4 * j + 1] * dty + V[4 * j + 2] * dtz;
@@ -559,37 +646,37 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
 
         // -- projection backward --
         {
-            float h[4];
+            real h[4];
             proj_point(PM, p, h);
-            const float m_w = 1.0f / (h[3] + 0.0000001f);
-            const float mul1 = h[0] * m_w * m_w, mul2 = h[1] * m_w * m_w;
+            const real m_w = 1.0f / (h[3] + RL(0.0000001));
+            const real mul1 = h[0] * m_w * m_w, mul2 = h[1] * m_w * m_w;
             for (int j = 0; j < 3; ++j)
                 dmean[j] += (PM[4 * j + 0] * m_w - PM[4 * j + 3] * mul1) * g2x +
                             (PM[4 * j + 1] * m_w - PM[4 * j + 3] * mul2) * g2y;
         }
-        if (grads->dL_dmeans2D) { grads->dL_dmeans2D[3 * i] = g2x; grads->dL_dmeans2D[3 * i + 1] = g2y; }
-        if (grads->dL_dopacities) grads->dL_dopacities[i] = ge.weight * (float)a.opacity;      // SPEC M4
+        if (G_means2D) { G_means2D[3 * i] = g2x; G_means2D[3 * i + 1] = g2y; }
+        if (G_opac) G_opac[i] = ge.weight * (real)a.opacity;      // SPEC M4
 
         // -- colour backward --
-        float dcolr[3] = {(float)a.color[0], (float)a.color[1], (float)a.color[2]};
+        real dcolr[3] = {(real)a.color[0], (real)a.color[1], (real)a.color[2]};
         if (g->colors_precomp) {
-            if (grads->dL_dcolors) for (int c = 0; c < 3; ++c) grads->dL_dcolors[3 * i + c] = dcolr[c];
+            if (G_colors) for (int c = 0; c < 3; ++c) G_colors[3 * i + c] = dcolr[c];
         } else {
             for (int c = 0; c < 3; ++c) if (ge.clamped[c]) dcolr[c] = 0.f;                      // Q8
-            const float* sh = g->shs + (size_t)3 * K * i;
-            float* dsh = grads->dL_dshs ? grads->dL_dshs + (size_t)3 * K * i : nullptr;
-            const float* cam = view->campos;
-            float dox = p[0] - cam[0], doy = p[1] - cam[1], doz = p[2] - cam[2];
-            float len = std::sqrt(dox * dox + doy * doy + doz * doz);
-            float x = dox / len, y = doy / len, z = doz / len;
-            float basis[16], bdx[16], bdy[16], bdz[16];
+            const in_t* sh = g->shs + (size_t)3 * K * i;
+            real* dsh = G_shs ? G_shs + (size_t)3 * K * i : nullptr;
+            const in_t* cam = view->campos;
+            real dox = (real)p[0] - (real)cam[0], doy = (real)p[1] - (real)cam[1], doz = (real)p[2] - (real)cam[2];
+            real len = std::sqrt(dox * dox + doy * doy + doz * doz);
+            real x = dox / len, y = doy / len, z = doz / len;
+            real basis[16], bdx[16], bdy[16], bdz[16];
             for (int k = 0; k < 16; ++k) basis[k] = bdx[k] = bdy[k] = bdz[k] = 0.f;
             basis[0] = SH_C0;
             if (deg > 0) {
                 basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
                 bdy[1] = -SH_C1; bdz[2] = SH_C1; bdx[3] = -SH_C1;
                 if (deg > 1) {
-                    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                     basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2.f * zz - xx - yy);
                     basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
                     bdx[4] = SH_C2[0] * y; bdy[4] = SH_C2[0] * x;
@@ -614,50 +701,50 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
                 }
             }
             const int ncoef = (deg + 1) * (deg + 1);
-            float ddir[3] = {0, 0, 0};
+            real ddir[3] = {0, 0, 0};
             for (int k = 0; k < ncoef; ++k)
                 for (int c = 0; c < 3; ++c) {
                     if (dsh) dsh[k * 3 + c] = basis[k] * dcolr[c];
-                    const float s = sh[k * 3 + c] * dcolr[c];
+                    const real s = (real)sh[k * 3 + c] * dcolr[c];
                     ddir[0] += bdx[k] * s; ddir[1] += bdy[k] * s; ddir[2] += bdz[k] * s;
                 }
             // d normalize: (I - d d^T) / len
-            const float dotv = x * ddir[0] + y * ddir[1] + z * ddir[2];
+            const real dotv = x * ddir[0] + y * ddir[1] + z * ddir[2];
             dmean[0] += (ddir[0] - x * dotv) / len;
             dmean[1] += (ddir[1] - y * dotv) / len;
             dmean[2] += (ddir[2] - z * dotv) / len;
         }
-        if (grads->dL_dmeans3D) for (int j = 0; j < 3; ++j) grads->dL_dmeans3D[3 * i + j] = dmean[j];
+        if (G_means3D) for (int j = 0; j < 3; ++j) G_means3D[3 * i + j] = dmean[j];
 
         // -- 3-D covariance backward --
         if (g->cov3D_precomp) {
-            if (grads->dL_dcov3D) for (int c = 0; c < 6; ++c) grads->dL_dcov3D[6 * i + c] = dcov[c];
+            if (G_cov3D) for (int c = 0; c < 6; ++c) G_cov3D[6 * i + c] = dcov[c];
         } else {
-            const float* q = g->rotations + 4 * i;
-            const float* s = g->scales + 3 * i;
-            const float mod = view->scale_modifier;
-            float r = q[0], x = q[1], y = q[2], z = q[3];
-            float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+            const in_t* q = g->rotations + 4 * i;
+            const in_t* s = g->scales + 3 * i;
+            const real mod = view->scale_modifier;
+            real r = q[0], x = q[1], y = q[2], z = q[3];
+            real R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                              {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                              {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-            float S[3] = {mod * s[0], mod * s[1], mod * s[2]};
-            float Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+            real S[3] = {mod * s[0], mod * s[1], mod * s[2]};
+            real Gm[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
                               {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
                               {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-            float dM[3][3], dR[3][3];
+            real dM[3][3], dR[3][3];
             for (int a2 = 0; a2 < 3; ++a2)
                 for (int b2 = 0; b2 < 3; ++b2) {
-                    float acc2 = 0.f;
+                    real acc2 = 0.f;
                     for (int k = 0; k < 3; ++k) acc2 += Gm[a2][k] * (R[k][b2] * S[b2]);
                     dM[a2][b2] = 2.f * acc2;
                 }
             for (int j = 0; j < 3; ++j) {
-                float ds = dM[0][j] * R[0][j] + dM[1][j] * R[1][j] + dM[2][j] * R[2][j];
-                if (grads->dL_dscales) grads->dL_dscales[3 * i + j] = mod * ds;
+                real ds = dM[0][j] * R[0][j] + dM[1][j] * R[1][j] + dM[2][j] * R[2][j];
+                if (G_scales) G_scales[3 * i + j] = mod * ds;
                 for (int a2 = 0; a2 < 3; ++a2) dR[a2][j] = dM[a2][j] * S[j];
             }
-            if (grads->dL_drotations) {
-                float* dq = grads->dL_drotations + 4 * i;
+            if (G_rot) {
+                real* dq = G_rot + 4 * i;
                 dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
                 dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
                 dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
@@ -674,17 +761,18 @@ extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_vi
     return msgs_oracle_backward_ex(st, view, g, dL_dcolor, grads, num_threads, nullptr);
 }
 
-extern "C" int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* s) { return (int64_t)s->list.size(); }
+extern "C" int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* s) { return (int64_t)s->list.size() - s->ghost_instances; }
+extern "C" const uint8_t* msgs_oracle_filter_edge(const msgs_oracle_state_t* s) { return s->filter_edge.data(); }
 extern "C" int64_t msgs_oracle_traversed(const msgs_oracle_state_t* s) { return s->traversed; }
 extern "C" int64_t msgs_oracle_valid_pairs(const msgs_oracle_state_t* s) { return s->valid_pairs; }
 extern "C" int64_t msgs_oracle_evaluated_pairs(const msgs_oracle_state_t* s) { return s->evaluated_pairs; }
-extern "C" const float* msgs_oracle_final_T(const msgs_oracle_state_t* s) { return s->final_T.data(); }
+extern "C" const float* msgs_oracle_final_T(const msgs_oracle_state_t* s) { return reinterpret_cast<const float*>(s->final_T.data()); }
 extern "C" const uint32_t* msgs_oracle_n_contrib(const msgs_oracle_state_t* s) { return s->n_contrib.data(); }
-extern "C" const float* msgs_oracle_depths(const msgs_oracle_state_t* s) { return s->depths.data(); }
-extern "C" const float* msgs_oracle_conic_opacity(const msgs_oracle_state_t* s) { return s->conic_opacity.data(); }
-extern "C" const float* msgs_oracle_rgb(const msgs_oracle_state_t* s) { return s->rgb.data(); }
-extern "C" const float* msgs_oracle_means2D(const msgs_oracle_state_t* s) { return s->means2D.data(); }
-extern "C" const float* msgs_oracle_cov3D(const msgs_oracle_state_t* s) { return s->cov3D.data(); }
+extern "C" const float* msgs_oracle_depths(const msgs_oracle_state_t* s) { return reinterpret_cast<const float*>(s->depths.data()); }
+extern "C" const float* msgs_oracle_conic_opacity(const msgs_oracle_state_t* s) { return reinterpret_cast<const float*>(s->conic_opacity.data()); }
+extern "C" const float* msgs_oracle_rgb(const msgs_oracle_state_t* s) { return reinterpret_cast<const float*>(s->rgb.data()); }
+extern "C" const float* msgs_oracle_means2D(const msgs_oracle_state_t* s) { return reinterpret_cast<const float*>(s->means2D.data()); }
+extern "C" const float* msgs_oracle_cov3D(const msgs_oracle_state_t* s) { return reinterpret_cast<const float*>(s->cov3D.data()); }
 extern "C" const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* s) { return s->rects.data(); }
 extern "C" const uint8_t* msgs_oracle_borderline_gaussians(const msgs_oracle_state_t* s) { return s->borderline_gauss.data(); }
 extern "C" void msgs_oracle_free(msgs_oracle_state_t* s) { delete s; }

@@ -54,6 +54,11 @@ const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* state);        /* [P
  * a different float32 implementation may legitimately take the other branch there, which moves this
  * Gaussian's conic-derived gradients by about one rim pixel's worth */
 const uint8_t* msgs_oracle_borderline_gaussians(const msgs_oracle_state_t* state);
+/* [P] 1 = the Gaussian's pixel size is within 1e-4 (relative) of an active min / max pixel-size threshold with fade_size == 0:
+ * its filter decision (rendered or dropped) hinges on the last bits of logf / sqrtf and may differ in another float32
+ * implementation.  Rendered or not, it stays in the tile lists (not blended when dropped), every pixel it reaches with
+ * alpha >= 1/255 is reported borderline, and every Gaussian blended at such a pixel is a borderline Gaussian. */
+const uint8_t* msgs_oracle_filter_edge(const msgs_oracle_state_t* state);
 void msgs_oracle_free(msgs_oracle_state_t* state);
 
 #ifdef __cplusplus

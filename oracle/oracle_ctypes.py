@@ -46,20 +46,26 @@ class Grads(C.Structure):
                 ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p)]
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+def build(force=False, f64=False):
+    name = "liboracle64.so" if f64 else "liboracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "msgs_oracle.cpp")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+_LIB64 = None
+
+
+def lib(f64=False):
+    """liboracle.so (float32, THE checker) or — f64 — liboracle64.so: the same source compiled with every computed
+    quantity in double (msgs_oracle.cpp, MSGS_ORACLE_F64), the float64 "truth" at the full BASELINE sizes"""
+    global _LIB, _LIB64
+    if (_LIB64 if f64 else _LIB) is None:
+        so = os.path.join(_HERE, "liboracle64.so" if f64 else "liboracle.so")
         if not os.path.exists(so):
-            build()
+            build(f64=f64)
         L = C.CDLL(so)
         L.msgs_oracle_forward.restype = C.c_int
         L.msgs_oracle_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), C.c_void_p, C.c_void_p,
@@ -78,14 +84,17 @@ def lib():
             f.restype = C.c_int64
             f.argtypes = [C.c_void_p]
         for name in ("final_T", "n_contrib", "depths", "conic_opacity", "rgb", "means2D", "cov3D", "rects",
-                     "borderline_gaussians"):
+                     "borderline_gaussians", "filter_edge"):
             f = getattr(L, "msgs_oracle_" + name)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
         L.msgs_oracle_free.restype = None
         L.msgs_oracle_free.argtypes = [C.c_void_p]
-        _LIB = L
-    return _LIB
+        if f64:
+            _LIB64 = L
+        else:
+            _LIB = L
+    return _LIB64 if f64 else _LIB
 
 
 def _f32(t):
@@ -99,42 +108,44 @@ def _ptr(t):
 class OracleResult:
     """Holds the oracle's forward outputs + the native state needed for backward."""
 
-    def __init__(self):
+    def __init__(self, f64=False):
         self.state = C.c_void_p(None)
         self._keep = []
+        self.f64 = bool(f64)
 
     def __del__(self):
         try:
             if self.state:
-                lib().msgs_oracle_free(self.state)
+                lib(self.f64).msgs_oracle_free(self.state)
                 self.state = C.c_void_p(None)
         except Exception:
             pass
 
     def _arr(self, name, shape, dtype):
-        p = getattr(lib(), "msgs_oracle_" + name)(self.state)
+        """(float arrays of the float64 build hold doubles: pass torch.float64 for them)"""
+        p = getattr(lib(self.f64), "msgs_oracle_" + name)(self.state)
         n = int(np.prod(shape))
         if n == 0:
             return torch.zeros(shape, dtype=dtype)
-        ct = {torch.float32: C.c_float, torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dtype]
+        ct = {torch.float32: C.c_float, torch.float64: C.c_double, torch.int32: C.c_int32, torch.uint8: C.c_uint8}[dtype]
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy()
         return torch.from_numpy(a).view(*shape)
 
     @property
     def num_instances(self):
-        return int(lib().msgs_oracle_num_instances(self.state))
+        return int(lib(self.f64).msgs_oracle_num_instances(self.state))
 
     @property
     def traversed(self):
-        return int(lib().msgs_oracle_traversed(self.state))
+        return int(lib(self.f64).msgs_oracle_traversed(self.state))
 
     @property
     def valid_pairs(self):
-        return int(lib().msgs_oracle_valid_pairs(self.state))
+        return int(lib(self.f64).msgs_oracle_valid_pairs(self.state))
 
     @property
     def evaluated_pairs(self):
-        return int(lib().msgs_oracle_evaluated_pairs(self.state))
+        return int(lib(self.f64).msgs_oracle_evaluated_pairs(self.state))
 
 
 def _usable_cpus():
@@ -167,13 +178,15 @@ def _threads(num_threads):
 
 
 def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_precomp=False,
-              cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0):
+              cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0, f64=False):
     """Forward on a scenes.Scene.  Returns OracleResult with .color/.acc_pixel_size/.depth/.radii/
-    .pixel_sizes/.borderline tensors (CPU)."""
-    L = lib()
+    .pixel_sizes/.borderline tensors (CPU).  f64: the float64 build — the same float32 inputs, every computed quantity and
+    every output in double (the "truth" of the three-way tests)."""
+    L = lib(f64)
+    rdt = torch.float64 if f64 else torch.float32
     W, H = cam.image_width, cam.image_height
     P = scene.P
-    r = OracleResult()
+    r = OracleResult(f64)
     t = dict(means3D=_f32(scene.means3D), opac=_f32(scene.opacities.reshape(-1)),
              maxps=_f32(scene.max_pixel_sizes), minps=_f32(scene.min_pixel_sizes),
              occ=_f32(scene.occ_multiplier), dcd=_f32(scene.dc_delta),
@@ -200,11 +213,11 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     g = Gaussians(P, 0, _ptr(t["means3D"]), _ptr(t["shs"]), _ptr(t["col"]), _ptr(t["opac"]),
                   _ptr(t["scales"]), _ptr(t["rot"]), _ptr(t["cov"]), _ptr(t["maxps"]), _ptr(t["minps"]),
                   _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]), None, None, None)
-    r.color = torch.zeros(3, H, W)
-    r.acc_pixel_size = torch.zeros(H, W)
-    r.depth = torch.zeros(H, W)
+    r.color = torch.zeros(3, H, W, dtype=rdt)
+    r.acc_pixel_size = torch.zeros(H, W, dtype=rdt)
+    r.depth = torch.zeros(H, W, dtype=rdt)
     r.radii = torch.zeros(P, dtype=torch.int32)
-    r.pixel_sizes = torch.zeros(P)
+    r.pixel_sizes = torch.zeros(P, dtype=rdt)
     r.borderline = torch.zeros(H, W, dtype=torch.uint8)
     rc = L.msgs_oracle_forward(C.byref(v), C.byref(g), _ptr(r.color), _ptr(r.acc_pixel_size), _ptr(r.depth),
                                _ptr(r.radii), _ptr(r.pixel_sizes), _ptr(r.borderline), C.byref(r.state),
@@ -217,26 +230,30 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     r.has_shs = not use_colors_precomp
     r.has_sr = not use_cov_precomp
     r.borderline_gaussians = r._arr("borderline_gaussians", (P,), torch.uint8).bool()
+    # Gaussians whose multi-scale filter decision could flip in another float32 implementation (msgs_oracle.h)
+    r.filter_edge = r._arr("filter_edge", (P,), torch.uint8).bool()
+    r.borderline_gaussians |= r.filter_edge
     return r
 
 
 def backward(r, dL_dcolor, num_threads=0, want_sums2d=False):
-    """Backward on an OracleResult; returns dict of CPU float32 gradient tensors.  want_sums2d: also "sums2d", the
-    [P,9] float64 per-Gaussian 2-D gradient sums between the blend backward and the per-Gaussian backward
-    (msgs_oracle.h, msgs_oracle_backward_ex)."""
-    L = lib()
+    """Backward on an OracleResult; returns dict of CPU gradient tensors (float32; float64 for a result of the float64
+    build).  want_sums2d: also "sums2d", the [P,9] float64 per-Gaussian 2-D gradient sums between the blend backward and the
+    per-Gaussian backward (msgs_oracle.h, msgs_oracle_backward_ex)."""
+    L = lib(r.f64)
+    rdt = torch.float64 if r.f64 else torch.float32
     P, K = r.P, r.K
     dl = _f32(dL_dcolor)
-    out = dict(means3D=torch.zeros(P, 3), means2D=torch.zeros(P, 3), opacities=torch.zeros(P, 1))
+    out = dict(means3D=torch.zeros(P, 3, dtype=rdt), means2D=torch.zeros(P, 3, dtype=rdt), opacities=torch.zeros(P, 1, dtype=rdt))
     if r.has_shs:
-        out["shs"] = torch.zeros(P, K, 3)
+        out["shs"] = torch.zeros(P, K, 3, dtype=rdt)
     else:
-        out["colors_precomp"] = torch.zeros(P, 3)
+        out["colors_precomp"] = torch.zeros(P, 3, dtype=rdt)
     if r.has_sr:
-        out["scales"] = torch.zeros(P, 3)
-        out["rotations"] = torch.zeros(P, 4)
+        out["scales"] = torch.zeros(P, 3, dtype=rdt)
+        out["rotations"] = torch.zeros(P, 4, dtype=rdt)
     else:
-        out["cov3D_precomp"] = torch.zeros(P, 6)
+        out["cov3D_precomp"] = torch.zeros(P, 6, dtype=rdt)
     gr = Grads(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out.get("shs")), _ptr(out.get("colors_precomp")),
                _ptr(out["opacities"]), _ptr(out.get("scales")), _ptr(out.get("rotations")),
                _ptr(out.get("cov3D_precomp")), None, None, None)

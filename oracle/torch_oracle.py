@@ -322,8 +322,10 @@ def rasterize(means3D, opacities, view, bg, **kw):
 
 def view_dict(cam, *, sh_degree, scale_modifier=1.0, filter_small=False, filter_large=False,
               fade_size=1.0):
+    # tan(FoV / 2) rounded to float32: what the op receives (GaussianRasterizationSettings -> msgs_view_t::tanfovx is a float)
+    f32 = lambda v: float(torch.tensor(v, dtype=torch.float64).to(torch.float32))
     return dict(image_width=cam.image_width, image_height=cam.image_height,
-                tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                tanfovx=f32(math.tan(cam.FoVx * 0.5)), tanfovy=f32(math.tan(cam.FoVy * 0.5)),
                 viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
                 campos=cam.camera_center, sh_degree=sh_degree, scale_modifier=scale_modifier,
                 filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)

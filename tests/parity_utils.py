@@ -23,8 +23,19 @@ import scenes
 
 FWD_ATOL = 1e-5
 BWD_RTOL = 1e-4
-BORDERLINE_PIXEL_BUDGET = 0.0045      # hard ceiling on the pixels excluded from the strict forward check (measured: C3 0.34 %,
-                                      # C3 k = 6 0.42 %; 0.5 % was the round-2 bound)
+BORDERLINE_PIXEL_BUDGET = 0.0045      # default ceiling on the pixels excluded from the strict forward check (small test scenes)
+# Per-config ceilings: 1.2 x the ORACLE's own count on that config (the fraction is a property of the scene and of the
+# oracle's flags, computed on the inputs: /tmp-style recount with oracle_ctypes.rasterize; round 4: C2 0.0175 %, C3 0.334 %,
+# C3@k=1 0.339 %, k=3 0.809 %, k=6 0.417 %, C4 views 0 / 3 / 6 0.159 / 0.161 / 0.163 %, C5 0.331 %) — so that a config
+# whose exclusions grow trips its own bound instead of hiding under the largest one.
+BORDERLINE_PIXEL_BUDGETS = {
+    "C2": 2.1e-4, "C3": 4.0e-3, "C3@k=1": 4.1e-3, "C3@k=3": 9.7e-3, "C3@k=6": 5.0e-3,
+    "C4v0": 1.9e-3, "C4v3": 1.95e-3, "C4v6": 1.96e-3, "C5": 4.0e-3,
+}
+
+
+def pixel_budget(name):
+    return BORDERLINE_PIXEL_BUDGETS.get(name.split(" ")[0], BORDERLINE_PIXEL_BUDGET)
 
 # Per-config ceilings on the two gradient tensors that end the conic -> 2-D covariance -> 3-D covariance chain of K8
 # (dL/dscaling, dL/drotation), max-norm relative, at ~1.5x the measured value (profiles/r3_parity.md; the HIP numbers are
@@ -106,8 +117,9 @@ def rel_err_reported(name, what, a, ref, rows=None):
 def check_forward(out, orc, name=""):
     ok = ~orc.borderline.bool()
     frac_bl = 1.0 - ok.float().mean().item()
-    report(name, f"borderline pixel fraction (bound {BORDERLINE_PIXEL_BUDGET:g})", frac_bl)
-    assert frac_bl < BORDERLINE_PIXEL_BUDGET, f"{name}: too many borderline pixels ({frac_bl:.4f})"
+    budget = pixel_budget(name)
+    report(name, f"borderline pixel fraction (bound {budget:g})", frac_bl)
+    assert frac_bl < budget, f"{name}: too many borderline pixels ({frac_bl:.5f} >= {budget:g})"
     col = out["render"].detach().cpu()
     d = (col - orc.color).abs()
     strict = d[:, ok].max().item() if ok.any() else 0.0
@@ -119,8 +131,17 @@ def check_forward(out, orc, name=""):
         scale = max(ref.abs().max().item(), 1.0)
         m = dd[ok].max().item() if ok.any() else 0.0
         assert m <= FWD_ATOL * scale, f"{name}: {key} max abs diff {m:.3e} (scale {scale:.2f})"
-    assert torch.equal(out["radii"].cpu(), orc.radii), f"{name}: radii differ"
-    assert torch.equal(out["visibility_filter"].cpu(), orc.radii > 0)
+    # radii: bit-equal, except that a Gaussian whose multi-scale filter decision sits within rounding of its threshold
+    # (oracle: filter_edge) may be rendered by one implementation and dropped by the other — radius or 0, nothing else
+    got_r = out["radii"].cpu()
+    edge = getattr(orc, "filter_edge", None)
+    edge = edge if edge is not None else torch.zeros_like(got_r, dtype=torch.bool)
+    assert torch.equal(got_r[~edge], orc.radii[~edge]), f"{name}: radii differ"
+    if edge.any():
+        ge, oe = got_r[edge], orc.radii[edge]
+        assert bool(((ge == oe) | (ge == 0) | (oe == 0)).all()), f"{name}: radii of filter-edge Gaussians differ"
+        report(name, "filter-edge Gaussians (decision may flip), flipped", float(((ge == 0) != (oe == 0)).sum().item()))
+    assert torch.equal(out["visibility_filter"].cpu(), got_r > 0)
     dps = (out["pixel_sizes"].cpu() - orc.pixel_sizes).abs()
     assert (dps <= 1e-4 * orc.pixel_sizes.abs().clamp_min(1.0)).all(), f"{name}: pixel_sizes differ {dps.max():.3e}"
     return strict
@@ -143,24 +164,15 @@ def own_relative_quantile(got, ref, rows, q=0.99):
     return torch.sort(e).values[k].item()
 
 
-def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99_tol=None, rtol_by_key=None):
-    """pc holds RAW parameters; the oracle returns grads w.r.t. the ACTIVATED inputs, so push the oracle's
-    grads through the same torch activations (exp / sigmoid / normalize / cat) on CPU in float64.
-    `flagged` [P] bool = oracle's borderline Gaussians (strict check on the others, loose on these).
-    `rtol_by_key` {tensor name: tolerance} overrides `rtol` per tensor (names: means3D, features_dc, features_rest,
-    opacity, scaling, rotation, means2D)."""
+def leaf_space(pc, m2grad, ograds):
+    """{tensor name: (HIP gradient, reference gradient in float64)} in the space of the model's LEAF parameters.  pc holds
+    RAW parameters; an oracle returns grads w.r.t. the ACTIVATED inputs, so they are pushed through the same torch
+    activations (exp / sigmoid / normalize / cat) on CPU in float64."""
     dt = torch.float64
-    P = pc._xyz.shape[0]
-    if flagged is None:
-        flagged = torch.zeros(P, dtype=torch.bool)
-    flagged = flagged.cpu()
-    report(name, "borderline Gaussian fraction (bound 3e-2)", flagged.float().mean().item())
-    assert flagged.float().mean().item() < 0.03, f"{name}: {flagged.float().mean().item():.4f} of the Gaussians borderline"
-    clean = ~flagged
-    pairs = {"means3D": (pc._xyz.grad, ograds["means3D"])}
+    pairs = {"means3D": (pc._xyz.grad, ograds["means3D"].to(dt))}
     if "shs" in ograds:
-        pairs["features_dc"] = (pc._features_dc.grad, ograds["shs"][:, :1])
-        pairs["features_rest"] = (pc._features_rest.grad, ograds["shs"][:, 1:])
+        pairs["features_dc"] = (pc._features_dc.grad, ograds["shs"][:, :1].to(dt))
+        pairs["features_rest"] = (pc._features_rest.grad, ograds["shs"][:, 1:].to(dt))
     raw = pc._opacity.detach().cpu().to(dt)
     s = torch.sigmoid(raw)
     pairs["opacity"] = (pc._opacity.grad, ograds["opacities"].to(dt).view_as(raw) * s * (1 - s))
@@ -169,7 +181,23 @@ def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99
         q = pc._rotation.detach().cpu().to(dt).requires_grad_(True)
         torch.nn.functional.normalize(q).backward(ograds["rotations"].to(dt))
         pairs["rotation"] = (pc._rotation.grad, q.grad)
-    pairs["means2D"] = (m2grad, ograds["means2D"])
+    pairs["means2D"] = (m2grad, ograds["means2D"].to(dt))
+    return pairs
+
+
+def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99_tol=None, rtol_by_key=None):
+    """HIP leaf gradients against an oracle's (leaf_space).
+    `flagged` [P] bool = oracle's borderline Gaussians (strict check on the others, loose on these).
+    `rtol_by_key` {tensor name: tolerance} overrides `rtol` per tensor (names: means3D, features_dc, features_rest,
+    opacity, scaling, rotation, means2D)."""
+    P = pc._xyz.shape[0]
+    if flagged is None:
+        flagged = torch.zeros(P, dtype=torch.bool)
+    flagged = flagged.cpu()
+    report(name, "borderline Gaussian fraction (bound 3e-2)", flagged.float().mean().item())
+    assert flagged.float().mean().item() < 0.03, f"{name}: {flagged.float().mean().item():.4f} of the Gaussians borderline"
+    clean = ~flagged
+    pairs = leaf_space(pc, m2grad, ograds)
     worst = {}
     for k, (got, ref) in pairs.items():
         worst[k] = rel_err(got, ref, clean)
@@ -185,6 +213,41 @@ def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99
         tol = (rtol_by_key or {}).get(k, rtol)
         assert v <= tol, f"{name}: grad {k} rel err {v:.3e} > {tol} ({worst})"
     return worst
+
+
+TRUTH_FACTOR = 1.25      # HIP may be at most this much farther from the float64 truth than the float32 oracle is (+ 1e-6)
+
+
+def check_against_truth(name, scene_seen, cam, st, bg, dL, out, pc, m2grad, orc, og, factor=TRUTH_FACTOR):
+    """The three-way check that turns "1e-4 between two float32 evaluations is ill-posed for dL/dscaling / dL/drotation" into an
+    asserted property: with the float64 build of the oracle (liboracle64.so: the same algorithm, the same float32 inputs, every
+    computed quantity in double — checked against the autograd oracle in tests/test_oracle_cpu.py) as the truth, the HIP result
+    is no farther from the truth than `factor` x the float32 oracle's own distance + 1e-6, per tensor (max-norm relative, on
+    the Gaussians / pixels no oracle flags as borderline), forward and backward.  Returns {tensor: (hip, oracle)} distances."""
+    from oracle import oracle_ctypes as oc
+    t = oc.rasterize(scene_seen, cam, st, bg, f64=True)
+    tg = oc.backward(t, dL)
+    flagged = (orc.borderline_gaussians | t.borderline_gaussians | (t.radii != orc.radii)).cpu()
+    clean = ~flagged
+    okpx = ~(orc.borderline.bool() | t.borderline.bool())
+    e_orc = (orc.color.double() - t.color).abs()[:, okpx].max().item()
+    e_hip = (out["render"].detach().cpu().double() - t.color).abs()[:, okpx].max().item()
+    report(name, "forward, oracle_f32 vs float64 truth", e_orc)
+    report(name, "forward, HIP vs float64 truth", e_hip)
+    assert e_hip <= factor * e_orc + 1e-6, f"{name}: forward HIP-vs-truth {e_hip:.3e} > {factor} x oracle-vs-truth {e_orc:.3e}"
+    hip_t = leaf_space(pc, m2grad, tg)                       # (HIP, truth) per tensor, leaf space
+    orc_t = leaf_space(pc, m2grad, og)                       # (HIP, oracle) per tensor: only the oracle side is used
+    dist_ = {}
+    for k, (got, truth) in hip_t.items():
+        d_hip = rel_err(got, truth, clean)
+        d_orc = rel_err(orc_t[k][1], truth, clean)
+        dist_[k] = (d_hip, d_orc)
+        report(name, f"grad {k}: HIP vs truth", d_hip)
+        report(name, f"grad {k}: oracle_f32 vs truth", d_orc)
+    for k, (d_hip, d_orc) in dist_.items():
+        assert d_hip <= factor * d_orc + 1e-6, \
+            f"{name}: grad {k}: HIP is {d_hip:.3e} from the float64 truth, the float32 oracle {d_orc:.3e} (allowed {factor}x + 1e-6)"
+    return dist_
 
 
 def small_scene(P, W, H, seed, **kw):
