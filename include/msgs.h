@@ -303,9 +303,11 @@ int msgs_set_blend_granularity(int32_t mode);
 /* Which blend-forward kernel msgs_forward_stage2 launches at or above the fine-grained threshold: 0 = the default,
  * 1 = quadrant lists (one wave64 per 8x8 pixel quadrant, one entry list per wave), 2 = one wave per tile, 3 = strip lists
  * (same mapping as 1, but each 16-lane row of a wave — an 8x2 pixel strip — walks its own entry list, the four rows in lock
- * step; strips chosen by the y-extent of the alpha >= 1/255 level set), 4 = strip lists with the exact 8x2 rectangle test.
- * All variants evaluate every pixel with the same instructions in the same order: outputs are bit-identical; for the parity
- * tests and A/B measurements.  Initial value from MSGS_FWD_GEN.  Returns the previous value. */
+ * step; strips chosen by the y-extent of the alpha >= 1/255 level set), 4 = strip lists with the exact 8x2 rectangle test,
+ * 5 = 4x4 BLOCK lists (a 16-lane row owns a 4x4 pixel block of the quadrant; blocks chosen by the bounding box of the level
+ * set), 6 = block lists with the exact 4x4 rectangle test.  All variants evaluate every pixel with the same instructions in
+ * the same order: outputs are bit-identical; for the parity tests and A/B measurements (none of 3-6 beats 1: DESIGN.md 4.1).
+ * Initial value from MSGS_FWD_GEN.  Returns the previous value. */
 int msgs_set_forward_variant(int32_t variant);
 
 /* msgs_forward: both stages in ONE call.  The caller passes `binning` and `scratch2` sized for a GUESS of the instance count

@@ -321,7 +321,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
 // 128 records per batch: the sixteen lists of a workgroup (4 waves x 4 rows x 132 words) and the records fit 15 KB, so that
 // eight workgroups stay resident per CU (the walk is issue-bound and wants 8 waves per SIMD).
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT, bool STRIP_EXACT>
+// MODE (round 4: the same kernel with 4x4 BLOCK lists — a DPP row owns a 4x4 pixel block of the wave's quadrant instead of an 8x2
+// strip; lane l of row r <-> pixel ((r & 1) * 4 + (l & 3), (r >> 1) * 4 + (l >> 2)) of the quadrant; more compact than a strip, so
+// an entry reaches it less often):
+//   0 strips by y-extent, 1 strips exact;  2 blocks by the level set's BOUNDING BOX (x- and y-extent, two sqrt per record, computed
+//   once by the loading thread: a block is listed when both extents overlap it — conservative), 3 blocks by the exact 4x4 test.
+template <bool COUNT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void blend_forward_strip_kernel(
     ViewParams vp, const GaussRec* __restrict__ rec, const uint32_t* __restrict__ ids, const uint2* __restrict__ ranges,
     float* __restrict__ out_color, float* __restrict__ out_ps, float* __restrict__ out_depth, float* __restrict__ final_T,
@@ -330,7 +335,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
     __shared__ float4 s_r0[SBATCH + 1], s_r1[SBATCH + 1], s_r2[SBATCH + 1];     // slot SBATCH: the sentinel record
     __shared__ uint32_t s_mask[SBATCH];
     __shared__ float2 s_yr[SBATCH];                                              // y-extent of the alpha >= 1/255 level set
+    __shared__ float2 s_xr[MODE == 2 ? SBATCH : 1];                              // x-extent (block lists by bounding box)
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][4][SBATCH + LIST_PAD];
+    constexpr bool STRIP_EXACT = MODE == 1;
+    constexpr bool BLOCKS = MODE >= 2;
     __shared__ uint32_t s_wlast[8];
     clear_slice(clear_ptr, clear_n16);
     if (threadIdx.x == 0) {
@@ -342,8 +350,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
     const int tile = swizzled_tile(blockIdx.x, num_tiles);
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, row = lane >> 4;
-    const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (w >> 1) * 8 + (lane >> 3);
+    const int px = tx * TILE + (w & 1) * 8 + (BLOCKS ? (row & 1) * 4 + (lane & 3) : (lane & 7));
+    const int py = ty * TILE + (w >> 1) * 8 + (BLOCKS ? (row >> 1) * 4 + ((lane >> 2) & 3) : (lane >> 3));
     const bool inside = px < vp.W && py < vp.H;
     const float pxf = (float)px, pyf = (float)py;
     const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
@@ -367,13 +375,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
             s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
             // y-extent of {f >= tau2}: |dy| <= sqrt(A tau2 / det) (levelset_rows_setup); everything when it cannot be bounded
-            float ylo = -3.0e38f, yhi = 3.0e38f;
+            float ylo = -3.0e38f, yhi = 3.0e38f, xlo = -3.0e38f, xhi = 3.0e38f;
             if (r2.w > -1.0e38f) {
                 const float det = r0.z * r1.x - r0.w * r0.w;
                 const float e = sqrtf(fmaxf(0.0f, (r0.z * r2.w) / det)) + 0.05f;
                 if (det > 0.0f && e == e) { ylo = r0.y - e; yhi = r0.y + e; }
+                if (MODE == 2) {       // |dx| <= sqrt(C tau2 / det)
+                    const float ex = sqrtf(fmaxf(0.0f, (r1.x * r2.w) / det)) + 0.05f;
+                    if (det > 0.0f && ex == ex) { xlo = r0.x - ex; xhi = r0.x + ex; }
+                }
             }
             s_yr[tid] = make_float2(ylo, yhi);
+            if (MODE == 2) s_xr[tid] = make_float2(xlo, xhi);
         }
         __syncthreads();
         // four row lists per wave: ballot + popcount prefix per strip
@@ -384,7 +397,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
             const bool hitq = e < n && ((s_mask[e] >> w) & 1u);
             bool b0 = false, b1 = false, b2 = false, b3 = false;
             if (hitq) {
-                if (STRIP_EXACT) {
+                if (MODE == 3) {               // exact 4x4 block test
+                    const float4 r0 = s_r0[e];
+                    const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                    if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
+                    else {
+                        b0 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 3.0f, qy0, qy0 + 3.0f);
+                        b1 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0 + 4.0f, qx0 + 7.0f, qy0, qy0 + 3.0f);
+                        b2 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 3.0f, qy0 + 4.0f, qy0 + 7.0f);
+                        b3 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0 + 4.0f, qx0 + 7.0f, qy0 + 4.0f, qy0 + 7.0f);
+                    }
+                } else if (MODE == 2) {        // bounding box of the level set against the four blocks
+                    const float2 yr = s_yr[e], xr = s_xr[e];
+                    const bool xl = xr.x <= qx0 + 3.0f && xr.y >= qx0, xh = xr.x <= qx0 + 7.0f && xr.y >= qx0 + 4.0f;
+                    const bool yl = yr.x <= qy0 + 3.0f && yr.y >= qy0, yh = yr.x <= qy0 + 7.0f && yr.y >= qy0 + 4.0f;
+                    b0 = xl && yl; b1 = xh && yl; b2 = xl && yh; b3 = xh && yh;
+                } else if (STRIP_EXACT) {
                     const float4 r0 = s_r0[e];
                     const float C = s_r1[e].x, tau2 = s_r2[e].w;
                     if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
@@ -1241,7 +1269,7 @@ constexpr int FINE_MAX_TILES_FWD = 300, FINE_MAX_TILES_BWD = 300;     // (round 
 // y-extent strip test, 4 = strip lists with the exact strip test; MSGS_FWD_GEN / msgs_set_forward_variant
 constexpr int FWD_GEN_DEFAULT = 1;
 static std::atomic<int> g_fwd_gen{env_gen("MSGS_FWD_GEN", FWD_GEN_DEFAULT)};
-int set_forward_variant(int v) { return g_fwd_gen.exchange(v >= 1 && v <= 4 ? v : FWD_GEN_DEFAULT); }
+int set_forward_variant(int v) { return g_fwd_gen.exchange(v >= 1 && v <= 6 ? v : FWD_GEN_DEFAULT); }
 static std::atomic<int> g_bwd_gen{[] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen == 2 ? gen : 0); }
 // blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
@@ -1405,11 +1433,19 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
         hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
                            out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last, order_flag);
     else if (fwd_gen == 3 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 8x2 strip lists, strips by the level set's y-extent
-        hipLaunchKernelGGL((blend_forward_strip_kernel<false, false>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
+        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 0>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
                            out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
                            order_flag);
     else if (fwd_gen == 4 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 8x2 strip lists, exact strip test
-        hipLaunchKernelGGL((blend_forward_strip_kernel<false, true>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
+        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 1>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
+                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
+                           order_flag);
+    else if (fwd_gen == 5 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 4x4 block lists by the level set's bounding box
+        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 2>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
+                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
+                           order_flag);
+    else if (fwd_gen == 6 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 4x4 block lists, exact block test
+        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 3>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
                            out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
                            order_flag);
     else if (fwd_gen >= 3)
@@ -1541,12 +1577,13 @@ hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const
     const int fwd_gen = g_fwd_gen.load();                            // the replica of the kernel variant in use
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
     float* const nf = nullptr;
-    if (tiles && fwd_gen == 3)
-        hipLaunchKernelGGL((blend_forward_strip_kernel<true, false>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, nf, nf,
-                           nf, nf, (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
-    else if (tiles && fwd_gen == 4)
-        hipLaunchKernelGGL((blend_forward_strip_kernel<true, true>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, nf, nf,
-                           nf, nf, (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
+#define MSGS_STRIP_COUNT(MODE) hipLaunchKernelGGL((blend_forward_strip_kernel<true, MODE>), dim3(tiles), dim3(256), 0, s, vp, rec, \
+        ids, ranges, nf, nf, nf, nf, (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr)
+    if (tiles && fwd_gen == 3) MSGS_STRIP_COUNT(0);
+    else if (tiles && fwd_gen == 4) MSGS_STRIP_COUNT(1);
+    else if (tiles && fwd_gen == 5) MSGS_STRIP_COUNT(2);
+    else if (tiles && fwd_gen == 6) MSGS_STRIP_COUNT(3);
+#undef MSGS_STRIP_COUNT
     else if (tiles)
         hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec,
                            ids, ranges, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,

@@ -20,7 +20,7 @@ def _all_variants(sc, cam, st, bg, dL):
     prev_g = lib.msgs_set_blend_granularity(1)       # coarse kernels at every size, so the variants are really exercised
     res = {}
     try:
-        for v in (1, 2, 3, 4):
+        for v in (1, 2, 3, 4, 5, 6):
             lib.msgs_set_forward_variant(v)
             res[v] = hip_render(sc, cam, st, bg, dL)
     finally:

@@ -18,7 +18,7 @@ def step(t=None):
     dgr._C.set_timer(t)
     for p_ in pc.parameters(): p_.grad = None
     out = render(camd, pc, PIPE, bg, **st); out["render"].backward(dL); return out
-for v in (1, 3, 4, 1, 3, 4):
+for v in (1, 3, 4, 5, 6, 1, 5, 6):
     lib.msgs_set_forward_variant(v)
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
