@@ -23,9 +23,10 @@ namespace {
 // stage, so a staged pair is 3 bytes, not 8: the tile id as KeyT (16 bits whenever the grid has fewer than 65535 tiles) and
 // the owner's thread number (8 bits; the 256 Gaussian ids of the block sit in LDS once).
 
-template <int EMIT_STAGE, typename KeyT>
+// OutT: the element type of the key array in HBM — uint16_t when the tile sort runs on 16-bit keys (radix_sort_keys16_ok)
+template <int EMIT_STAGE, typename KeyT, typename OutT = uint32_t>
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ ids,
+                                                   OutT* __restrict__ keys, uint32_t* __restrict__ ids,
                                                    int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev) {
     // ranks 0 .. V-1 of the depth order are the Gaussians that stayed in the compacting depth sort (GeomLayout::nvalid)
     {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
@@ -61,9 +62,19 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     if (blk_len <= 0) return;
     const bool staged = blk_len <= EMIT_STAGE;
 
-    if (count) {
+    // A Gaussian with many instances is emitted by its whole WAVE (below): one thread looping over thousands of tiles while 63
+    // lanes wait made the emit 4.3 ms for the 427 M instances of a multi-scale model rendered without its filters
+    // (render.py's defaults; 145 k Gaussians wider than 256 px), i.e. 0.8 TB/s of stores.
+    constexpr uint32_t HEAVY_MIN = 96;
+    const bool heavy = count > HEAVY_MIN;
+    auto put = [&](int64_t at, uint32_t k, uint32_t g_id, uint32_t owner) {
+        if (staged) { s_keys[at - blk_lo] = (KeyT)k; s_own[at - blk_lo] = (uint8_t)owner; }
+        else { keys[at] = (OutT)k; ids[at] = g_id; }
+    };
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (count) { q0 = binrec[gi].q0; q1 = binrec[gi].q1; }
+    if (count && !heavy) {
         const int64_t end = min((int64_t)off + count, D);
-        const float4 q0 = binrec[gi].q0, q1 = binrec[gi].q1;
         const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
         const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
         const float conC = q1.x;
@@ -74,30 +85,66 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
             int tlo = minx, thi = maxx - 1;
             if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi)) continue;
             for (int tx = tlo; tx <= thi && off < end; ++tx) {
-                const uint32_t k = (uint32_t)(ty * vp.gx + tx);
-                if (staged) { s_keys[off - blk_lo] = (KeyT)k; s_own[off - blk_lo] = (uint8_t)threadIdx.x; }
-                else { keys[off] = k; ids[off] = gi; }
+                put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
                 ++off;
             }
         }
         // count >= emitted by construction (larger margin in the count): park the surplus slots on the sentinel tile
-        for (; off < end; ++off) {
-            const uint32_t k = (uint32_t)(vp.gx * vp.gy);
-            if (staged) { s_keys[off - blk_lo] = (KeyT)k; s_own[off - blk_lo] = (uint8_t)threadIdx.x; }
-            else { keys[off] = k; ids[off] = gi; }
+        for (; off < end; ++off) put(off, (uint32_t)(vp.gx * vp.gy), gi, threadIdx.x);
+    }
+    // heavy Gaussians, one after the other, by all 64 lanes of their wave: lane <-> tile row for the row intervals (the same
+    // levelset_row_interval as above and as the count: same bits), then row by row with the lanes on consecutive tiles —
+    // consecutive output slots, so the stores coalesce
+    {
+        const int lane = threadIdx.x & 63;
+        uint64_t hv = __ballot(heavy);
+        while (hv) {
+            const int src = __ffsll((long long)hv) - 1;
+            hv &= hv - 1;
+            const uint32_t h_gi = (uint32_t)__shfl((int)gi, src);
+            const uint32_t h_owner = (uint32_t)((threadIdx.x & ~63) + src);
+            const int64_t h_off = ((int64_t)__shfl((int)(uint32_t)(off >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)off, src);
+            const uint32_t h_count = (uint32_t)__shfl((int)count, src);
+            const int64_t h_end = min(h_off + (int64_t)h_count, D);
+            const float gx_ = __shfl(q0.x, src), gy_ = __shfl(q0.y, src), cA = __shfl(q0.z, src), cBh = __shfl(q0.w, src);
+            const float cC = __shfl(q1.x, src), tau2 = __shfl(q1.y, src);
+            const uint32_t rcx = __float_as_uint(__shfl(q1.z, src)), rcy = __float_as_uint(__shfl(q1.w, src));
+            const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
+            const bool test = tau2 > -1.0e38f;
+            const LevelSetRows ls = test ? levelset_rows_setup(cA, cBh, cC, tau2) : LevelSetRows{};
+            int64_t at = h_off;                                        // wave-uniform write position
+            for (int row0 = miny; row0 < maxy && at < h_end; row0 += 64) {
+                const int ty = row0 + lane;
+                int tlo = minx, thi = maxx - 1;
+                bool hit = ty < maxy;
+                if (hit && test) hit = levelset_row_interval(ls, gx_, gy_, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi);
+                const int n_row = hit ? thi - tlo + 1 : 0;
+                const int nrows = min(64, maxy - row0);
+                for (int r = 0; r < nrows && at < h_end; ++r) {        // wave-uniform: row r of this group of 64
+                    const int n_r = __shfl(n_row, r);
+                    if (n_r == 0) continue;
+                    const int tlo_r = __shfl(tlo, r);
+                    const uint32_t kbase = (uint32_t)((row0 + r) * vp.gx + tlo_r);
+                    for (int j = lane; j < n_r; j += 64)
+                        if (at + j < h_end) put(at + j, kbase + (uint32_t)j, h_gi, h_owner);
+                    at += n_r;
+                }
+            }
+            for (int64_t a = at + lane; a < h_end; a += 64) put(a, (uint32_t)(vp.gx * vp.gy), h_gi, h_owner);   // surplus -> sentinel
         }
     }
     if (!staged) return;
     __syncthreads();
     for (int i = threadIdx.x; i < (int)blk_len; i += blockDim.x) {
-        keys[blk_lo + i] = (uint32_t)s_keys[i];
+        keys[blk_lo + i] = (OutT)s_keys[i];
         ids[blk_lo + i] = s_gi[s_own[i]];
     }
 }
 
 // four consecutive keys per thread (one 16-byte load); the neighbours across thread boundaries come from the adjacent lanes, across
 // wave boundaries from memory.  (One key per thread with three 4-byte loads ran at 1.5 TB/s: 14 us at C3, 150 us at C5.)
-__global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict__ keys, int64_t D,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ keys, int64_t D,
                                                      uint2* __restrict__ ranges, int num_tiles,
                                                      const uint32_t* __restrict__ D_dev) {
     if (D_dev) D = (int64_t)*D_dev;
@@ -105,18 +152,21 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
     const int lane = threadIdx.x & 63;
     const bool full = i0 + 3 < D;
     uint32_t k[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (full) {
+    if (full && sizeof(KeyT) == 4) {
         const uint4 v = *reinterpret_cast<const uint4*>(keys + i0);
         k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    } else if (full) {                 // four 16-bit keys in one 8-byte load
+        const uint2 v = *reinterpret_cast<const uint2*>(keys + i0);
+        k[0] = v.x & 0xFFFFu; k[1] = v.x >> 16; k[2] = v.y & 0xFFFFu; k[3] = v.y >> 16;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (i0 + j < D) k[j] = keys[i0 + j];
+        for (int j = 0; j < 4; ++j) if (i0 + j < D) k[j] = (uint32_t)keys[i0 + j];
     }
     // key in front of k[0] / behind k[3] (every lane takes part in the shuffles)
     uint32_t prev = (uint32_t)__shfl_up((int)k[3], 1), next = (uint32_t)__shfl_down((int)k[0], 1);
     if (i0 >= D) return;
-    if (lane == 0) prev = i0 > 0 ? keys[i0 - 1] : 0xFFFFFFFFu;
-    if (lane == 63) next = i0 + 4 < D ? keys[i0 + 4] : 0xFFFFFFFFu;
+    if (lane == 0) prev = i0 > 0 ? (uint32_t)keys[i0 - 1] : 0xFFFFFFFFu;
+    if (lane == 63) next = i0 + 4 < D ? (uint32_t)keys[i0 + 4] : 0xFFFFFFFFu;
     const uint32_t nt = (uint32_t)num_tiles;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -134,11 +184,18 @@ __global__ __launch_bounds__(256) void ranges_kernel(const uint32_t* __restrict_
 }  // namespace
 
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids, int64_t D,
-                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev) {
+                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev, bool keys16) {
     if (P == 0 || D == 0) return hipSuccess;     // (callers fold a ZeroJob in only when D > 0)
     const bool narrow = vp.gx * vp.gy < 65535;        // tile ids and the sentinel (= number of tiles) fit 16 bits
     const dim3 grid((P + 255) / 256), block(256);
-    if (D > 8 * (int64_t)P) {
+    if (keys16 && !narrow) return hipErrorInvalidValue;
+    if (keys16) {
+        uint16_t* k16 = reinterpret_cast<uint16_t*>(keys);
+        if (D > 8 * (int64_t)P)
+            hipLaunchKernelGGL((emit_kernel<12288, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev);
+        else
+            hipLaunchKernelGGL((emit_kernel<3072, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev);
+    } else if (D > 8 * (int64_t)P) {
         if (narrow) hipLaunchKernelGGL((emit_kernel<12288, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
         else hipLaunchKernelGGL((emit_kernel<6144, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
     } else {
@@ -149,13 +206,18 @@ hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* 
 }
 
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
-                         bool pre_zeroed, const uint32_t* D_dev) {
+                         bool pre_zeroed, const uint32_t* D_dev, bool keys16) {
     if (!pre_zeroed) {
         hipError_t e = launch_zero(ranges, sizeof(uint2) * (size_t)num_tiles, s);
         if (e != hipSuccess) return e;
     }
     if (D == 0) return hipSuccess;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((D + 1023) / 1024)), dim3(256), 0, s, keys, D, ranges, num_tiles, D_dev);
+    const dim3 grid((unsigned)((D + 1023) / 1024)), block(256);
+    if (keys16)
+        hipLaunchKernelGGL(ranges_kernel<uint16_t>, grid, block, 0, s, reinterpret_cast<const uint16_t*>(keys), D, ranges, num_tiles,
+                           D_dev);
+    else
+        hipLaunchKernelGGL(ranges_kernel<uint32_t>, grid, block, 0, s, keys, D, ranges, num_tiles, D_dev);
     return hipGetLastError();
 }
 

@@ -336,7 +336,10 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch /* SortScratch(n) */,
                             hipStream_t s, bool pre_zeroed = false, uint32_t* n_valid_dev = nullptr,
-                            const uint32_t* n_dev = nullptr);
+                            const uint32_t* n_dev = nullptr, bool keys16 = false);
+// keys16: keys_in / keys_out hold uint16 keys (tile ids below 65536; 6 instead of 8 bytes per pair and pass); allowed when
+// radix_sort_keys16_ok(n, begin_bit, end_bit)
+bool radix_sort_keys16_ok(int64_t n, int begin_bit, int end_bit);
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words);
 bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit);
 
@@ -355,10 +358,12 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and b
 // binning.hip
 // D_dev (optional, device word): the instance count when the host does not know it yet (speculative stage 2); D is then the
 // CAPACITY the grids and the geometry are sized for
+// keys16: the key arrays hold uint16 tile ids (grids of fewer than 65535 tiles)
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
-                       int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0}, const uint32_t* D_dev = nullptr);
+                       int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0}, const uint32_t* D_dev = nullptr,
+                       bool keys16 = false);
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
-                         bool pre_zeroed = false, const uint32_t* D_dev = nullptr);
+                         bool pre_zeroed = false, const uint32_t* D_dev = nullptr, bool keys16 = false);
 int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value
 int set_blend_granularity(int mode);      // blend.hip: 0 = by tile count, 1 = coarse, 2 = fine (16 waves per tile)
 int set_forward_variant(int v);           // blend.hip: 0 = default, 1 quadrant lists, 2 tile, 3 | 4 strip lists; returns the previous

@@ -199,8 +199,10 @@ __device__ __forceinline__ int64_t elem_index(int64_t chunk_base, int w, int r, 
 // rendered) — they are neither counted here nor written by the scatter, so the pass's output holds only the survivors, in
 // stable order — and the scatter publishes their number; the later passes take their element count from that device word
 // (n_ptr) and run over the survivors only: their grids are still sized for the upper bound, surplus blocks leave at once.
-template <int ITEMS, bool DROP = false>
-__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
+// KeyT: uint32_t, or uint16_t for the tile sort whenever the tile ids (and the sentinel) fit 16 bits — 6 instead of 8 bytes per
+// pair and pass; the keys sit in uint16 arrays in HBM and are widened in registers / LDS.
+template <int ITEMS, bool DROP = false, typename KeyT = uint32_t>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
                                                                   int shift, uint32_t mask, int64_t nblocks,
                                                                   uint32_t* __restrict__ hist,
                                                                   uint32_t* __restrict__ gsum, int gsize, int ngroups,
@@ -214,23 +216,26 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const uint32_t
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (ITEMS % 4 == 0 && chunk_base + (int64_t)SORT_THREADS * ITEMS <= n) {
+    constexpr int KPV = 16 / (int)sizeof(KeyT);            // keys per 16-byte load
+    if (ITEMS % KPV == 0 && chunk_base + (int64_t)SORT_THREADS * ITEMS <= n) {
         // a full chunk: the block only needs the chunk's digit counts, whatever thread sees which key — 16-byte loads
         const uint4* kv = reinterpret_cast<const uint4*>(keys + chunk_base);
 #pragma unroll
-        for (int r = 0; r < ITEMS / 4; ++r) {
+        for (int r = 0; r < ITEMS / KPV; ++r) {
             const uint4 v = kv[r * SORT_THREADS + threadIdx.x];
-            const uint32_t k4[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (!DROP || k4[j] != 0xFFFFFFFFu) atomicAdd(&s_hist[(k4[j] >> shift) & mask], 1u);
+            for (int j = 0; j < KPV; ++j) {
+                const uint32_t k = sizeof(KeyT) == 4 ? w4[j] : ((w4[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+                if (!DROP || k != 0xFFFFFFFFu) atomicAdd(&s_hist[(k >> shift) & mask], 1u);
+            }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
             if (i < n) {
-                const uint32_t k = keys[i];
+                const uint32_t k = (uint32_t)keys[i];
                 if (!DROP || k != 0xFFFFFFFFu) atomicAdd(&s_hist[(k >> shift) & mask], 1u);
             }
         }
@@ -285,10 +290,10 @@ __global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ 
     }
 }
 
-template <bool STAGED, int ITEMS, bool DROP = false>
-__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+template <bool STAGED, int ITEMS, bool DROP = false, typename KeyT = uint32_t>
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
-                                                                     uint32_t* __restrict__ keys_out,
+                                                                     KeyT* __restrict__ keys_out,
                                                                      uint32_t* __restrict__ vals_out, int64_t n,
                                                                      int shift, uint32_t mask, int64_t nblocks,
                                                                      const uint32_t* __restrict__ hist_scanned,
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-        key[r] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        key[r] = i < n ? (uint32_t)keys_in[i] : 0xFFFFFFFFu;
         const bool valid = i < n && (!DROP || key[r] != 0xFFFFFFFFu);      // DROP: not-rendered Gaussians leave the sort here
         val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
         const uint32_t d = (key[r] >> shift) & mask;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
             if (i < n && (!DROP || key[r] != 0xFFFFFFFFu)) {
                 const uint32_t d = (key[r] >> shift) & mask;
                 const uint32_t pos = s_cnt[w][d] + rank[r];
-                keys_out[pos] = key[r];
+                keys_out[pos] = (KeyT)key[r];
                 vals_out[pos] = val[r];
             }
         }
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const uint3
         if (j < nvalid) {
             const uint32_t k = s_key[j];
             const uint32_t pos = (uint32_t)j + s_delta[(k >> shift) & mask];
-            keys_out[pos] = k;
+            keys_out[pos] = (KeyT)k;
             vals_out[pos] = s_val[j];
         }
     }
@@ -759,6 +764,13 @@ bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit) {
     return use_classic_sort() && !onesweep && !scan_table && passes <= 4 && staged;
 }
 
+// may radix_sort_pairs(..., keys16 = true) be used for this sort?  (16-bit key arrays: grouped, staged configurations only;
+// MSGS_SORT_KEYS32=1 keeps 32-bit keys for A/B runs)
+bool radix_sort_keys16_ok(int64_t n, int begin_bit, int end_bit) {
+    static const bool off = [] { const char* e = getenv("MSGS_SORT_KEYS32"); return e && e[0] == '1'; }();
+    return !off && end_bit <= 16 && radix_sort_supports_device_count(n, begin_bit, end_bit);
+}
+
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {
     if (n <= 0) return false;
     int passes = passes_for(begin_bit, end_bit);
@@ -778,22 +790,64 @@ namespace {
 __global__ void store_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 
 // one grouped pass (histogram + scatter) with ITEMS keys per thread; drop / n_ptr / n_out: compaction (radix_hist_kernel)
-template <int ITEMS>
-void launch_grouped_pass(const uint32_t* src_k, const uint32_t* src_v, uint32_t* dst_k, uint32_t* dst_v, int64_t n, int shift,
+template <int ITEMS, typename KeyT = uint32_t>
+void launch_grouped_pass(const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v, int64_t n, int shift,
                          uint32_t mask, int64_t nb, uint32_t* hist, uint32_t* gs, int gsize, int ngroups, bool drop,
                          const uint32_t* n_ptr, uint32_t* n_out, hipStream_t s) {
     const dim3 grid((unsigned)nb), block(SORT_THREADS);
     if (drop) {
-        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, true>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
-                           (const uint32_t*)nullptr);
-        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, true>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, true, KeyT>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
+                           ngroups, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, true, KeyT>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
                            mask, nb, hist, gs, gsize, ngroups, false, (const uint32_t*)nullptr, n_out);
     } else {
-        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, false>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
-                           n_ptr);
-        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, false>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                           mask, nb, hist, gs, gsize, ngroups, false, n_ptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, false, KeyT>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
+                           ngroups, n_ptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, false, KeyT>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
+                           shift, mask, nb, hist, gs, gsize, ngroups, false, n_ptr, (uint32_t*)nullptr);
     }
+}
+
+// The tile sort with 16-bit keys (grouped, staged configurations; no compaction): the same passes as radix_sort_pairs over
+// uint16 key arrays.  keys_in / keys_out / the alternate key buffer are addressed as uint16 (the caller's 4-byte-per-key
+// buffers are simply half used).
+hipError_t radix_sort_pairs_u16(uint16_t* keys_in, uint32_t* vals_in, uint16_t* keys_out, uint32_t* vals_out, int64_t n,
+                                int passes, int begin_bit, int end_bit, const GroupGeom& G, uint16_t* keys_alt, uint32_t* vals_alt,
+                                uint32_t* hist, uint32_t* gsum_all, const uint32_t* n_dev, hipStream_t s) {
+    const uint16_t* src_k = keys_in;
+    const uint32_t* src_v = vals_in;
+    int next_shift = begin_bit;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = next_shift;
+        const int left = end_bit - shift;
+        const int bits = (left + (passes - p) - 1) / (passes - p);
+        next_shift = shift + bits;
+        const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << (bits > 0 ? bits : 1)) - 1u);
+        const bool to_out = ((passes - 1 - p) % 2) == 0;
+        uint16_t* dst_k = to_out ? keys_out : keys_alt;
+        uint32_t* dst_v = to_out ? vals_out : vals_alt;
+        uint32_t* gs = gsum_all + (size_t)p * 256 * G.ngroups;
+        const dim3 grid((unsigned)G.nb), block(SORT_THREADS);
+        if (G.big && G.scanned) {
+            hipLaunchKernelGGL((radix_hist_kernel<16, false, uint16_t>), grid, block, 0, s, src_k, n, shift, mask, G.nb, hist, gs,
+                               G.gsize, G.ngroups, n_dev);
+            hipLaunchKernelGGL(group_scan_kernel, dim3((unsigned)G.ngroups + 1), dim3(256), 0, s, gs, G.ngroups, hist, G.gsize, G.nb);
+            hipLaunchKernelGGL((radix_scatter_kernel<true, 16, false, uint16_t>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
+                               shift, mask, G.nb, hist, gs, G.gsize, G.ngroups, true, n_dev, (uint32_t*)nullptr);
+        } else if (G.big) {
+            launch_grouped_pass<16, uint16_t>(src_k, src_v, dst_k, dst_v, n, shift, mask, G.nb, hist, gs, G.gsize, G.ngroups, false,
+                                              n_dev, nullptr, s);
+        } else if (G.mid) {
+            launch_grouped_pass<8, uint16_t>(src_k, src_v, dst_k, dst_v, n, shift, mask, G.nb, hist, gs, G.gsize, G.ngroups, false,
+                                             n_dev, nullptr, s);
+        } else {
+            launch_grouped_pass<SORT_ITEMS, uint16_t>(src_k, src_v, dst_k, dst_v, n, shift, mask, G.nb, hist, gs, G.gsize, G.ngroups,
+                                                      false, n_dev, nullptr, s);
+        }
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    return hipGetLastError();
 }
 }  // namespace
 
@@ -806,7 +860,7 @@ void launch_grouped_pass(const uint32_t* src_k, const uint32_t* src_v, uint32_t*
 // radix_sort_supports_device_count).
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s, bool pre_zeroed,
-                            uint32_t* n_valid_dev, const uint32_t* n_dev) {
+                            uint32_t* n_valid_dev, const uint32_t* n_dev, bool keys16) {
     if (n <= 0) {
         if (n_valid_dev) hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, n_valid_dev, 0u);
         return hipSuccess;
@@ -846,6 +900,12 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
         const int hb = (int)(nb < 1024 ? nb : 1024);
         hipLaunchKernelGGL(radix_hist_all_kernel, dim3(hb), dim3(256), 0, s, keys_in, n, begin_bit, end_bit, passes,
                            digit_hist);
+    }
+    if (keys16) {          // (the caller asked radix_sort_keys16_ok first: grouped + staged, no compaction)
+        if (!grouped || !staged || n_valid_dev || end_bit > 16) return hipErrorInvalidValue;
+        return radix_sort_pairs_u16(reinterpret_cast<uint16_t*>(keys_in), vals_in, reinterpret_cast<uint16_t*>(keys_out), vals_out,
+                                    n, passes, begin_bit, end_bit, G, reinterpret_cast<uint16_t*>(keys_alt), vals_alt, hist,
+                                    gsum_all, n_dev, s);
     }
     static const bool no_compact = [] { const char* e = getenv("MSGS_SORT_NO_COMPACT"); return e && e[0] == '1'; }();
     const bool compact = n_valid_dev != nullptr && grouped && staged && !G.scanned && !no_compact;
