@@ -201,9 +201,11 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g,
                         void* scratch, size_t scratch_bytes,
                         void* image_state, size_t image_bytes,
                         float* out_color, float* out_acc_pixel_size, float* out_depth,
-                        void* grad_records, size_t grad_records_bytes,
+                        void* grad_records, size_t grad_records_bytes, int32_t backward_follows,
                         const msgs_timing_t* timing, void* stream);
-/* grad_records (optional, NULL = none): the buffer the caller will pass to msgs_backward as `scratch`
+/* backward_follows: non-zero when msgs_backward will be called on this forward's state — the forward then also leaves the
+ * backward's heaviest-first tile launch order behind (one small kernel).  Independent of grad_records.
+ * grad_records (optional, NULL = none): the buffer the caller will pass to msgs_backward as `scratch`
  * (>= msgs_backward_scratch_bytes(P)).  The per-Gaussian gradient records in it have to start from zero; the blend
  * kernel of the forward clears them on the side (it is instruction-bound, the stores are free there), and a
  * msgs_backward called with msgs_grads_t.scratch_is_clear = 1 saves the fill launch. */
@@ -322,7 +324,7 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* gaussians, int
                  void* geom, size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning,
                  size_t binning_bytes, void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes,
                  float* out_color, float* out_acc_pixel_size, float* out_depth, void* grad_records,
-                 size_t grad_records_bytes, int64_t* num_instances_host, int32_t* stage2_done,
+                 size_t grad_records_bytes, int32_t backward_follows, int64_t* num_instances_host, int32_t* stage2_done,
                  const msgs_timing_t* timing, void* stream);
 
 /* ---- forward without the host wait: several views in flight from one host thread -------------------------------------
@@ -344,7 +346,8 @@ int msgs_forward_launch(const msgs_view_t* view, const msgs_gaussians_t* gaussia
                         void* geom, size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning,
                         size_t binning_bytes, void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes,
                         float* out_color, float* out_acc_pixel_size, float* out_depth, void* grad_records,
-                        size_t grad_records_bytes, msgs_status_t* status, const msgs_timing_t* timing, void* stream);
+                        size_t grad_records_bytes, int32_t backward_follows, msgs_status_t* status,
+                        const msgs_timing_t* timing, void* stream);
 int msgs_forward_finish(msgs_status_t* status, int64_t* num_instances_host, int32_t* stage2_done);
 
 /* msgs_preprocess_only: the per-Gaussian stage alone (frustum cull, multi-scale filters, projection) — radii and

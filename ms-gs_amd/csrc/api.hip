@@ -126,12 +126,14 @@ struct SpecStage2 {
     void* image; size_t image_bytes;
     float* out_color; float* out_acc_ps; float* out_depth;
     void* grad_records; size_t grad_records_bytes;
+    int backward_follows;
     int launched_rc;           // out: status of the speculative launch
 };
 int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes, int64_t D,
                         void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes, void* image_v,
                         size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
-                        size_t grad_records_bytes, const msgs_timing_t* timing, void* stream, const uint32_t* D_dev);
+                        size_t grad_records_bytes, int backward_follows, const msgs_timing_t* timing, void* stream,
+                        const uint32_t* D_dev);
 
 // The instance count D comes back through three pinned, device-mapped host words {D, flags, ticket} that a kernel writes
 // itself and the host polls: no copy command, no interrupt-driven wait (a blocking hipStreamSynchronize wakes up tens of
@@ -255,7 +257,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
         spec->launched_rc = forward_stage2_impl(view, g, geom_v, geom_bytes, spec->capacity, spec->binning, spec->binning_bytes,
                                                 spec->scratch2, spec->scratch2_bytes, spec->image, spec->image_bytes,
                                                 spec->out_color, spec->out_acc_ps, spec->out_depth, spec->grad_records,
-                                                spec->grad_records_bytes, timing, stream, clamped_dev);
+                                                spec->grad_records_bytes, spec->backward_follows, timing, stream, clamped_dev);
     return MSGS_OK;
 }
 
@@ -337,7 +339,8 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
 // mode and the sort geometry can take its count from a device word (MSGS_NO_SPECULATIVE_STAGE2=1: never)
 static bool prepare_spec(const msgs_view_t* view, const msgs_gaussians_t* g, void* binning, size_t binning_bytes, void* scratch2,
                          size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color, float* out_acc_ps,
-                         float* out_depth, void* grad_records, size_t grad_records_bytes, SpecStage2& spec) {
+                         float* out_depth, void* grad_records, size_t grad_records_bytes, int backward_follows,
+                         SpecStage2& spec) {
     static const bool no_spec = [] { const char* e = getenv("MSGS_NO_SPECULATIVE_STAGE2"); return e && e[0] == '1'; }();
     if (no_spec || view->debug || g->P <= 0 || !binning || !scratch2 || !image || !out_color || !out_acc_ps || !out_depth ||
         view->image_width <= 0 || view->image_height <= 0)
@@ -354,6 +357,7 @@ static bool prepare_spec(const msgs_view_t* view, const msgs_gaussians_t* g, voi
     spec.image = image; spec.image_bytes = image_bytes;
     spec.out_color = out_color; spec.out_acc_ps = out_acc_ps; spec.out_depth = out_depth;
     spec.grad_records = grad_records; spec.grad_records_bytes = grad_records_bytes;
+    spec.backward_follows = backward_follows;
     spec.launched_rc = MSGS_OK;
     return true;
 }
@@ -392,12 +396,12 @@ int msgs_forward_launch(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                         size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
                         void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
                         float* out_acc_ps, float* out_depth, void* grad_records, size_t grad_records_bytes,
-                        msgs_status_t* status, const msgs_timing_t* timing, void* stream) {
+                        int32_t backward_follows, msgs_status_t* status, const msgs_timing_t* timing, void* stream) {
     if (!view || !g || !status) return MSGS_ERR_INVALID_ARG;
     if (status->launched) return MSGS_ERR_INVALID_ARG;          // one launch per handle at a time
     SpecStage2 spec{};
     const bool use_spec = prepare_spec(view, g, binning, binning_bytes, scratch2, scratch2_bytes, image, image_bytes, out_color,
-                                       out_acc_ps, out_depth, grad_records, grad_records_bytes, spec);
+                                       out_acc_ps, out_depth, grad_records, grad_records_bytes, backward_follows, spec);
     int rc = forward_stage1_launch(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, timing, stream,
                                    use_spec ? &spec : nullptr, status->sb, status->pend);
     if (rc) return rc;
@@ -425,13 +429,14 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
                  size_t geom_bytes, void* scratch1, size_t scratch1_bytes, void* binning, size_t binning_bytes,
                  void* scratch2, size_t scratch2_bytes, void* image, size_t image_bytes, float* out_color,
                  float* out_acc_ps, float* out_depth, void* grad_records, size_t grad_records_bytes,
-                 int64_t* num_instances_host, int32_t* stage2_done, const msgs_timing_t* timing, void* stream) {
+                 int32_t backward_follows, int64_t* num_instances_host, int32_t* stage2_done, const msgs_timing_t* timing,
+                 void* stream) {
     if (!stage2_done) return MSGS_ERR_INVALID_ARG;
     *stage2_done = 0;
     if (!view || !g) return MSGS_ERR_INVALID_ARG;
     SpecStage2 spec{};
     bool use_spec = prepare_spec(view, g, binning, binning_bytes, scratch2, scratch2_bytes, image, image_bytes, out_color,
-                                 out_acc_ps, out_depth, grad_records, grad_records_bytes, spec);
+                                 out_acc_ps, out_depth, grad_records, grad_records_bytes, backward_follows, spec);
     int rc = forward_stage1_impl(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, num_instances_host,
                                  timing, stream, use_spec ? &spec : nullptr);
     if (rc) return rc;
@@ -447,8 +452,8 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
     if (!binning || binning_bytes < msgs_binning_bytes(D, W, H)) return MSGS_OK;
     if (D > 0 && (!scratch2 || scratch2_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_OK;
     rc = msgs_forward_stage2(view, g, geom, geom_bytes, D, binning, binning_bytes, scratch2, scratch2_bytes, image,
-                             image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, timing,
-                             stream);
+                             image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, backward_follows,
+                             timing, stream);
     if (rc) return rc;
     *stage2_done = 1;
     return MSGS_OK;
@@ -470,10 +475,11 @@ int msgs_preprocess_only(const msgs_view_t* view, const msgs_gaussians_t* g, int
 int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes,
                         int64_t D, void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes,
                         void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
-                        void* grad_records, size_t grad_records_bytes, const msgs_timing_t* timing, void* stream) {
+                        void* grad_records, size_t grad_records_bytes, int32_t backward_follows, const msgs_timing_t* timing,
+                        void* stream) {
     return forward_stage2_impl(view, g, geom_v, geom_bytes, D, binning_v, binning_bytes, scratch_v, scratch_bytes, image_v,
-                               image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, timing, stream,
-                               nullptr);
+                               image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, backward_follows,
+                               timing, stream, nullptr);
 }
 
 }  // extern "C"
@@ -484,7 +490,8 @@ namespace {
 int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes, int64_t D,
                         void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes, void* image_v,
                         size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
-                        size_t grad_records_bytes, const msgs_timing_t* timing, void* stream, const uint32_t* D_dev) {
+                        size_t grad_records_bytes, int backward_follows, const msgs_timing_t* timing, void* stream,
+                        const uint32_t* D_dev) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (D < 0 || D > 0xFFFFFFFFll) return MSGS_ERR_TOO_MANY;
@@ -540,7 +547,7 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                                  (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib),
                                  (uint32_t*)(image + IL.tile_last),
                                  grad_records, grad_records ? GRAD_REC_BYTES * (size_t)P : 0, s));
-    if (grad_records)      // a backward will follow: give its one-wave-per-tile kernel a heaviest-first launch order
+    if (backward_follows)  // give the backward's one-wave-per-tile kernel a heaviest-first launch order
         HIP_TRY(launch_tile_order(vp, (const uint32_t*)(image + IL.tile_last), (uint32_t*)(image + IL.tile_order), s));
     tm.end(MSGS_K_BLEND_FWD);
     return debug_sync(view, s);

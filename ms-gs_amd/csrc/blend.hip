@@ -1321,31 +1321,35 @@ static bool bwd_v1(int tiles) {
 // tiles per SIMD in total at 1080p: with tiles dispatched in image order the SIMDs run dry at very different times (measured:
 // the number of running waves falls linearly over the second half of the kernel).  Dispatching the heaviest tiles first
 // leaves only light tiles for the end.  Key = the forward's per-tile traversal length (tile_last), NOT the list length: with
-// early termination the two differ by 2.3x on average and by much more per tile.  One 1024-thread block per XCD run of the
+// early termination the two differ by 2.3x on average and by much more per tile.  One 256-thread block per XCD run of the
 // swizzled order (the tiles of a run stay on their XCD): counting sort into 2048 bins of 8 entries, heaviest first.
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int ORDER_BINS = 2048, ORDER_SHIFT = 3;
 // GLOBAL (one block): one heaviest-first sequence over all tiles, dealt to the XCDs round-robin by the dispatcher (block b ->
 // XCD b % 8): balances the XCDs against each other as well, at the price of the L2 locality of the contiguous runs.
+// (256 threads per block since round 4: a 1024-thread block needs sixteen free wave slots on ONE CU, and with a second view in
+//  flight — host/multi_view.py — it waited 30-45 us for them behind the other view's blend workgroups; four slots are found at once)
+constexpr int ORDER_THREADS = 256, ORDER_PER_THREAD = ORDER_BINS / ORDER_THREADS;
 template <bool GLOBAL>
-__global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const uint32_t* __restrict__ tile_last,
-                                                          uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(int num_tiles, const uint32_t* __restrict__ tile_last,
+                                                                   uint32_t* __restrict__ order) {
     __shared__ uint32_t s_bin[ORDER_BINS];
-    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_wave[ORDER_THREADS / 64];
     const int per = GLOBAL ? num_tiles : num_tiles >> 3, main = GLOBAL ? num_tiles : per << 3;
     const int x = blockIdx.x;                           // XCD run x: swizzled positions = tiles [x * per, (x + 1) * per)
     const int tid = threadIdx.x;
-    for (int b = tid; b < ORDER_BINS; b += 1024) s_bin[b] = 0;
+    for (int b = tid; b < ORDER_BINS; b += ORDER_THREADS) s_bin[b] = 0;
     __syncthreads();
-    for (int j = tid; j < per; j += 1024) {
+    for (int j = tid; j < per; j += ORDER_THREADS) {
         const uint32_t key = min(tile_last[x * per + j] >> ORDER_SHIFT, (uint32_t)(ORDER_BINS - 1));
         atomicAdd(&s_bin[ORDER_BINS - 1 - key], 1u);    // bin 0 = heaviest
     }
     __syncthreads();
-    // exclusive scan of the 2048 bins: two per thread
-    const uint32_t c0 = s_bin[2 * tid], c1 = s_bin[2 * tid + 1];
-    uint32_t v = c0 + c1;
+    // exclusive scan of the 2048 bins: ORDER_PER_THREAD consecutive bins per thread
+    uint32_t c[ORDER_PER_THREAD], v = 0;
+#pragma unroll
+    for (int k = 0; k < ORDER_PER_THREAD; ++k) { c[k] = s_bin[ORDER_PER_THREAD * tid + k]; v += c[k]; }
     const int lane = tid & 63, w = tid >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -1357,19 +1361,19 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const u
     __syncthreads();
     uint32_t base = 0;
     for (int k = 0; k < w; ++k) base += s_wave[k];
-    const uint32_t ex = base + inc - v;
+    uint32_t run = base + inc - v;
     __syncthreads();
-    s_bin[2 * tid] = ex;
-    s_bin[2 * tid + 1] = ex + c0;
+#pragma unroll
+    for (int k = 0; k < ORDER_PER_THREAD; ++k) { s_bin[ORDER_PER_THREAD * tid + k] = run; run += c[k]; }
     __syncthreads();
-    for (int j = tid; j < per; j += 1024) {
+    for (int j = tid; j < per; j += ORDER_THREADS) {
         const uint32_t t = (uint32_t)(x * per + j);
         const uint32_t key = min(tile_last[t] >> ORDER_SHIFT, (uint32_t)(ORDER_BINS - 1));
         const uint32_t pos = atomicAdd(&s_bin[ORDER_BINS - 1 - key], 1u);
         order[x * per + pos] = t;
     }
     if (x == 0) {
-        for (int t = main + tid; t < num_tiles; t += 1024) order[t] = (uint32_t)t;      // ragged tail: identity
+        for (int t = main + tid; t < num_tiles; t += ORDER_THREADS) order[t] = (uint32_t)t;      // ragged tail: identity
         if (tid == 0) order[num_tiles] = TILE_ORDER_MAGIC + (GLOBAL ? 1u : 0u);     // visible to the backward through the stream order
     }
 }
@@ -1384,10 +1388,12 @@ hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, ui
     static const int mode = [] { const char* e = getenv("MSGS_BWD_LPT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
     const int tiles = vp.gx * vp.gy;
     if (mode == 0 || tiles < 8 || !bwd_uses_tile_kernel(tiles)) return hipSuccess;
+    // the fine-grained forward kernels do not write tile_last (and clear the order's validity word): no order from garbage
+    if (g_granularity.load() == 2 || use_fine(tiles, FINE_MAX_TILES_FWD)) return hipSuccess;
     if (mode == 2)
-        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1), dim3(1024), 0, s, tiles, tile_last, tile_order);
+        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1), dim3(ORDER_THREADS), 0, s, tiles, tile_last, tile_order);
     else
-        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(8), dim3(1024), 0, s, tiles, tile_last, tile_order);
+        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(8), dim3(ORDER_THREADS), 0, s, tiles, tile_last, tile_order);
     return hipGetLastError();
 }
 

@@ -234,8 +234,9 @@ def _alloc_grad_records(ctx, P, dev):
     kernel is instruction-bound, the stores are free) — the backward then skips its fill launch.  Not in the verification
     mode, whose scratch is sized by the instance count."""
     ctx.grad_rec = None
-    if _forward_clear and P > 0 and getattr(_caller, "grad_enabled", True) and any(ctx.needs_input_grad) \
-            and not _C.lib.msgs_get_deterministic():
+    # a backward can follow this forward (msgs_forward*: backward_follows — the tile launch order is prepared)
+    ctx.backward_follows = bool(P > 0 and getattr(_caller, "grad_enabled", True) and any(ctx.needs_input_grad))
+    if _forward_clear and ctx.backward_follows and not _C.lib.msgs_get_deterministic():
         ctx.grad_rec = _bytes(_C.lib.msgs_backward_scratch_bytes(P), dev)
     return ctx.grad_rec
 
@@ -334,7 +335,8 @@ class deferred_forward:
 class _PendingForward:
     """State of one launched forward: resolve() -> (geom, binning, image, D), waiting for the count if nobody has yet."""
 
-    def __init__(self, call, status, stream, key, guess, geom, binning, image, outs, grad_rec, keep):
+    def __init__(self, call, status, stream, key, guess, geom, binning, image, outs, grad_rec, keep, backward_follows=False):
+        self.backward_follows = bool(backward_follows)
         self.call, self.status, self.stream, self.key, self.guess = call, status, stream, key, guess
         self.geom, self.binning, self.image, self.outs, self.grad_rec, self.keep = geom, binning, image, outs, grad_rec, keep
         self.state = None
@@ -365,7 +367,8 @@ class _PendingForward:
                                                      _ptr(self.binning), self.binning.numel(), _ptr(scratch2),
                                                      scratch2.numel(), _ptr(self.image), self.image.numel(), _ptr(color),
                                                      _ptr(acc_ps), _ptr(depth), _ptr(grad_rec),
-                                                     grad_rec.numel() if grad_rec is not None else 0, _C.timer_ptr(),
+                                                     grad_rec.numel() if grad_rec is not None else 0,
+                                                     int(self.backward_follows), _C.timer_ptr(),
                                                      C.c_void_p(self.stream.cuda_stream)), "msgs_forward_stage2")
                     del scratch2
             self.state = (self.geom, self.binning, self.image, D)
@@ -385,7 +388,7 @@ def _resolve(state):
     return state.resolve() if isinstance(state, _PendingForward) else state
 
 
-def _forward_impl(call, grad_rec=None):
+def _forward_impl(call, grad_rec=None, backward_follows=False):
     dev, P, W, H = call.device, call.P, call.W, call.H
     lib = _C.lib
     key = (dev.index, P, W, H, call.view.filter_small, call.view.filter_large)
@@ -422,11 +425,12 @@ def _forward_impl(call, grad_rec=None):
                                                  _ptr(binning), n_bin, _ptr(scratch2), n_s2,
                                                  _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),
                                                  _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
-                                                 status, _C.timer_ptr(), stream), "msgs_forward_launch")
+                                                 int(backward_follows), status, _C.timer_ptr(), stream), "msgs_forward_launch")
             except Exception:
                 _give_status(status)
                 raise
-            state = _PendingForward(call, status, cur, key, guess, geom, binning, image, (color, acc_ps, depth), grad_rec, keep)
+            state = _PendingForward(call, status, cur, key, guess, geom, binning, image, (color, acc_ps, depth), grad_rec, keep,
+                                    backward_follows)
             pending.append(state)
             return color, acc_ps, depth, radii, pixel_sizes, state
         D, done = C.c_int64(0), C.c_int32(0)
@@ -434,7 +438,7 @@ def _forward_impl(call, grad_rec=None):
                                   _ptr(geom), n_geom, _ptr(scratch1), n_s1,
                                   _ptr(binning), n_bin, _ptr(scratch2), n_s2,
                                   _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),
-                                  _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
+                                  _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0, int(backward_follows),
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
         _last_instances[key] = max(D, (guess + D) // 2) if guess is not None else D
@@ -446,7 +450,7 @@ def _forward_impl(call, grad_rec=None):
                                              _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
                                              _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),
                                              _ptr(grad_rec), grad_rec.numel() if grad_rec is not None else 0,
-                                             _C.timer_ptr(), stream), "msgs_forward_stage2")
+                                             int(backward_follows), _C.timer_ptr(), stream), "msgs_forward_stage2")
     return color, acc_ps, depth, radii, pixel_sizes, (geom, binning, image, D)
 
 
@@ -476,7 +480,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         call = _Call(raster_settings, means3D, _opt(sh), _opt(colors_precomp), opacities, _opt(scales),
                      _opt(rotations), _opt(cov3Ds_precomp), _opt(max_pixel_sizes), _opt(min_pixel_sizes),
                      _opt(occ_multiplier), _opt(dc_delta), _opt(base_mask))
-        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device))
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device), ctx.backward_follows)
         ctx.call = call
         ctx.state = state
         ctx.radii = radii
@@ -687,7 +691,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         call = _Call(raster_settings, xyz, None, None, opacity_raw, scaling_raw, rotation_raw, None,
                      _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
                      _opt(base_mask), raw_features=(features_dc, features_rest))
-        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device))
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device), ctx.backward_follows)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
         _snapshot_sinks(ctx, (xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw))
@@ -757,7 +761,7 @@ class _RasterizeGaussiansChained(torch.autograd.Function):
         call = _Call(raster_settings, xyz, _opt(shs), None, opacities, scales, rotations, None,
                      _opt(max_pixel_sizes), _opt(min_pixel_sizes), _opt(occ_multiplier), _opt(dc_delta),
                      _opt(base_mask), raw_features=(features_dc, features_rest), rotations_raw=rotation_raw)
-        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device))
+        color, acc_ps, depth, radii, pixel_sizes, state = _forward_impl(call, _alloc_grad_records(ctx, call.P, call.device), ctx.backward_follows)
         ctx.call, ctx.state, ctx.radii = call, state, radii
         ctx.shapes = (means2D.shape, features_dc.shape, features_rest.shape, opacity_raw.shape)
         _snapshot_sinks(ctx, (xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw))

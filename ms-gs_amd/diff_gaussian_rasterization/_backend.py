@@ -108,21 +108,21 @@ def _load():
     lib.msgs_set_forward_variant.argtypes = [C.c_int32]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
-                                 vp, vp, vp, vp, sz, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
+                                 vp, vp, vp, vp, sz, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
     lib.msgs_status_create.restype = C.c_int
     lib.msgs_status_create.argtypes = [C.POINTER(vp)]
     lib.msgs_status_destroy.restype = C.c_int
     lib.msgs_status_destroy.argtypes = [vp]
     lib.msgs_forward_launch.restype = C.c_int
     lib.msgs_forward_launch.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
-                                        vp, vp, vp, vp, sz, vp, C.POINTER(Timing), vp]
+                                        vp, vp, vp, vp, sz, C.c_int32, vp, C.POINTER(Timing), vp]
     lib.msgs_forward_finish.restype = C.c_int
     lib.msgs_forward_finish.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.msgs_preprocess_only.restype = C.c_int
     lib.msgs_preprocess_only.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp]
     lib.msgs_forward_stage2.restype = C.c_int
     lib.msgs_forward_stage2.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, sz, C.c_int64, vp, sz, vp, sz,
-                                        vp, sz, vp, vp, vp, vp, sz, C.POINTER(Timing), vp]
+                                        vp, sz, vp, vp, vp, vp, sz, C.c_int32, C.POINTER(Timing), vp]
     lib.msgs_backward.restype = C.c_int
     lib.msgs_backward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, sz, C.c_int64, vp, sz, vp, sz,
                                   vp, vp, sz, C.POINTER(Grads), C.POINTER(Timing), vp]
