@@ -431,6 +431,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true")
+    ap.add_argument("--no-two-view", action="store_true",
+                    help="skip the informational two-views-in-flight block (tools/profile_round.sh: its co-resident kernels "
+                         "would enter the per-kernel averages of the profile)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -832,16 +835,23 @@ def main():
             name_of = {"blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_tile"}[dom]
             here = csrc_sha256()
 
-            def committed(fname):
-                try:
-                    j_ = json.load(open(os.path.join(ROOT, "profiles", fname)))
-                    if j_.get("csrc_sha256") != here or (P, W, H) != (1_000_000, 1920, 1080) or world != 1:
-                        return None
-                    hits = [v for k, v in j_["kernels"].items() if k.startswith(name_of)]
-                    return max(hits, key=lambda v: v.get("launches", 1)) if hits else None
-                except Exception:
-                    return None
-            tr = committed("traffic_r3.json")
+            def committed(prefix):
+                """the newest profiles/<prefix>_rNN.json whose kernel-source hash matches this tree"""
+                import glob
+                for fname in sorted(glob.glob(os.path.join(ROOT, "profiles", prefix + "_r*.json")), reverse=True):
+                    try:
+                        j_ = json.load(open(fname))
+                        if j_.get("csrc_sha256") != here or (P, W, H) != (1_000_000, 1920, 1080) or world != 1:
+                            continue
+                        hits = [v for k, v in j_["kernels"].items() if k.startswith(name_of)]
+                        if hits:
+                            committed.source = os.path.relpath(fname, ROOT)
+                            return max(hits, key=lambda v: v.get("launches", 1))
+                    except Exception:
+                        continue
+                return None
+            committed.source = None
+            tr = committed("traffic")
             traffic = int(tr["hbm_bytes"]) if tr else None
             # what actually bounds the kernel (DESIGN.md 5.4): INSTRUCTION ISSUE.  One model for both blend kernels: per
             # launch, wave-instructions by class from the committed PMC summary (same hash rule) x the calibrated issue cost
@@ -850,7 +860,8 @@ def main():
             # LDS 4.0 per instruction per SIMD at the kernels' access widths) / (1024 SIMDs x 2.4 GHz).  The VALU mix per
             # kernel is counted in the ISA of the inner loops (fractions of plain / half-rate / transcendental).
             valu = None
-            sq = committed("sq_r3.json")
+            sq = committed("sq")
+            sq_source = committed.source
             if sq and "SQ_INSTS_VALU" in sq:
                 mix = {"blend_fwd": (18.5 / 23.5, 4.0 / 23.5, 1.0 / 23.5),
                        "blend_bwd": (0.64, 0.31, 0.05)}[dom]
@@ -865,7 +876,7 @@ def main():
                         "valu_only_floor_ms": round(nv * cyc_v / (1024 * 2.4e9) * 1e3, 4),
                         "model": "sum over classes of wave-instructions x calibrated cycles per instruction per SIMD "
                                  "(VALU mix, scalar 2.0, LDS 4.0) / (1024 SIMDs x 2.4 GHz)",
-                        "source": "profiles/sq_r3.json + profiles/r2_valu_calibration.txt"}
+                        "source": f"{sq_source} + profiles/r2_valu_calibration.txt"}
             # every SURVEY 8(d) row against HBM, from the same HIP-event kernel times: the HBM-bound kernels read against
             # HBM, the issue-bound blend pair against both
             S_sh = 12 * 16
@@ -938,8 +949,8 @@ def main():
             # informational: the same workload with TWO views in flight (host/multi_view.py; review item 1).  Eight copies of the
             # C3 view per sweep, so a view is the same work as a headline step; `value` above stays one view per step.
             try:
-                result["two_view_pipeline"] = two_view_timing(pc, cam, bg, dL, settings, W, H, args.warmup,
-                                                              (result.get("roofline") or {}).get("whole_step"))
+                result["two_view_pipeline"] = None if args.no_two_view else two_view_timing(
+                    pc, cam, bg, dL, settings, W, H, args.warmup, (result.get("roofline") or {}).get("whole_step"))
             except Exception as e:
                 result["two_view_pipeline"] = {"error": repr(e)}
             # informational: one whole training iteration (train.py:202-218,239-250,416-418) on the same workload —
