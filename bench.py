@@ -348,6 +348,30 @@ def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8
         out["forward_ms_per_view"] = timed(lambda: pipe.render_views(cams, pc, PIPE, bg, **settings))
         out["fused_forward_ms_per_view"] = timed(lambda: pipe.render_views(cams, pc, PIPE, bg, render_fn=render_fused,
                                                                            share_getters=False, **settings))
+    # the same per pyramid level k = 1..6 of the scene (what pyramid_ms / render_forward_ms report for the serial call pattern):
+    # at the low levels a view is mostly latency-bound per-Gaussian and binning kernels, which two lanes overlap almost fully
+    try:
+        import scenes as _sc
+        lv_fb, lv_f, lv_sizes = [out["fwd_bwd_ms_per_view"]], [out["forward_ms_per_view"]], [[W, H]]
+        for k in range(1, 7):
+            Wk, Hk = int(W / 2 ** k), int(H / 2 ** k)
+            ck = [_sc.front_camera(Wk, Hk).to(cam.world_view_transform.device)] * views
+            dk = _sc.grad_seed(Wk, Hk, 40 + k).to(cam.world_view_transform.device)
+
+            def piped_k():
+                zero()
+                pipe.train_views(ck, pc, PIPE, bg, lambda i, pkg: pkg["render"].backward(dk), **settings)
+            lv_fb.append(timed(piped_k))
+            zero()
+            with torch.no_grad():
+                lv_f.append(timed(lambda: pipe.render_views(ck, pc, PIPE, bg, **settings)))
+            lv_sizes.append([Wk, Hk])
+        out["pyramid"] = {"levels": lv_sizes, "fwd_bwd_ms_per_view": lv_fb, "forward_ms_per_view": lv_f,
+                          "what": "two lanes per pyramid level k = 0..6, training settings (compare pyramid_ms.ms and "
+                                  "render_forward_ms of the serial call pattern)"}
+    except Exception as e:      # informational
+        out["pyramid"] = {"error": repr(e)}
+    zero()
     out["value_fwd_bwd"] = round(W * H / 1e6 / (out["fwd_bwd_ms_per_view"] * 1e-3), 3)
     out["unit"] = "Mpixels/s"
     if whole_step and whole_step.get("algorithmic_bytes"):
