@@ -56,7 +56,7 @@ _GC_DEFAULT = gc.isenabled()
 def quiet_gc():
     """Timed regions run with Python's cyclic garbage collector paused: a full collection of this process's heap takes 30-70 ms
     and lands, at a position fixed by the allocation count, inside some timed window of ~10 ms (seen as a 5.9 ms 'step' at one
-    pyramid level; tools/diag_level_jitter2.py).  Interpreter housekeeping, not part of a step.  The collection itself is done by
+    pyramid level; tools/diag_host_stalls.py).  Interpreter housekeeping, not part of a step.  The collection itself is done by
     settle_gc() BEFORE the warm-up steps, never between warm-up and timing: a 35 ms pause there lets the GPU clock down and the
     first timed steps pay for the ramp (measured: +0.07 ms per step over a 20-step region).  The collector is switched back on
     when the region ends (host memory must not grow across the many timed loops of one run)."""
