@@ -1,7 +1,7 @@
-"""Which part of a step's HOST time holds the sporadic 5-55 ms stall of the un-synchronised step loops (diag_level_jitter2):
+"""Which part of a step's HOST time holds the sporadic 5-55 ms stall of the un-synchronised step loops :
 the C-ABI calls (msgs_forward / msgs_backward, i.e. hipLaunchKernel and friends) or the torch side (allocator, autograd)?
 Wraps the two entry points with a host timer and reads the caching allocator's hipMalloc / hipFree counters per step.
-python tools/diag_level_jitter3.py [reps]"""
+python tools/diag_host_stalls.py [reps]"""
 import gc, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
