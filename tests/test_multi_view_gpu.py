@@ -173,3 +173,20 @@ def test_multi_view_step_exchange_on_one_rank_equals_the_serial_mean():
             assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad / len(cams)), n
         for i in range(len(cams)):
             assert torch.equal(vs[i].grad, ref_m2[i])
+
+
+def test_randomised_sweeps_stay_bit_identical():
+    """tools/soak_pipeline.py in small: random views, pyramid levels, lane counts, entries and accumulation modes, first-frame and
+    guess-exceeded paths mixed in — every sweep equal to the serial loop bit for bit (stream-ordering / allocator-reuse regressions
+    show up here)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # in-process (a child process must not be started from a process that has initialised the GPU)
+    sys.argv, argv = [os.path.join(root, "tools", "soak_pipeline.py"), "80", "80000"], sys.argv
+    try:
+        with pytest.raises(SystemExit) as e:
+            exec(compile(open(sys.argv[0]).read(), sys.argv[0], "exec"), {"__name__": "__main__", "__file__": sys.argv[0]})
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
