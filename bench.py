@@ -440,6 +440,19 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
             opt.step()
             opt.zero_grad(set_to_none=True)
     out["ms_per_iteration_torch_composition"] = round(timed(torch_composition), 4)
+    # the same GPU pieces with ONE optimizer step over 8 views, two in flight (train_step.fused_train_iteration_views)
+    try:
+        from multi_view import ViewPipeline
+        from train_step import fused_train_iteration_views
+        model = SyntheticGaussians(scene, dev)
+        opt = FusedAdam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
+        vp_ = ViewPipeline(dev)
+        cams8, gts8 = [cam] * 8, [gt] * 8
+        t_ = timed(lambda: fused_train_iteration_views(model, opt, vp_, cams8, gts8, PIPE, bg, **settings))
+        out["ms_per_view_8_views_per_optimizer_step"] = round(t_ / 8, 4)
+        del model, opt
+    except Exception as e:      # informational
+        out["ms_per_view_8_views_per_optimizer_step"] = repr(e)
     out["note"] = "C3 scene, fixed U(0,1) target, lambda_dssim 0.2, level 0, statistics on; informational"
     return out
 
@@ -738,13 +751,18 @@ def main():
 
             def step_multi(k):
                 mv.step(vp_, mine, PIPE, bg, bwd_, **settings)
-            step_multi(0)
-            tm_ = timed_region(step_multi, args.steps) / args.steps
-            two_views = {"views_per_rank_per_step": len(mine), "ms_per_optimizer_step": round(1e3 * tm_, 4),
-                         "fwd_bwd_ms_per_view": round(1e3 * tm_ / len(mine), 4),
-                         "value": round(n_views * (W * H / 1e6) / tm_, 3), "unit": "Mpixels/s",
-                         "what": "one optimizer step over all 8 C4 views: each rank renders its 8 / N views through the two-lane "
-                                 "pipeline into one flat bucket, ONE dense all-reduce per step"}
+            try:        # informational: a failure here must not cost the scaling line (the ranks run the same code on the same
+                step_multi(0)   # shapes, so a local failure is the same on every rank and nobody is left inside a collective)
+                tm_ = timed_region(step_multi, args.steps) / args.steps
+                two_views = {"views_per_rank_per_step": len(mine), "ms_per_optimizer_step": round(1e3 * tm_, 4),
+                             "fwd_bwd_ms_per_view": round(1e3 * tm_ / len(mine), 4),
+                             "value": round(n_views * (W * H / 1e6) / tm_, 3), "unit": "Mpixels/s",
+                             "what": "one optimizer step over all 8 C4 views: each rank renders its 8 / N views through the "
+                                     "two-lane pipeline into one flat bucket, ONE dense all-reduce per step"}
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench rank {rank}] two_views_per_rank failed: {e!r}", file=sys.stderr)
+                two_views = {"error": repr(e)}
+                dgr.set_grad_accumulator(None)
             for p_ in pc.parameters():
                 p_.grad = None
             del mv, vp_

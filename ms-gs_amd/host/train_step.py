@@ -35,3 +35,33 @@ def fused_train_iteration(model, optimizer, cam, gt_image, pipe, bg, *, lambda_d
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return loss.detach(), Ll1, pkg
+
+
+def fused_train_iteration_views(model, optimizer, pipeline, cams, gt_images, pipe, bg, *, lambda_dssim=0.2, loss_multiplier=1.0,
+                                reso_lvl=0, filter_small=False, filter_large=False, fade_size=1.0, base_mask=False,
+                                update_pixel_sizes=True, densify=True, render_fn=render_fused):
+    """ONE optimizer step over SEVERAL views (gradient accumulation over the views of the step, as the view-parallel config C4
+    does across GPUs — the reference itself steps after every view, train.py:193-216): the views run through
+    multi_view.ViewPipeline two at a time, their gradients are summed inside the per-Gaussian backward kernel, the per-view
+    statistics (train.py:239-250) are applied afterwards in view order — update_pixel_sizes is order dependent — and the optimizer
+    steps once.  Returns (losses [n] tensor, render packages); same arithmetic as the serial composition (same views, same
+    order), bit for bit (tests/test_train_step_gpu.py)."""
+    losses = [None] * len(cams)
+
+    def backward_fn(i, pkg):
+        loss, _ = l1_ssim_loss(pkg["render"], gt_images[i], lambda_dssim)
+        if loss_multiplier != 1.0:
+            loss = loss * loss_multiplier
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward()
+        losses[i] = loss.detach()
+        return pkg
+    pkgs = pipeline.train_views(cams, model, pipe, bg, backward_fn, render_fn=render_fn, share_getters=render_fn is not render_fused,
+                                filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)
+    with torch.no_grad():
+        for pkg in pkgs:                              # on the caller's stream, after the lanes have joined: view order
+            update_training_stats(model, pkg["viewspace_points"], pkg["radii"], pkg["pixel_sizes"], reso_lvl,
+                                  base_mask=base_mask, update_pixel_sizes=update_pixel_sizes, densify=densify)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return torch.stack(losses), pkgs

@@ -107,3 +107,48 @@ def test_short_run_reduces_the_loss():
     assert all(torch.isfinite(p).all() for p in model.parameters())
     assert losses[-1] < 0.6 * losses[0], losses
     assert model.denom.sum().item() > 0 and model.max_radii2D.max().item() > 0
+
+
+def test_multi_view_iteration_equals_the_serial_composition():
+    """train_step.fused_train_iteration_views (two views in flight, gradients summed in the kernel, statistics in view order, one
+    Adam step) against the same iteration composed serially from the same pieces: parameters, optimizer moments and every
+    statistic bit for bit, over three optimizer steps of four views"""
+    from gaussian_renderer import render_fused
+    from loss_utils import l1_ssim_loss
+    from multi_view import ViewPipeline
+    from synthetic_model import SyntheticGaussians
+    from train_epilogue import FusedAdam, update_training_stats
+    from train_step import fused_train_iteration_views
+    W, H, V = 200, 128, 4
+    sc = scenes.ball_scene(30000, seed=12, log_s=-3.2)
+    cams = [scenes.ring_camera(v, 8, W, H).to("cuda") for v in range(V)]
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(50 + v)).cuda() for v in range(V)]
+    bg = torch.zeros(3).cuda()
+    st = dict(filter_small=False, filter_large=False, fade_size=1.0)
+    a, b = SyntheticGaussians(sc, "cuda"), SyntheticGaussians(sc, "cuda")
+    oa = FusedAdam(a.training_setup(1), lr=0.0, eps=1e-15)
+    ob = FusedAdam(b.training_setup(1), lr=0.0, eps=1e-15)
+    pipe2 = ViewPipeline("cuda")
+    for it in range(3):
+        la, _ = fused_train_iteration_views(a, oa, pipe2, cams, gts, PIPE, bg, **st)
+        lb = []
+        for c, g in zip(cams, gts):                   # the serial composition
+            pkg = render_fused(c, b, PIPE, bg, **st)
+            loss, _ = l1_ssim_loss(pkg["render"], g, 0.2)
+            loss.backward()
+            lb.append(loss.detach())
+            with torch.no_grad():
+                update_training_stats(b, pkg["viewspace_points"], pkg["radii"], pkg["pixel_sizes"], 0)
+        with torch.no_grad():
+            ob.step()
+            ob.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        assert torch.equal(la, torch.stack(lb)), it
+        for n in a.LEAVES:
+            assert torch.equal(getattr(a, n), getattr(b, n)), (it, n)
+        for k in ("xyz_gradient_accum", "denom", "max_radii2D", "max_pixel_sizes", "min_pixel_sizes"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (it, k)
+    for (ga_, gb_) in zip(oa.param_groups, ob.param_groups):
+        pa, pb = ga_["params"][0], gb_["params"][0]
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
