@@ -69,9 +69,9 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # the rehearsal child is already running beside this session: collect its result FIRST, so that no other test shares the GPU
-    # with it
-    items.sort(key=lambda it: 0 if "test_bench_multirank_gpu" in it.nodeid else 1)
+    # the rehearsal child is already running beside this session (it shares the GPU with the first tests for ~40 s: they check
+    # results, not times): its result is collected LAST, so that with `-x` a failure of the rehearsal cannot hide the other tests
+    items.sort(key=lambda it: 1 if "test_bench_multirank_gpu" in it.nodeid else 0)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
