@@ -651,14 +651,14 @@ class GradAccumulator:
         self.last = None
 
 
-_accumulator = [None]
+_accumulator = threading.local()
 
 
 def set_grad_accumulator(acc):
-    """Install (or, with None, remove) the GradAccumulator the following forwards of the raw / chained entries snapshot.
-    Returns the previous one."""
-    prev = _accumulator[0]
-    _accumulator[0] = acc
+    """Install (or, with None, remove) the GradAccumulator the following forwards of the raw / chained entries OF THIS THREAD
+    snapshot (the forward runs on the caller's thread; the backward finds the accumulator on its ctx).  Returns the previous one."""
+    prev = getattr(_accumulator, "acc", None)
+    _accumulator.acc = acc
     return prev
 
 
@@ -667,7 +667,7 @@ def _snapshot_sinks(ctx, leaves):
     backward — which runs on autograd's worker thread — never reads module state another thread may be changing."""
     ctx.sinks = tuple(_grad_sinks.get(id(t)) for t in leaves)
     ctx.sh_factor = (_sh_factor_sink[0], _sh_factor_sink[1])
-    ctx.accum = _accumulator[0]
+    ctx.accum = getattr(_accumulator, "acc", None)
     ctx.leaves = leaves if ctx.accum is not None else None
 
 

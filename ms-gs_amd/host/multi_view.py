@@ -99,8 +99,22 @@ class ViewPipeline:
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(cur)
 
-    def _model(self, pc, share_getters):
-        return SharedGetters(pc).prime() if share_getters else pc
+    def _model(self, pc, share_getters, pipe=None, training=False):
+        """share_getters in a TRAINING sweep is only sound when the op chains the getters' backward itself: the
+        getters' autograd nodes are then never run.  If autograd had to run them, the first view's backward would free the graph
+        the other views share.  So the sweep shares them only when the op will recognise them (checked here on the model's own
+        tensors) and the pipeline settings keep the SH / covariance inside the op; train_views verifies every view afterwards."""
+        if not share_getters:
+            return pc
+        shared = SharedGetters(pc).prime()
+        if training:
+            ok = bool(dgr.chain_reference_getters) and pipe is not None and not getattr(pipe, "convert_SHs_python", False) \
+                and not getattr(pipe, "compute_cov3D_python", False) and torch.is_grad_enabled()
+            ok = ok and dgr._match_reference_getters(shared.get_xyz, shared.get_features, shared.get_opacity,
+                                                     shared.get_scaling, shared.get_rotation) is not None
+            if not ok:
+                return pc
+        return shared
 
     # -- forward only ----------------------------------------------------------------------------------------------
     def render_views(self, cams, pc, pipe, bg_color, consume=None, render_fn=_render, share_getters=True, **settings):
@@ -113,7 +127,7 @@ class ViewPipeline:
         Returns the list of result dicts (or of consume()'s return values), usable on the caller's stream."""
         n = len(cams)
         ns = len(self.streams)
-        model = self._model(pc, share_getters)
+        model = self._model(pc, share_getters, pipe, training=torch.is_grad_enabled())
         cur = self._fork()
         out = [None] * n
         pkgs = [None] * n
@@ -162,7 +176,7 @@ class ViewPipeline:
         view on the other stream always goes out before a backward."""
         n = len(cams)
         ns = len(self.streams)
-        model = self._model(pc, share_getters)
+        model = self._model(pc, share_getters, pipe, training=True)
         acc = prev_acc = None
         if accumulator is not None or (accumulate_in_kernel and n > 1):
             acc = accumulator if accumulator is not None else dgr.GradAccumulator([getattr(pc, name) for name in LEAF_NAMES])
@@ -176,7 +190,15 @@ class ViewPipeline:
                 def launch(i):
                     with torch.cuda.stream(self.streams[i % ns]):
                         before = len(pending)
-                        pkgs[i] = (render_fn(cams[i], model, pipe, bg_color, **settings), pending[before:])
+                        pkg = render_fn(cams[i], model, pipe, bg_color, **settings)
+                        if model is not pc and n > 1:
+                            fn = getattr(pkg.get("render"), "grad_fn", None)
+                            if fn is not None and "Chained" not in type(fn).__name__:
+                                raise RuntimeError(
+                                    "ViewPipeline.train_views(share_getters=True): this render did not take the op's chained "
+                                    "entry (override_color, a modified getter, ...), so autograd would run the shared getters' "
+                                    "backward once per view and free their graph after the first: pass share_getters=False")
+                        pkgs[i] = (pkg, pending[before:])
                 if n:
                     launch(0)
                 for i in range(n):

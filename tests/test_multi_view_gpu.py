@@ -190,3 +190,50 @@ def test_randomised_sweeps_stay_bit_identical():
         assert e.value.code == 0
     finally:
         sys.argv = argv
+
+
+def test_pipeline_with_the_plain_path_and_debug_mode():
+    """views that do NOT take the chained / raw entry inside the pipeline: override_color (plain autograd path: the accumulator is
+    not consulted, autograd accumulates as usual) and pipe.debug (msgs_view_t::debug: no speculative stage 2, every stage
+    synchronised) — results equal to the serial loop"""
+    import types
+    from gaussian_renderer import render
+    from multi_view import ViewPipeline
+    from synthetic_model import SyntheticGaussians
+    sc, cams, dLs = _ball(P=20000, n_views=3)
+    bg = torch.tensor([0.2, 0.2, 0.2], device="cuda")
+    colors = torch.rand(sc.P, 3, generator=torch.Generator().manual_seed(3)).cuda().requires_grad_(True)
+    dbg = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=True)
+    for pipe_ns, kw in ((PIPE, dict(override_color=colors)), (dbg, {})):
+        ref_pc = SyntheticGaussians(sc, "cuda")
+        colors.grad = None
+        ref = []
+        for c, d in zip(cams, dLs):
+            o = render(c, ref_pc, pipe_ns, bg, **kw, **ST)
+            o["render"].backward(d)
+            ref.append(o)
+        ref_color_grad = None if colors.grad is None else colors.grad.clone()
+        pc = SyntheticGaussians(sc, "cuda")
+        colors.grad = None
+        got = []
+
+        def bwd(i, pkg):
+            pkg["render"].backward(dLs[i])
+            got.append(pkg)
+        rf = lambda c, m, p, b, **s: render(c, m, p, b, **kw, **s)
+        if "override_color" in kw:        # shared getters cannot serve a render that leaves their backward to autograd: said loudly
+            with pytest.raises(RuntimeError, match="share_getters=False"):
+                ViewPipeline("cuda").train_views(cams, SyntheticGaussians(sc, "cuda"), pipe_ns, bg, lambda i, pkg: None, render_fn=rf, **ST)
+            colors.grad = None
+        ViewPipeline("cuda").train_views(cams, pc, pipe_ns, bg, bwd, render_fn=rf, share_getters="override_color" not in kw, **ST)
+        torch.cuda.synchronize()
+        for o, r in zip(got, ref):
+            for k in OUT_KEYS:
+                assert torch.equal(o[k], r[k]), k
+        for n in ("_xyz", "_opacity", "_scaling", "_rotation"):
+            assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad), n
+        if "override_color" in kw:
+            assert torch.equal(colors.grad, ref_color_grad)
+        else:
+            for n in ("_features_dc", "_features_rest"):
+                assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad), n
