@@ -218,12 +218,13 @@ def check_backward(pc, m2grad, ograds, name="", rtol=BWD_RTOL, flagged=None, q99
 TRUTH_FACTOR = 1.25      # HIP may be at most this much farther from the float64 truth than the float32 oracle is (+ 1e-6)
 
 
-def check_against_truth(name, scene_seen, cam, st, bg, dL, out, pc, m2grad, orc, og, factor=TRUTH_FACTOR):
+def check_against_truth(name, scene_seen, cam, st, bg, dL, out, pc, m2grad, orc, og, factor=TRUTH_FACTOR, enforce=True):
     """The three-way check that turns "1e-4 between two float32 evaluations is ill-posed for dL/dscaling / dL/drotation" into an
     asserted property: with the float64 build of the oracle (liboracle64.so: the same algorithm, the same float32 inputs, every
     computed quantity in double — checked against the autograd oracle in tests/test_oracle_cpu.py) as the truth, the HIP result
     is no farther from the truth than `factor` x the float32 oracle's own distance + 1e-6, per tensor (max-norm relative, on
-    the Gaussians / pixels no oracle flags as borderline), forward and backward.  Returns {tensor: (hip, oracle)} distances."""
+    the Gaussians / pixels no oracle flags as borderline), forward and backward.  Returns {tensor: (hip, oracle)} distances
+    (enforce=False: only measures)."""
     from oracle import oracle_ctypes as oc
     t = oc.rasterize(scene_seen, cam, st, bg, f64=True)
     tg = oc.backward(t, dL)
@@ -234,7 +235,8 @@ def check_against_truth(name, scene_seen, cam, st, bg, dL, out, pc, m2grad, orc,
     e_hip = (out["render"].detach().cpu().double() - t.color).abs()[:, okpx].max().item()
     report(name, "forward, oracle_f32 vs float64 truth", e_orc)
     report(name, "forward, HIP vs float64 truth", e_hip)
-    assert e_hip <= factor * e_orc + 1e-6, f"{name}: forward HIP-vs-truth {e_hip:.3e} > {factor} x oracle-vs-truth {e_orc:.3e}"
+    assert not enforce or e_hip <= factor * e_orc + 1e-6, \
+        f"{name}: forward HIP-vs-truth {e_hip:.3e} > {factor} x oracle-vs-truth {e_orc:.3e}"
     hip_t = leaf_space(pc, m2grad, tg)                       # (HIP, truth) per tensor, leaf space
     orc_t = leaf_space(pc, m2grad, og)                       # (HIP, oracle) per tensor: only the oracle side is used
     dist_ = {}
@@ -244,8 +246,9 @@ def check_against_truth(name, scene_seen, cam, st, bg, dL, out, pc, m2grad, orc,
         dist_[k] = (d_hip, d_orc)
         report(name, f"grad {k}: HIP vs truth", d_hip)
         report(name, f"grad {k}: oracle_f32 vs truth", d_orc)
+    dist_["forward"] = (e_hip, e_orc)
     for k, (d_hip, d_orc) in dist_.items():
-        assert d_hip <= factor * d_orc + 1e-6, \
+        assert not enforce or d_hip <= factor * d_orc + 1e-6, \
             f"{name}: grad {k}: HIP is {d_hip:.3e} from the float64 truth, the float32 oracle {d_orc:.3e} (allowed {factor}x + 1e-6)"
     return dist_
 
