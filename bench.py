@@ -385,7 +385,7 @@ def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8
     return out
 
 
-def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup):
+def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup, multi_view=True):
     import torch.nn.functional as F
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
@@ -442,6 +442,8 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
     out["ms_per_iteration_torch_composition"] = round(timed(torch_composition), 4)
     # the same GPU pieces with ONE optimizer step over 8 views, two in flight (train_step.fused_train_iteration_views)
     try:
+        if not multi_view:
+            raise RuntimeError("skipped (--no-two-view)")
         from multi_view import ViewPipeline
         from train_step import fused_train_iteration_views
         model = SyntheticGaussians(scene, dev)
@@ -1003,7 +1005,7 @@ def main():
             # index statistics).  Separate copies of the model; neither is part of `value`.
             try:
                 result["train_iteration"] = train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev,
-                                                                   args.steps, args.warmup)
+                                                                   args.steps, args.warmup, multi_view=not args.no_two_view)
             except Exception as e:
                 result["train_iteration"] = {"error": repr(e)}
         result["binning"] = stats
