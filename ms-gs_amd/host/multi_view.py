@@ -193,7 +193,8 @@ class ViewPipeline:
                         pkg = render_fn(cams[i], model, pipe, bg_color, **settings)
                         if model is not pc and n > 1:
                             fn = getattr(pkg.get("render"), "grad_fn", None)
-                            if fn is not None and "Chained" not in type(fn).__name__:
+                            # (the raw-parameter entry never reads the getters: sharing them is harmless there)
+                            if fn is not None and not any(t in type(fn).__name__ for t in ("Chained", "Raw")):
                                 raise RuntimeError(
                                     "ViewPipeline.train_views(share_getters=True): this render did not take the op's chained "
                                     "entry (override_color, a modified getter, ...), so autograd would run the shared getters' "
