@@ -227,6 +227,24 @@ def test_huge_and_tiny_gaussians():
     check_backward(pc, m2, og, "huge", flagged=orc.borderline_gaussians)
 
 
+@pytest.mark.parametrize("W,H,keys16", [(4080, 4096, True), (4096, 4096, False)])
+def test_tile_key_width_boundary(W, H, keys16):
+    """The tile sort moves 16-bit keys while the tile ids and the sentinel (= number of tiles) fit: 255 x 256 = 65 280 tiles use
+    them, 256 x 256 = 65 536 tiles fall back to 32-bit keys — both against the oracle, with Gaussians large enough to reach the
+    last tiles (ids near 65 000) and a few that span hundreds of tiles (the wave-cooperative emit path)."""
+    assert (((W + 15) // 16) * ((H + 15) // 16) < 65535) == keys16
+    sc, cam = small_scene(3000, W, H, 91, scale_k=0.004 * 1920.0 / W * 1.2)
+    sc.scales[:12] *= 60.0                                  # > 96 instances each: emitted by their whole wave
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    dL = scenes.grad_seed(W, H, 91)
+    out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
+    orc, og = _oracle(pc.seen, cam, ST0, bg, dL)
+    check_forward(out, orc, f"boundary {W}x{H}")
+    check_backward(pc, m2, og, f"boundary {W}x{H}", flagged=orc.borderline_gaussians)
+    D = out["render"].grad_fn.state[3]
+    assert D > 5000 and int((out["radii"] > 0).sum()) > 1000
+
+
 def test_mark_visible():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     W, H = 64, 64
