@@ -245,6 +245,25 @@ def test_tile_key_width_boundary(W, H, keys16):
     assert D > 5000 and int((out["radii"] > 0).sum()) > 1000
 
 
+def test_wave_emitted_gaussian_inside_the_lds_stage():
+    """emit: a Gaussian with more than 96 instances is written by its whole wave; when its block's output range still fits the
+    LDS stage (<= 3072 pairs) the wave path has to deposit into the stage like the per-thread path.  One ~200-tile Gaussian among
+    sub-pixel ones, and one spanning more than 64 tile rows (the row loop of the wave path runs more than once)."""
+    for W, H, big in ((320, 240, 14.0), (96, 1200, 60.0)):
+        sc, cam = small_scene(250, W, H, 93)
+        sc.scales[:] *= 0.05
+        sc.scales[7] *= 20.0 * big
+        sc.opacities[7] = 0.9
+        bg = torch.zeros(3)
+        dL = scenes.grad_seed(W, H, 93)
+        out, pc, m2 = hip_render(sc, cam, ST0, bg, dL)
+        orc, og = _oracle(pc.seen, cam, ST0, bg, dL)
+        D = out["render"].grad_fn.state[3]
+        assert 96 < D <= 3072, D
+        check_forward(out, orc, f"wave emit {W}x{H}")
+        check_backward(pc, m2, og, f"wave emit {W}x{H}", flagged=orc.borderline_gaussians)
+
+
 def test_mark_visible():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     W, H = 64, 64
