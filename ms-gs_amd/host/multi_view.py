@@ -131,26 +131,28 @@ class ViewPipeline:
         cur = self._fork()
         out = [None] * n
         pkgs = [None] * n
-        with dgr.deferred_forward() as pending:
-            def launch(i):
-                with torch.cuda.stream(self.streams[i % ns]):
-                    before = len(pending)
-                    pkgs[i] = (render_fn(cams[i], model, pipe, bg_color, **settings), pending[before:])
-            if n:
-                launch(0)
-            for i in range(n):
-                if i + 1 < n:
-                    launch(i + 1)
-                pkg, mine = pkgs[i]
-                pkgs[i] = None
-                for p_ in mine:
-                    p_.resolve()
-                if consume is not None:
+        try:
+            with dgr.deferred_forward() as pending:
+                def launch(i):
                     with torch.cuda.stream(self.streams[i % ns]):
-                        out[i] = consume(i, pkg)
-                else:
-                    out[i] = pkg
-        self._join(cur)
+                        before = len(pending)
+                        pkgs[i] = (render_fn(cams[i], model, pipe, bg_color, **settings), pending[before:])
+                if n:
+                    launch(0)
+                for i in range(n):
+                    if i + 1 < n:
+                        launch(i + 1)
+                    pkg, mine = pkgs[i]
+                    pkgs[i] = None
+                    for p_ in mine:
+                        p_.resolve()
+                    if consume is not None:
+                        with torch.cuda.stream(self.streams[i % ns]):
+                            out[i] = consume(i, pkg)
+                    else:
+                        out[i] = pkg
+        finally:
+            self._join(cur)                       # also when a view raised: the lanes may still be reading the model
         for o in out:
             if isinstance(o, dict):
                 self._hand_over(o, cur)
@@ -215,7 +217,7 @@ class ViewPipeline:
         finally:
             if acc is not None:
                 dgr.set_grad_accumulator(prev_acc)
-        self._join(cur)
+            self._join(cur)                       # also when a view raised: the lanes may still be reading the model
         if acc is not None:
             acc.finish()
         for o in out:
