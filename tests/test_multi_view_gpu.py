@@ -237,3 +237,32 @@ def test_pipeline_with_the_plain_path_and_debug_mode():
         else:
             for n in ("_features_dc", "_features_rest"):
                 assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad), n
+
+
+def test_a_view_that_raises_mid_step_leaves_the_pipeline_usable():
+    """backward_fn raises on the third of six views (two forwards are in flight, an accumulator is installed, one view's gradients
+    are already in the bucket): the exception reaches the caller, the lanes are joined, no accumulator stays installed, and the
+    same pipeline then produces the serial loop's bits."""
+    import diff_gaussian_rasterization as dgr
+    from multi_view import ViewPipeline
+    from synthetic_model import SyntheticGaussians
+    sc, cams, dLs = _ball(P=30000)
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    ref_pc, _, _ = _serial_train(sc, cams, dLs, bg)
+    pc = SyntheticGaussians(sc, "cuda")
+    pipe = ViewPipeline("cuda")
+
+    def failing(i, pkg):
+        if i == 2:
+            raise KeyError("view 2")
+        pkg["render"].backward(dLs[i])
+    with pytest.raises(KeyError):
+        pipe.train_views(cams, pc, PIPE, bg, failing, **ST)
+    torch.cuda.synchronize()
+    assert dgr.set_grad_accumulator(None) is None
+    for p in pc.parameters():
+        p.grad = None
+    pipe.train_views(cams, pc, PIPE, bg, lambda i, pkg: pkg["render"].backward(dLs[i]), **ST)
+    torch.cuda.synchronize()
+    for n in LEAVES:
+        assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad), n
