@@ -28,7 +28,7 @@ for it in range(N):
     fade = rng.choice([0.0, 0.5, 1.0])
     gran = rng.choice([0, 1, 2])
     bwd_gen = rng.choice([0, 1, 2])
-    fwd_var = rng.choice([0, 0, 1, 3, 4])
+    fwd_var = rng.choice([0, 0, 1, 3, 4, 5, 6])
     seed = rng.randint(0, 10 ** 6)
     cfg = dict(P=P, W=W, H=H, deg=deg, ms=ms, fade=fade, gran=gran, bwd_gen=bwd_gen, fwd_var=fwd_var, seed=seed)
     try:
