@@ -324,11 +324,17 @@ class deferred_forward:
 
     def __exit__(self, *exc):
         _deferred.pending = self.prev
-        for p_ in self.list:
-            if exc[0] is None:
-                p_.resolve()
+        first = None
+        for p_ in self.list:                  # every launched view is waited for, also behind one that failed
+            if exc[0] is None and first is None:
+                try:
+                    p_.resolve()
+                except Exception as e:        # noqa: BLE001 - re-raised below, after the other handles are finished
+                    first = e
             else:
                 p_.abandon()
+        if first is not None:
+            raise first
         return False
 
 
@@ -339,18 +345,23 @@ class _PendingForward:
         self.backward_follows = bool(backward_follows)
         self.call, self.status, self.stream, self.key, self.guess = call, status, stream, key, guess
         self.geom, self.binning, self.image, self.outs, self.grad_rec, self.keep = geom, binning, image, outs, grad_rec, keep
-        self.state = None
+        self.state = self.error = None
         self.lock = threading.Lock()
 
     def resolve(self):
         with self.lock:
             if self.state is not None:
                 return self.state
+            if self.status is None:                     # an earlier resolve() failed: the view has no result
+                raise RuntimeError("this forward failed when its instance count was collected") from self.error
             lib, call = _C.lib, self.call
             D, done = C.c_int64(0), C.c_int32(0)
             status, self.status = self.status, None
             try:
                 _C.check(lib.msgs_forward_finish(status, C.byref(D), C.byref(done)), "msgs_forward_finish")
+            except Exception as e:
+                self.error = e
+                raise
             finally:
                 _give_status(status)
             D = int(D.value)
@@ -359,6 +370,7 @@ class _PendingForward:
             if not done.value:                          # first frame of this shape, or the scene grew past the margin
                 dev, W, H = call.device, call.W, call.H
                 color, acc_ps, depth = self.outs
+                self.error = RuntimeError("stage 2 on exact buffers failed")     # cleared below
                 with _on_device(dev), torch.cuda.stream(self.stream):
                     self.binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
                     scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
@@ -372,7 +384,7 @@ class _PendingForward:
                                                      C.c_void_p(self.stream.cuda_stream)), "msgs_forward_stage2")
                     del scratch2
             self.state = (self.geom, self.binning, self.image, D)
-            self.outs = self.grad_rec = None
+            self.outs = self.grad_rec = self.error = None
             return self.state
 
     def abandon(self):

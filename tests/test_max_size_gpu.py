@@ -123,10 +123,23 @@ def test_more_than_2_pow_32_instances_is_an_error_not_a_wrap():
                 p.resolve()
     torch.cuda.synchronize()
     sc2, cam2 = small_scene(2000, 96, 64, 6, sh_degree=0)
+    ok_model, cam2 = SyntheticGaussians(sc2, dev, requires_grad=False), cam2.to(dev)
+    # ... and when the failure surfaces at the END of a deferred block, with a healthy view launched behind the failing one:
+    # the block raises, but the healthy view's wait is finished too (its handle goes back to the pool) and a later resolve()
+    # of the failed one raises again instead of touching a handle it no longer owns
+    with torch.no_grad(), pytest.raises(RuntimeError, match="tile instances"):
+        with dgr.deferred_forward() as pending:
+            render(camd, model, PIPE, bg, **st)
+            healthy = render(cam2, ok_model, PIPE, bg, **st)
+    assert pending[1].state is not None and pending[0].state is None
+    with pytest.raises(RuntimeError):
+        pending[0].resolve()
+    torch.cuda.synchronize()
     with torch.no_grad():
-        a = render(cam2.to(dev), SyntheticGaussians(sc2, dev, requires_grad=False), PIPE, bg, **st)["render"].clone()
-        b = render(cam2.to(dev), SyntheticGaussians(sc2, dev, requires_grad=False), PIPE, bg, **st)["render"]
+        a = render(cam2, ok_model, PIPE, bg, **st)["render"].clone()
+        b = render(cam2, ok_model, PIPE, bg, **st)["render"]
     assert torch.equal(a, b) and torch.isfinite(a).all() and a.abs().max() > 0
+    assert torch.equal(healthy["render"], a)
 
 
 def test_instance_count_between_2_pow_31_and_2_pow_32():
