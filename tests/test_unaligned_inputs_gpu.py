@@ -89,3 +89,46 @@ def test_four_byte_aligned_precomputed_colours_and_covariances():
         assert torch.equal(img, res[0][0])
         for g, g0 in zip(grads, res[0][1]):
             assert torch.equal(g, g0)
+
+
+def test_strided_inputs_are_rendered_like_their_contiguous_copies():
+    """per-Gaussian tensors that are column slices of wider tensors (not contiguous): the wrapper copies, the gradients come back
+    through the views into the wide leaves — same bits as with contiguous leaves"""
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from synthetic_model import SyntheticGaussians
+    W, H = 160, 96
+    sc, cam = small_scene(3000, W, H, 23, sh_degree=3)
+    dev = torch.device("cuda")
+    camd, dL = cam.to(dev), scenes.grad_seed(W, H, 23).to(dev)
+    m = SyntheticGaussians(sc, dev, requires_grad=False)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                                       tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+                                       viewmatrix=camd.world_view_transform, projmatrix=camd.full_proj_transform,
+                                       sh_degree=3, campos=camd.camera_center, prefiltered=False, debug=False)
+    vals = dict(means3D=m.get_xyz, opacities=m.get_opacity, scales=m.get_scaling, rotations=m.get_rotation, shs=m.get_features)
+    res = []
+    for strided in (False, True):
+        leaves, ins = {}, {}
+        for k, v in vals.items():
+            if strided:
+                flat = v.reshape(sc.P, -1)
+                wide = torch.zeros(sc.P, flat.shape[1] + 3, device=dev)
+                wide[:, 2:2 + flat.shape[1]] = flat
+                wide.requires_grad_(True)
+                leaves[k] = wide
+                ins[k] = wide[:, 2:2 + flat.shape[1]].view(v.shape) if v.dim() == 2 else \
+                    wide[:, 2:2 + flat.shape[1]].unflatten(1, v.shape[1:])
+                assert not ins[k].is_contiguous() or ins[k].shape[1] == 1
+            else:
+                leaves[k] = ins[k] = v.clone().requires_grad_(True)
+        m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+        img, *_ = GaussianRasterizer(rs)(means2D=m2, **ins)
+        img.backward(dL)
+        torch.cuda.synchronize()
+        grads = {k: (leaves[k].grad[:, 2:2 + vals[k].reshape(sc.P, -1).shape[1]].reshape(vals[k].shape) if strided
+                     else leaves[k].grad) for k in vals}
+        res.append((img, grads, m2.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    for k in vals:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
