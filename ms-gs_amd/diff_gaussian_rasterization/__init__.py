@@ -544,7 +544,16 @@ class _RasterizeGaussians(torch.autograd.Function):
 # copy), so neither a zero-fill of the bucket nor an accumulation pass over it is needed.  Keys: id() of the leaf tensor
 # OBJECT, validated through a weak reference (an address-based key could match an unrelated tensor after densification
 # re-allocates the parameters).
-_grad_sinks = {}
+class _SinkRegistry(threading.local):
+    """per host thread: set_grad_sinks and the forward that snapshots the sinks run on the training loop's thread; a second
+    thread of the process (a viewer, an evaluation loop, another trainer) neither sees nor disturbs them"""
+
+    def __init__(self):
+        self.grad = {}
+        self.sh_factor = [None, None]   # [destination tensor, optional torch.cuda.Event recorded once the factors are written]
+
+
+_sinks = _SinkRegistry()
 
 
 def _save_inputs(ctx, *tensors):
@@ -559,9 +568,6 @@ def _check_saved(ctx):
         ctx.saved_tensors              # raises "modified by an inplace operation" when a version changed
 
 
-_sh_factor_sink = [None, None]          # [destination tensor, optional torch.cuda.Event recorded once the factors are written]
-
-
 def set_grad_sinks(mapping, sh_factor=None, factors_ready=None):
     """mapping: {leaf parameter: destination tensor (float32, contiguous, same numel)} or None to clear.
     sh_factor: optional [P,3] float32 destination.  When given, the backward of the raw / chained entries does NOT form
@@ -570,6 +576,7 @@ def set_grad_sinks(mapping, sh_factor=None, factors_ready=None):
     None for features_dc / features_rest.  factors_ready: optional torch.cuda.Event (created BEFORE the call so that its
     handle exists); the library records it on the backward's stream right behind the kernel that writes the factors, ahead
     of the per-Gaussian backward — a side stream that waits on it can start exchanging the factors while that kernel runs."""
+    _grad_sinks, _sh_factor_sink = _sinks.grad, _sinks.sh_factor
     _grad_sinks.clear()
     _sh_factor_sink[0] = None
     _sh_factor_sink[1] = None
@@ -677,8 +684,8 @@ def set_grad_accumulator(acc):
 def _snapshot_sinks(ctx, leaves):
     """Called in forward (the caller's thread): the sinks registered for THIS call travel on its ctx, so that the
     backward — which runs on autograd's worker thread — never reads module state another thread may be changing."""
-    ctx.sinks = tuple(_grad_sinks.get(id(t)) for t in leaves)
-    ctx.sh_factor = (_sh_factor_sink[0], _sh_factor_sink[1])
+    ctx.sinks = tuple(_sinks.grad.get(id(t)) for t in leaves)
+    ctx.sh_factor = (_sinks.sh_factor[0], _sinks.sh_factor[1])
     ctx.accum = getattr(_accumulator, "acc", None)
     ctx.leaves = leaves if ctx.accum is not None else None
 

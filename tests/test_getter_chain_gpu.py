@@ -117,7 +117,7 @@ def test_gradient_sinks_deliver_into_the_exchange_bucket():
             for p, v in zip(pc.parameters(), b.views):
                 assert p.grad.data_ptr() == v.data_ptr()                      # adopted, not copied
         ex.drain()
-        assert not dgr._grad_sinks
+        assert not dgr._sinks.grad
         for n in LEAVES:
             got, want = getattr(pc, n).grad, getattr(ref, n).grad / 2
             # render_fused evaluates the activations in the kernels, 1 ulp from torch's (tests/test_fused_gpu.py)

@@ -76,10 +76,17 @@ def test_four_threads_render_and_backpropagate_concurrently():
             except Exception:
                 pass
 
-    threads = [threading.Thread(target=worker, args=(v,)) for v in range(n_threads)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=300)
+    # the main thread plays a view-parallel trainer that has its SH-factor sink registered (view_parallel.FactoredGradExchange):
+    # the registry is per thread, the workers' backwards must keep forming their own SH gradient rows
+    import diff_gaussian_rasterization as dgr
+    dgr.set_grad_sinks({}, sh_factor=torch.empty(sc.P, 3, device=dev))
+    try:
+        threads = [threading.Thread(target=worker, args=(v,)) for v in range(n_threads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+    finally:
+        dgr.set_grad_sinks(None)
     assert not any(t.is_alive() for t in threads), "a worker thread hangs"
     assert not errors, errors[0]
