@@ -899,6 +899,7 @@ def main():
             committed.source = None
             tr = committed("traffic")
             traffic = int(tr["hbm_bytes"]) if tr else None
+            committed.traffic_file = committed.source if tr else None
             # what actually bounds the kernel: INSTRUCTION ISSUE.  One model for both blend kernels: per
             # launch, wave-instructions by class from the committed PMC summary (same hash rule) x the calibrated issue cost
             # of each class (tools/valu_calib.hip -> profiles/r2_valu_calibration.txt: a SIMD issues about one instruction of
@@ -938,6 +939,26 @@ def main():
                               "GBps": round(b / (kms[k] * 1e-3) / 1e9, 1),
                               "frac": round(b / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                           for k, b in alg_all.items() if kms.get(k, 0.0) > 0}
+            # measured HBM bytes per step and class from the same committed PMC summary (mean per launch x launches per step;
+            # every launch of that profile is a C3 launch: tools/profile_round.sh runs without the pyramid and two-view legs)
+            try:
+                tj = json.load(open(os.path.join(ROOT, committed.traffic_file))) if committed.traffic_file else None
+            except Exception:
+                tj = None
+            if tj:
+                classes = {"preprocess": ("preprocess_kernel",), "scan": ("scan_",), "emit": ("emit_kernel",),
+                           "sort(depth+tile)": ("radix_", "group_scan_kernel"), "ranges": ("ranges_kernel",),
+                           "blend_fwd": ("blend_forward_kernel",), "blend_bwd": ("blend_backward_tile",),
+                           "preprocess_bwd": ("preprocess_backward_kernel",)}
+                steps_ = max([v["launches"] for k, v in tj["kernels"].items() if k.startswith("blend_backward_tile")] or [0])
+                for cls, prefixes in classes.items():
+                    if cls not in per_kernel or not steps_:
+                        continue
+                    tot = sum(v["hbm_bytes"] * v["launches"] for k, v in tj["kernels"].items() if k.startswith(prefixes))
+                    if tot > 0:
+                        per_kernel[cls]["traffic"] = int(tot / steps_)
+                        per_kernel[cls]["traffic_over_algorithmic"] = round(tot / steps_ / alg_all[cls], 2)
+                        per_kernel[cls]["traffic_GBps"] = round(tot / steps_ / (kms[cls] * 1e-3) / 1e9, 1)
             total_alg = float(sum(alg_all.values()))
             whole = {"algorithmic_bytes": int(total_alg), "ms_per_step": round(ms_per_step, 4),
                      "GBps": round(total_alg / (ms_per_step * 1e-3) / 1e9, 1),
