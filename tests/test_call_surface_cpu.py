@@ -63,3 +63,22 @@ def test_duck_types_carry_every_attribute_render_reads():
     pc = SyntheticGaussians(sc, "cpu", requires_grad=False)
     for a in SURFACE["attributes_read"]["pc"]:
         assert hasattr(pc, a), a
+
+
+def test_defaults_mirror_the_reference_argument_classes():
+    """tests/golden/arguments.json: defaults of the reference's PipelineParams / OptimizationParams, read by instantiating the classes
+    (make_arguments_golden.py).  The stand-ins the tests, smoke() and bench.py drive the op with use the same values."""
+    import inspect
+    args = json.load(open(os.path.join(HERE, "golden", "arguments.json")))
+    from gaussian_renderer import PIPE
+    assert vars(PIPE) == args["PipelineParams"]
+    from synthetic_model import SyntheticGaussians
+    o = args["OptimizationParams"]
+    assert SyntheticGaussians.LRS == dict(xyz=o["position_lr_init"], f_dc=o["feature_lr"], f_rest=o["feature_lr"] / 20.0,
+                                          opacity=o["opacity_lr"], scaling=o["scaling_lr"], rotation=o["rotation_lr"])
+    import loss_utils
+    import train_step
+    assert inspect.signature(loss_utils.l1_ssim_loss).parameters["lambda_dssim"].default == o["lambda_dssim"]
+    for fn in (train_step.fused_train_iteration, train_step.fused_train_iteration_views):
+        assert inspect.signature(fn).parameters["lambda_dssim"].default == o["lambda_dssim"]
+    assert args["ModelParams"]["sh_degree"] == 3
