@@ -19,7 +19,7 @@ limit_thread_pools(reserve=0)
 # and on the GPU boxes a process that has initialised the GPU must not start another program: the child is therefore started
 # HERE, when a `-m gpu` session is configured — before anything in this process touches the GPU (torch.cuda.device_count()
 # does not initialise it; torch.cuda.is_available() further down does) — and the test only collects its output.
-BENCH_REHEARSAL = {"proc": None, "log": None}
+BENCH_REHEARSAL = {"proc": None, "log": None, "torchrun": None, "torchrun_log": None}
 
 
 def _start_bench_rehearsal(config):
@@ -47,6 +47,13 @@ def _start_bench_rehearsal(config):
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
          "--no-pyramid"], env=env, stdout=subprocess.PIPE, stderr=log, text=True, cwd=ROOT)
     BENCH_REHEARSAL["log"] = log.name
+    # the driver's own way to start N > 1: torch.distributed.run around bench.py (WORLD_SIZE set, no self-launch)
+    log2 = tempfile.NamedTemporaryFile(prefix="msgs_bench_rehearsal_torchrun_", suffix=".log", delete=False)
+    BENCH_REHEARSAL["torchrun"] = subprocess.Popen(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+         "--no-cpu-baseline", "--no-pyramid"], env=env, stdout=subprocess.PIPE, stderr=log2, text=True, cwd=ROOT)
+    BENCH_REHEARSAL["torchrun_log"] = log2.name
 
 
 def pytest_configure(config):
@@ -55,9 +62,10 @@ def pytest_configure(config):
 
 
 def pytest_unconfigure(config):
-    p = BENCH_REHEARSAL["proc"]
-    if p is not None and p.poll() is None:       # the test did not run (deselected / interrupted): do not leave it behind
-        p.terminate()
+    for key in ("proc", "torchrun"):
+        p = BENCH_REHEARSAL.get(key)
+        if p is not None and p.poll() is None:   # the test did not run (deselected / interrupted): do not leave it behind
+            p.terminate()
 
 
 def _has_gpu():
