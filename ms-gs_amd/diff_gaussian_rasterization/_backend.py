@@ -11,7 +11,10 @@ import torch  # noqa: F401  -- must be loaded first: libmsgs_hip.so has to bind 
 #                     instance (matched by SONAME) that PyTorch-ROCm loaded, since streams cross the boundary
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("MSGS_HIP_LIB", os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
+# MSGS_HIP_LIB, else the copy a `pip install` placed inside the package (ms-gs_amd/setup.py), else the source tree's lib/
+_LIB_PATH = os.environ.get("MSGS_HIP_LIB") or next(
+    (p for p in (os.path.join(_PKG, "libmsgs_hip.so"),) if os.path.exists(p)),
+    os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
 ABI_VERSION = 8
 
