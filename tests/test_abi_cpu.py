@@ -95,7 +95,6 @@ def test_product_never_imports_the_oracle():
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
-    import importlib
     import subprocess
     import sys
     code = ("import os, sys; os.environ['MSGS_HIP_LIB']='/nonexistent/libmsgs_hip.so'; "

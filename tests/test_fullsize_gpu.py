@@ -14,7 +14,6 @@ TIGHT_RTOL = 1e-4
 LINEARITY_RTOL = {"_scaling": 1e-3, "_rotation": 3e-4}       # measured 2.5e-4 / 5.9e-5; the other tensors <= 1.5e-6
 LINEARITY_RTOL_DEFAULT = 1e-5
 FULL_Q99 = 1e-4
-import ctypes as C
 
 import pytest
 import torch

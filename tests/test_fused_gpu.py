@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import scenes
-from parity_utils import PIPE, check_forward, rel_err, rel_err_reported, small_scene
+from parity_utils import PIPE, check_forward, rel_err_reported, small_scene
 
 pytestmark = pytest.mark.gpu
 

@@ -2,7 +2,6 @@
 oracle, both against the committed golden fixtures, and the restated helpers against the fixtures that
 were generated from the reference's own importable functions (tests/golden/make_golden.py)."""
 import copy
-import math
 import os
 
 import numpy as np
