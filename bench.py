@@ -615,6 +615,11 @@ def main():
         try:
             step()
             torch.cuda.synchronize()
+            if os.environ.get("MSGS_BENCH_FAIL_FACTORED") == str(rank):
+                # rehearsal of the fallback (tests/test_bench_multirank_gpu.py): ONE rank fails its first factored step —
+                # behind its collectives, so that its peer is not left inside one — and both ranks have to land on the
+                # dense exchange through the agreement below
+                raise RuntimeError("injected failure of the factored exchange (MSGS_BENCH_FAIL_FACTORED)")
         except Exception as e:           # noqa: BLE001 - any failure of the new path must not lose the measurement
             print(f"[bench rank {rank}] factored exchange failed ({e!r}); falling back to the dense all-reduce", file=sys.stderr)
             ok.zero_()
@@ -755,18 +760,33 @@ def main():
 
             def step_multi(k):
                 mv.step(vp_, mine, PIPE, bg, bwd_, **settings)
-            try:        # informational: a failure here must not cost the scaling line (the ranks run the same code on the same
-                step_multi(0)   # shapes, so a local failure is the same on every rank and nobody is left inside a collective)
+            # Informational: a failure here must not cost the scaling line — but mv.step ends in an all-reduce, and a failure
+            # on ONE rank (out of memory, a HIP error on one GPU) must not leave its peers inside that collective.  So every
+            # rank first runs its views WITHOUT the collective (the rank-local part: pipeline, accumulator, bucket), the ranks
+            # agree over the CPU group that all of them got through, and only then the collective version runs — outside any
+            # try: a failure there ends this rank, and the launcher (or torch.distributed.run) stops its peers.
+            ok2 = torch.ones(1)
+            err2 = None
+            try:
+                mv.bucket.detach_grads()
+                vp_.train_views(mine, pc, PIPE, bg, bwd_, accumulator=mv.acc, **settings)
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench rank {rank}] two_views_per_rank failed locally: {e!r}", file=sys.stderr)
+                err2 = repr(e)
+                ok2.zero_()
+                dgr.set_grad_accumulator(None)
+            dist.all_reduce(ok2, op=dist.ReduceOp.MIN, group=agree)
+            if ok2.item() == 0:
+                two_views = {"error": err2 or "another rank failed in its rank-local dry run; block skipped on every rank"}
+            else:
+                step_multi(0)
                 tm_ = timed_region(step_multi, args.steps) / args.steps
                 two_views = {"views_per_rank_per_step": len(mine), "ms_per_optimizer_step": round(1e3 * tm_, 4),
                              "fwd_bwd_ms_per_view": round(1e3 * tm_ / len(mine), 4),
                              "value": round(n_views * (W * H / 1e6) / tm_, 3), "unit": "Mpixels/s",
                              "what": "one optimizer step over all 8 C4 views: each rank renders its 8 / N views through the "
                                      "two-lane pipeline into one flat bucket, ONE dense all-reduce per step"}
-            except Exception as e:      # noqa: BLE001
-                print(f"[bench rank {rank}] two_views_per_rank failed: {e!r}", file=sys.stderr)
-                two_views = {"error": repr(e)}
-                dgr.set_grad_accumulator(None)
             for p_ in pc.parameters():
                 p_.grad = None
             del mv, vp_

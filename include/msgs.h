@@ -231,7 +231,8 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g,
  * float once like the library's own records.  `geom` and `radii` are those of the forward of the same view.  For the
  * parity tests: fed the oracle's sums, the two per-Gaussian stages are compared on bit-identical inputs
  * (tests/test_k8_isolation_gpu.py); also usable by a caller that blends elsewhere.  Reference-API inputs only
- * (raw_params = 0). */
+ * (raw_params = 0); grads->accumulate / wait_before_accumulate / accumulated must be zero / NULL (MSGS_ERR_INVALID_ARG
+ * otherwise: accumulation across views is msgs_backward's contract). */
 int msgs_backward_per_gaussian(const msgs_view_t* view, const msgs_gaussians_t* g, const int32_t* radii,
                                const void* geom, size_t geom_bytes, const double* sums2d, const msgs_grads_t* grads,
                                void* stream);

@@ -617,6 +617,9 @@ int msgs_backward_per_gaussian(const msgs_view_t* view, const msgs_gaussians_t* 
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (!grads || g->raw_params) return MSGS_ERR_INVALID_ARG;
+    // the textbook branch of the per-Gaussian kernel neither waits for `wait_before_accumulate` nor records `accumulated`:
+    // accumulation across views is msgs_backward's contract only
+    if (grads->accumulate || grads->wait_before_accumulate || grads->accumulated) return MSGS_ERR_INVALID_ARG;
     const int P = g->P;
     if (P == 0) return MSGS_OK;
     if (!radii || !geom_v || !sums2d) return MSGS_ERR_INVALID_ARG;

@@ -341,8 +341,10 @@ class deferred_forward:
 class _PendingForward:
     """State of one launched forward: resolve() -> (geom, binning, image, D), waiting for the count if nobody has yet."""
 
-    def __init__(self, call, status, stream, key, guess, geom, binning, image, outs, grad_rec, keep, backward_follows=False):
+    def __init__(self, call, status, stream, key, guess, geom, binning, image, outs, grad_rec, keep, backward_follows=False,
+                 scratch1=None):
         self.backward_follows = bool(backward_follows)
+        self.scratch1 = scratch1              # holds the device status words msgs_forward_finish may still copy from
         self.call, self.status, self.stream, self.key, self.guess = call, status, stream, key, guess
         self.geom, self.binning, self.image, self.outs, self.grad_rec, self.keep = geom, binning, image, outs, grad_rec, keep
         self.state = self.error = None
@@ -364,6 +366,7 @@ class _PendingForward:
                 raise
             finally:
                 _give_status(status)
+                self.scratch1 = None
             D = int(D.value)
             guess = self.guess
             _last_instances[self.key] = max(D, (guess + D) // 2) if guess is not None else D
@@ -424,12 +427,14 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
         keep = _bytes(_a256(n_geom) + _a256(n_img) + n_bin, dev)
         geom, image = keep[:n_geom], keep[_a256(n_geom):_a256(n_geom) + n_img]
         binning = keep[_a256(n_geom) + _a256(n_img):] if n_bin else None
-        tmp = _bytes(_a256(n_s1) + n_s2, dev)
-        scratch1 = tmp[:n_s1]
-        scratch2 = tmp[_a256(n_s1):] if n_s2 else None
         if pending is not None:
-            # launch only; the temporaries go back to the caching allocator at once, which hands them out again in THIS
-            # stream's order only (blocks are bound to the stream they were allocated on)
+            # launch only.  The stage-2 temporaries go back to the caching allocator at once, which hands them out again in
+            # THIS stream's order only (blocks are bound to the stream they were allocated on).  The stage-1 scratch holds the
+            # device copy of the status words that msgs_forward_finish may still READ at resolve time (MSGS_BLOCKING_SYNC=1, a
+            # failed pinned allocation, or a flag that never landed: a copy enqueued behind whatever this stream was given
+            # since) — it stays referenced by the pending state until resolve()
+            scratch1 = _bytes(n_s1, dev)
+            scratch2 = _bytes(n_s2, dev) if n_s2 else None
             status = _take_status()
             try:
                 _C.check(lib.msgs_forward_launch(call.view_ref, call.g_ref, _ptr(radii), _ptr(pixel_sizes),
@@ -442,9 +447,12 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
                 _give_status(status)
                 raise
             state = _PendingForward(call, status, cur, key, guess, geom, binning, image, (color, acc_ps, depth), grad_rec, keep,
-                                    backward_follows)
+                                    backward_follows, scratch1)
             pending.append(state)
             return color, acc_ps, depth, radii, pixel_sizes, state
+        tmp = _bytes(_a256(n_s1) + n_s2, dev)
+        scratch1 = tmp[:n_s1]
+        scratch2 = tmp[_a256(n_s1):] if n_s2 else None
         D, done = C.c_int64(0), C.c_int32(0)
         _C.check(lib.msgs_forward(call.view_ref, call.g_ref, _ptr(radii), _ptr(pixel_sizes),
                                   _ptr(geom), n_geom, _ptr(scratch1), n_s1,

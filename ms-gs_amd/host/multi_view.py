@@ -93,11 +93,23 @@ class ViewPipeline:
             cur.wait_stream(s)
 
     @staticmethod
-    def _hand_over(pkg, cur):
-        """tensors allocated on a side stream and handed to the caller: tell the caching allocator that `cur` uses them"""
-        for v in pkg.values():
-            if torch.is_tensor(v) and v.is_cuda:
-                v.record_stream(cur)
+    def _hand_over(obj, cur):
+        """tensors allocated on a side stream and handed to the caller: tell the caching allocator that `cur` uses them.
+        Covers what a view returns — a tensor, a result dict, a tuple / list of those — and the .grad of the leaf tensors
+        among them (`viewspace_points.grad` is allocated by the backward on the lane's stream and read on the caller's by
+        the statistics update, /root/reference/train.py:247-250)."""
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                obj.record_stream(cur)
+                g = obj.grad if obj.is_leaf else None
+                if g is not None and g.is_cuda:
+                    g.record_stream(cur)
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                ViewPipeline._hand_over(v, cur)
+        elif isinstance(obj, (tuple, list)):
+            for v in obj:
+                ViewPipeline._hand_over(v, cur)
 
     def _model(self, pc, share_getters, pipe=None, training=False):
         """share_getters in a TRAINING sweep is only sound when the op chains the getters' backward itself: the
@@ -154,10 +166,7 @@ class ViewPipeline:
         finally:
             self._join(cur)                       # also when a view raised: the lanes may still be reading the model
         for o in out:
-            if isinstance(o, dict):
-                self._hand_over(o, cur)
-            elif torch.is_tensor(o) and o.is_cuda:
-                o.record_stream(cur)
+            self._hand_over(o, cur)
         return out
 
     # -- forward + backward ----------------------------------------------------------------------------------------
@@ -220,7 +229,6 @@ class ViewPipeline:
             self._join(cur)                       # also when a view raised: the lanes may still be reading the model
         if acc is not None:
             acc.finish()
-        for o in out:
-            if isinstance(o, dict):
-                self._hand_over(o, cur)
+        for o in out:                             # whatever backward_fn returned: result dicts, losses, viewspace_points
+            self._hand_over(o, cur)
         return out

@@ -55,9 +55,10 @@ def fused_train_iteration_views(model, optimizer, pipeline, cams, gt_images, pip
         with torch.autograd.set_multithreading_enabled(False):
             loss.backward()
         losses[i] = loss.detach()
-        return pkg
+        return pkg, losses[i]         # everything returned here is handed over to the caller's stream (record_stream)
     pkgs = pipeline.train_views(cams, model, pipe, bg, backward_fn, render_fn=render_fn, share_getters=render_fn is not render_fused,
                                 filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)
+    pkgs = [p_[0] for p_ in pkgs]
     with torch.no_grad():
         for pkg in pkgs:                              # on the caller's stream, after the lanes have joined: view order
             update_training_stats(model, pkg["viewspace_points"], pkg["radii"], pkg["pixel_sizes"], reso_lvl,

@@ -194,3 +194,37 @@ def test_gradient_records_are_zero_after_the_forward_and_capacity_is_checked(P, 
     small = torch.empty(64, dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError, match="smaller"):
         dgr._forward_impl(call, small)
+
+
+def test_per_gaussian_backward_entry_refuses_accumulation():
+    """msgs_backward_per_gaussian (the isolation entry of tests/test_k8_isolation_gpu.py) runs the textbook branch of the
+    per-Gaussian kernel, which neither waits for `wait_before_accumulate` nor records `accumulated`: accumulation across views
+    is msgs_backward's contract, and asking for it here is an invalid argument instead of a race."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    kw, cam = _inputs()
+    rs = _settings(cam, torch.zeros(3, device="cuda"))
+    call = dgr._Call(rs, kw["means3D"], kw["shs"], None, kw["opacities"], kw["scales"], kw["rotations"], None,
+                     kw["max_pixel_sizes"], kw["min_pixel_sizes"], None, None, kw["base_mask"])
+    with torch.no_grad():
+        _, _, _, radii, _, (geom, _, _, _) = dgr._forward_impl(call)
+    P, K = call.P, call.K
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device="cuda")
+    out = [e(P, 3), e(P, 3), e(P, K, 3), e(P), e(P, 3), e(P, 4)]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    sums = torch.zeros(P, 9, dtype=torch.float64, device="cuda")
+    ev = torch.cuda.Event()
+    ev.record()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(acc=0, wait=None, rec=None):
+        grads = dgr._C.Grads(p(out[0]), p(out[1]), p(out[2]), None, p(out[3]), p(out[4]), p(out[5]), None, None, None, None,
+                             0, acc, wait, rec)
+        return dgr._C.lib.msgs_backward_per_gaussian(C.byref(call.view), C.byref(call.g), p(radii), p(geom), geom.numel(),
+                                                     p(sums), C.byref(grads), stream)
+    assert run() == 0
+    assert run(acc=1) == -1
+    assert run(wait=C.c_void_p(ev.cuda_event)) == -1
+    assert run(rec=C.c_void_p(ev.cuda_event)) == -1
+    torch.cuda.synchronize()
+    assert all(float(t.abs().max()) == 0.0 for t in out)       # zero sums in, zero gradients out: the valid call ran

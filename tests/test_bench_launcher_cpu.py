@@ -63,3 +63,33 @@ def test_a_dead_rank_takes_the_others_down_quickly():
     assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
     assert "the other ranks were stopped" in r.stderr
     assert time.time() - t0 < 120
+
+
+def test_rehearsal_supervisor_runs_its_jobs_one_after_the_other(tmp_path):
+    """tests/_rehearsals.py (the supervisor of the `-m gpu` session's child processes): jobs run sequentially, each with its own
+    environment, a free port is inserted where asked, `<name>.rc` appears last, a failing or overrunning job does not stop the
+    next one."""
+    import time
+    spec = {"dir": str(tmp_path), "cwd": ROOT, "jobs": [
+        {"name": "a", "argv": [sys.executable, "-c", "import os,sys,time; time.sleep(0.5); print(os.environ['X_JOB'], sys.argv[1:])",
+                               "--port"], "free_port_arg": "--port", "env": {"X_JOB": "first"}},
+        {"name": "b", "argv": [sys.executable, "-c", "import sys; sys.stderr.write('boom'); sys.exit(7)"]},
+        {"name": "c", "argv": [sys.executable, "-c", "import time; time.sleep(30)"], "timeout": 0.5},
+        {"name": "d", "argv": [sys.executable, "-c", "import os; print(os.environ.get('WORLD_SIZE', 'unset'))"],
+         "unset_env": ["WORLD_SIZE"]},
+    ]}
+    sp = tmp_path / "spec.json"
+    sp.write_text(json.dumps(spec))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rehearsals.py"), str(sp)],
+                       env=dict(os.environ, WORLD_SIZE="9"), timeout=120)
+    assert r.returncode == 0 and time.time() - t0 < 60
+    rc = {n: int((tmp_path / f"{n}.rc").read_text()) for n in "abcd"}
+    assert rc == {"a": 0, "b": 7, "c": 124, "d": 0}
+    out_a = (tmp_path / "a.out").read_text()
+    assert out_a.startswith("first ['--port', '") and int(out_a.split("'")[3]) > 0
+    assert (tmp_path / "b.err").read_text() == "boom"
+    assert (tmp_path / "d.out").read_text().strip() == "unset"
+    # sequential: every .rc is written after the previous job's
+    m = [os.path.getmtime(tmp_path / f"{n}.rc") for n in "abcd"]
+    assert m == sorted(m)
