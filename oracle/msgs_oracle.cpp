@@ -102,6 +102,10 @@ struct msgs_oracle_state {
     std::vector<uint8_t> borderline_gauss;  // Gaussian had an alpha within rounding distance of 1/255 on some pixel, or
                                             // shares a pixel with a Gaussian whose filter decision could flip
     std::vector<uint8_t> filter_edge;       // Gaussian's own filter decision is within rounding of flipping
+    std::vector<uint8_t> shared_gauss;      // Gaussian reaches (alpha >= 1/255) a pixel at which SOME discrete decision could
+                                            // flip — an alpha at 1/255, a transmittance at 1e-4, a filter-edge Gaussian: its
+                                            // term at that pixel moves with that decision (T behind the entry scales by
+                                            // 1 - 1/255, the colour composited behind the entries in front changes)
     int64_t ghost_instances = 0;
     int64_t traversed = 0;
     int64_t valid_pairs = 0;      // (pixel, Gaussian) evaluations with alpha >= 1/255 before the pixel terminated
@@ -377,6 +381,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
     st->n_contrib.assign((size_t)W * H, 0);
     st->borderline_gauss.assign(P, 0);
     st->filter_edge.assign(P, 0);
+    st->shared_gauss.assign(P, 0);
     for (int i = 0; i < P; ++i) st->filter_edge[i] = st->geom[i].filter_edge;
     const real bg[3] = {view->bg[0], view->bg[1], view->bg[2]};
     int64_t traversed = 0, valid_pairs = 0, evaluated_pairs = 0;
@@ -393,21 +398,36 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                 real T = 1.0f, C[3] = {0, 0, 0}, aps = 0.f, adp = 0.f;
                 uint32_t contributor = 0, last = 0;
                 bool flag = false, taint = false;
+                // T_hi: the largest transmittance ANY float32 implementation of the algorithm can hold at this point of the
+                // list — the same product with every entry whose blending hinges on a borderline decision left out (an alpha
+                // at 1/255, a filter-edge Gaussian).  Where the oracle terminates, another implementation may still be
+                // blending as long as T_hi (1 - alpha) has not fallen below 1e-4: the flags cover the list that far.
+                real T_hi = 1.0f;
                 uint32_t k_end = lo;
+                bool done = false;             // the ORACLE's pixel has terminated (Q7); the scan goes on in shadow
                 for (uint32_t k = lo; k < hi; ++k) {
-                    k_end = k + 1;
-                    ++contributor;
                     const Geom& ge = st->geom[st->list[k]];
-                    if (!ge.ghost) ++evaluated_pairs;
+                    if (!done) { k_end = k + 1; ++contributor; if (!ge.ghost) ++evaluated_pairs; }
                     real dx = ge.px - pxf, dy = ge.py - pyf;
                     real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                     if (power > 0.0f) continue;
                     real alpha = std::min(RL(0.99), ge.opacity * std::exp(power));        // Q6
+                    const bool reaches = alpha * 255.0f >= 1.0f - RL(2e-5);
+                    const bool own_edge = std::fabs(alpha * 255.0f - 1.0f) < RL(2e-5);
+                    if (done) {
+                        // shadow: only how far another implementation can get
+                        if (!reaches) continue;
+                        const real th = T_hi * (1 - alpha);
+                        if (th < RL(0.0001) - RL(2e-8)) break;
+                        k_end = k + 1;
+                        if (!ge.filter_edge && !own_edge) T_hi = th;
+                        continue;
+                    }
                     // a Gaussian whose filter decision could flip reaches this pixel: the pixel, and every Gaussian
                     // blended here, depends on that decision
-                    if (ge.filter_edge && alpha * 255.0f >= 1.0f - RL(2e-5)) taint = true;
+                    if (ge.filter_edge && reaches) taint = true;
                     if (ge.ghost) continue;
-                    if (std::fabs(alpha * 255.0f - 1.0f) < RL(2e-5)) {
+                    if (own_edge) {
                         flag = true;
                         uint8_t* bg_flag = &st->borderline_gauss[st->list[k]];
 #pragma omp atomic write
@@ -417,16 +437,28 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                     ++valid_pairs;
                     real test_T = T * (1 - alpha);
                     if (std::fabs(test_T - RL(0.0001)) < RL(2e-8)) flag = true;
-                    if (test_T < RL(0.0001)) break;                                         // Q7: not blended
+                    if (test_T < RL(0.0001)) {                                              // Q7: not blended
+                        done = true;
+                        if (!(flag || taint)) break;          // nothing undecided at this pixel: no shadow needed
+                        const real th = T_hi * (1 - alpha);
+                        if (th < RL(0.0001) - RL(2e-8)) break;
+                        if (!ge.filter_edge && !own_edge) T_hi = th;
+                        continue;
+                    }
                     real wgt = alpha * T;
                     for (int c = 0; c < 3; ++c) C[c] += ge.rgb[c] * wgt;
                     aps += ge.pixel_size * wgt;                                          // SPEC M6
                     adp += ge.depth * wgt;
                     T = test_T;
+                    if (!ge.filter_edge && !own_edge) T_hi *= (1 - alpha);
                     last = contributor;
                 }
-                if (taint) {
-                    flag = true;
+                if (taint) flag = true;
+                if (flag) {
+                    // every Gaussian that reaches this pixel inside the range any implementation may traverse: its term here
+                    // moves with the undecided entry.  filter-edge taint: tier 1 (borderline_gauss, excluded from the strict
+                    // gradient check) as since round 4; an alpha / T decision: tier 2 (shared_gauss), which the strict checks
+                    // still cover — it EXPLAINS an exceedance, it does not excuse one in advance (tests/parity_utils.py)
                     for (uint32_t k = lo; k < k_end; ++k) {
                         const uint32_t id = st->list[k];
                         const Geom& ge = st->geom[id];
@@ -434,9 +466,14 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                         real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                         if (power > 0.0f) continue;
                         if (std::min(RL(0.99), ge.opacity * std::exp(power)) * 255.0f < 1.0f - RL(2e-5)) continue;
-                        uint8_t* bg_flag = &st->borderline_gauss[id];
+                        uint8_t* sh_flag = &st->shared_gauss[id];
 #pragma omp atomic write
-                        *bg_flag = 1;
+                        *sh_flag = 1;
+                        if (taint) {
+                            uint8_t* bg_flag = &st->borderline_gauss[id];
+#pragma omp atomic write
+                            *bg_flag = 1;
+                        }
                     }
                 }
                 const size_t pix = (size_t)y * W + x;
@@ -763,6 +800,7 @@ extern "C" int msgs_oracle_backward(const msgs_oracle_state_t* st, const msgs_vi
 
 extern "C" int64_t msgs_oracle_num_instances(const msgs_oracle_state_t* s) { return (int64_t)s->list.size() - s->ghost_instances; }
 extern "C" const uint8_t* msgs_oracle_filter_edge(const msgs_oracle_state_t* s) { return s->filter_edge.data(); }
+extern "C" const uint8_t* msgs_oracle_shared_borderline_gaussians(const msgs_oracle_state_t* s) { return s->shared_gauss.data(); }
 extern "C" int64_t msgs_oracle_traversed(const msgs_oracle_state_t* s) { return s->traversed; }
 extern "C" int64_t msgs_oracle_valid_pairs(const msgs_oracle_state_t* s) { return s->valid_pairs; }
 extern "C" int64_t msgs_oracle_evaluated_pairs(const msgs_oracle_state_t* s) { return s->evaluated_pairs; }

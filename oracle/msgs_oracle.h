@@ -59,6 +59,14 @@ const uint8_t* msgs_oracle_borderline_gaussians(const msgs_oracle_state_t* state
  * implementation.  Rendered or not, it stays in the tile lists (not blended when dropped), every pixel it reaches with
  * alpha >= 1/255 is reported borderline, and every Gaussian blended at such a pixel is a borderline Gaussian. */
 const uint8_t* msgs_oracle_filter_edge(const msgs_oracle_state_t* state);
+/* [P] 1 = the Gaussian reaches (alpha >= 1/255) a pixel the forward reports borderline — where an alpha sits at 1/255, a
+ * transmittance at 1e-4, or a filter-edge Gaussian arrives — inside the part of the pixel's list that ANY float32
+ * implementation may traverse (the oracle follows the largest transmittance another implementation can hold past its own
+ * termination).  At that pixel the Gaussian's own term moves with the undecided entry: behind it the transmittance scales by
+ * 1 - 1/255, in front of it the colour composited behind changes.  A superset of the filter-edge part of
+ * msgs_oracle_borderline_gaussians; the parity tests keep these Gaussians IN the strict check and use the flag only to
+ * explain an exceedance (tests/parity_utils.py). */
+const uint8_t* msgs_oracle_shared_borderline_gaussians(const msgs_oracle_state_t* state);
 void msgs_oracle_free(msgs_oracle_state_t* state);
 
 #ifdef __cplusplus

@@ -46,8 +46,17 @@ class Grads(C.Structure):
                 ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p)]
 
 
-def build(force=False, f64=False):
-    name = "liboracle64.so" if f64 else "liboracle.so"
+_SO_NAMES = {"f32": "liboracle.so", "f64": "liboracle64.so", "fma": "liboracle_fma.so"}
+
+
+def _variant(f64=False, fma=False):
+    if f64 and fma:
+        raise ValueError("the float64 build has no contraction variant")
+    return "f64" if f64 else ("fma" if fma else "f32")
+
+
+def build(force=False, f64=False, fma=False):
+    name = _SO_NAMES[_variant(f64, fma)]
     so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "msgs_oracle.cpp")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
@@ -55,17 +64,25 @@ def build(force=False, f64=False):
     return so
 
 
-_LIB64 = None
+_LIBS = {}
 
 
-def lib(f64=False):
-    """liboracle.so (float32, THE checker) or — f64 — liboracle64.so: the same source compiled with every computed
-    quantity in double (msgs_oracle.cpp, MSGS_ORACLE_F64), the float64 "truth" at the full BASELINE sizes"""
-    global _LIB, _LIB64
-    if (_LIB64 if f64 else _LIB) is None:
-        so = os.path.join(_HERE, "liboracle64.so" if f64 else "liboracle.so")
+def lib(f64=False, fma=False):
+    """liboracle.so (float32, contraction off: THE checker), — f64 — liboracle64.so: the same source compiled with every computed
+    quantity in double (msgs_oracle.cpp, MSGS_ORACLE_F64), the float64 "truth" at the full BASELINE sizes, or — fma —
+    liboracle_fma.so: the float32 source compiled with FMA contraction (-ffp-contract=fast -mfma), i.e. the reference algorithm
+    under the OTHER legal float32 rounding (what nvcc emits by default for the real CUDA reference): the yardstick of how far
+    two faithful float32 evaluations of this algorithm sit from each other (tests/fuzz_cases.py, tools/parity_floor.py)"""
+    global _LIB
+    key = _variant(f64, fma)
+    if key == "f32" and _LIB is not None and _LIBS.get("f32") is not _LIB:
+        _LIBS["f32"] = _LIB                     # (tools/parity_floor.with_oracle_lib swaps the float32 build through _LIB)
+    if key == "f32" and _LIB is None:
+        _LIBS.pop("f32", None)
+    if _LIBS.get(key) is None:
+        so = os.path.join(_HERE, _SO_NAMES[key])
         if not os.path.exists(so):
-            build(f64=f64)
+            build(f64=f64, fma=fma)
         L = C.CDLL(so)
         L.msgs_oracle_forward.restype = C.c_int
         L.msgs_oracle_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), C.c_void_p, C.c_void_p,
@@ -84,17 +101,16 @@ def lib(f64=False):
             f.restype = C.c_int64
             f.argtypes = [C.c_void_p]
         for name in ("final_T", "n_contrib", "depths", "conic_opacity", "rgb", "means2D", "cov3D", "rects",
-                     "borderline_gaussians", "filter_edge"):
+                     "borderline_gaussians", "filter_edge", "shared_borderline_gaussians"):
             f = getattr(L, "msgs_oracle_" + name)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
         L.msgs_oracle_free.restype = None
         L.msgs_oracle_free.argtypes = [C.c_void_p]
-        if f64:
-            _LIB64 = L
-        else:
+        _LIBS[key] = L
+        if key == "f32":
             _LIB = L
-    return _LIB64 if f64 else _LIB
+    return _LIBS[key]
 
 
 def _f32(t):
@@ -108,22 +124,24 @@ def _ptr(t):
 class OracleResult:
     """Holds the oracle's forward outputs + the native state needed for backward."""
 
-    def __init__(self, f64=False):
+    def __init__(self, f64=False, fma=False):
         self.state = C.c_void_p(None)
         self._keep = []
         self.f64 = bool(f64)
+        self.fma = bool(fma)
+        self._lib = lib(f64, fma)             # the build that owns `state` (freed through the same one)
 
     def __del__(self):
         try:
             if self.state:
-                lib(self.f64).msgs_oracle_free(self.state)
+                self._lib.msgs_oracle_free(self.state)
                 self.state = C.c_void_p(None)
         except Exception:
             pass
 
     def _arr(self, name, shape, dtype):
         """(float arrays of the float64 build hold doubles: pass torch.float64 for them)"""
-        p = getattr(lib(self.f64), "msgs_oracle_" + name)(self.state)
+        p = getattr(self._lib, "msgs_oracle_" + name)(self.state)
         n = int(np.prod(shape))
         if n == 0:
             return torch.zeros(shape, dtype=dtype)
@@ -133,19 +151,19 @@ class OracleResult:
 
     @property
     def num_instances(self):
-        return int(lib(self.f64).msgs_oracle_num_instances(self.state))
+        return int(self._lib.msgs_oracle_num_instances(self.state))
 
     @property
     def traversed(self):
-        return int(lib(self.f64).msgs_oracle_traversed(self.state))
+        return int(self._lib.msgs_oracle_traversed(self.state))
 
     @property
     def valid_pairs(self):
-        return int(lib(self.f64).msgs_oracle_valid_pairs(self.state))
+        return int(self._lib.msgs_oracle_valid_pairs(self.state))
 
     @property
     def evaluated_pairs(self):
-        return int(lib(self.f64).msgs_oracle_evaluated_pairs(self.state))
+        return int(self._lib.msgs_oracle_evaluated_pairs(self.state))
 
 
 def _usable_cpus():
@@ -178,15 +196,15 @@ def _threads(num_threads):
 
 
 def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_precomp=False,
-              cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0, f64=False):
+              cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0, f64=False, fma=False):
     """Forward on a scenes.Scene.  Returns OracleResult with .color/.acc_pixel_size/.depth/.radii/
     .pixel_sizes/.borderline tensors (CPU).  f64: the float64 build — the same float32 inputs, every computed quantity and
-    every output in double (the "truth" of the three-way tests)."""
-    L = lib(f64)
+    every output in double (the "truth" of the three-way tests).  fma: the float32 build with FMA contraction (lib())."""
+    L = lib(f64, fma)
     rdt = torch.float64 if f64 else torch.float32
     W, H = cam.image_width, cam.image_height
     P = scene.P
-    r = OracleResult(f64)
+    r = OracleResult(f64, fma)
     t = dict(means3D=_f32(scene.means3D), opac=_f32(scene.opacities.reshape(-1)),
              maxps=_f32(scene.max_pixel_sizes), minps=_f32(scene.min_pixel_sizes),
              occ=_f32(scene.occ_multiplier), dcd=_f32(scene.dc_delta),
@@ -233,6 +251,9 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     # Gaussians whose multi-scale filter decision could flip in another float32 implementation (msgs_oracle.h)
     r.filter_edge = r._arr("filter_edge", (P,), torch.uint8).bool()
     r.borderline_gaussians |= r.filter_edge
+    # tier 2: Gaussians that share a pixel with ANY undecided discrete decision (msgs_oracle.h).  They stay in the strict checks;
+    # the flag explains an exceedance after the fact (parity_utils.classify_exceedance)
+    r.shared_borderline_gaussians = r._arr("shared_borderline_gaussians", (P,), torch.uint8).bool() | r.borderline_gaussians
     return r
 
 
@@ -240,7 +261,7 @@ def backward(r, dL_dcolor, num_threads=0, want_sums2d=False):
     """Backward on an OracleResult; returns dict of CPU gradient tensors (float32; float64 for a result of the float64
     build).  want_sums2d: also "sums2d", the [P,9] float64 per-Gaussian 2-D gradient sums between the blend backward and the
     per-Gaussian backward (msgs_oracle.h, msgs_oracle_backward_ex)."""
-    L = lib(r.f64)
+    L = r._lib
     rdt = torch.float64 if r.f64 else torch.float32
     P, K = r.P, r.K
     dl = _f32(dL_dcolor)

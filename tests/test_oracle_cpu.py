@@ -2,6 +2,7 @@
 oracle, both against the committed golden fixtures, and the restated helpers against the fixtures that
 were generated from the reference's own importable functions (tests/golden/make_golden.py)."""
 import copy
+import math
 import os
 
 import numpy as np
@@ -248,6 +249,73 @@ def test_filter_edge_flags_cover_everything_a_flipped_filter_decision_changes():
     # and with a fade ramp the decision is continuous: nothing is flagged
     r = oc.rasterize(s2, cam, dict(st, fade_size=0.5), bg)
     assert int(r.filter_edge.sum()) == 0
+
+
+def test_shared_flags_cover_everything_a_flipped_alpha_decision_changes():
+    """An alpha within float32 rounding of 1/255 may be blended by one implementation and skipped by another.  The oracle flags
+    the pixel and the Gaussian itself (tier 1) — and, since round 5, every Gaussian that reaches that pixel inside the range any
+    implementation may traverse (tier 2, shared_borderline_gaussians): behind the undecided entry the transmittance scales by
+    1 - 1/255, in front of it the colour composited behind changes.  Here 20 Gaussians get an opacity that puts their alpha at one
+    chosen pixel 3e-7 (relative) above and 3e-7 below 1/255 — both sides of the decision, five float32 ulps apart — and
+    everything that differs between the two renders by more than that perturbation itself can explain has to be inside the
+    flagged sets of BOTH renders."""
+    W, H = 96, 64
+    cam = scenes.front_camera(W, H)
+    sc = scenes.frustum_scene(1500, W, H, seed=43, scale_k=_k(W, 0.6))
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    dL = scenes.grad_seed(W, H, 43) * W * H
+    r0 = oc.rasterize(sc, cam, ST0, bg)
+    co = r0._arr("conic_opacity", (sc.P, 4), torch.float32).double()
+    m2 = r0._arr("means2D", (sc.P, 2), torch.float32).double()
+    ncontrib = r0._arr("n_contrib", (H, W), torch.int32)
+    vis = torch.nonzero(r0.radii > 2).squeeze(1)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    chosen, target = [], []
+    for i in vis[torch.randperm(vis.numel(), generator=torch.Generator().manual_seed(2))].tolist():
+        dx, dy = m2[i, 0] - xs, m2[i, 1] - ys
+        power = -0.5 * (co[i, 0] * dx * dx + co[i, 2] * dy * dy) - co[i, 1] * dx * dy
+        # a pixel of its footprint where exp(power) ~ e^-3 and the pixel is alive deep into its list
+        cand = (power < -2.0) & (power > -4.5) & (ncontrib > 3)
+        if not cand.any():
+            continue
+        flat = torch.nonzero(cand.reshape(-1)).squeeze(1)
+        j = flat[torch.argmin((power.reshape(-1)[flat] + 3.0).abs())].item()
+        o = (1.0 / 255.0) / math.exp(power.reshape(-1)[j].item())
+        if not (0.02 < o < 0.9):
+            continue
+        chosen.append(i)
+        target.append(o)
+        if len(chosen) == 20:
+            break
+    assert len(chosen) == 20
+    idx = torch.tensor(chosen)
+    res = []
+    for sign in (+1.0, -1.0):
+        s2 = copy.copy(sc)
+        op = sc.opacities.clone().double()
+        op[idx, 0] = torch.tensor(target, dtype=torch.float64) * (1.0 + sign * 3e-7)
+        s2.opacities = op.float()
+        r = oc.rasterize(s2, cam, ST0, bg)
+        res.append((r, oc.backward(r, dL)))
+    (ra, ga), (rb, gb) = res
+    assert torch.equal(ra.radii, rb.radii)
+    # the two sides decided differently somewhere: pixels moved by far more than the 3e-7 perturbation explains
+    d_px = (ra.color.double() - rb.color.double()).abs().max(dim=0).values
+    moved = d_px > 2e-6
+    assert moved.any()
+    assert not (moved & ~ra.borderline.bool()).any() and not (moved & ~rb.borderline.bool()).any()
+    assert ra.borderline_gaussians[idx].any() and rb.borderline_gaussians[idx].any()
+    assert (ra.shared_borderline_gaussians >= ra.borderline_gaussians).all()
+    covered_strictly_more = False
+    for k in ga:
+        a, b = ga[k].double().reshape(sc.P, -1), gb[k].double().reshape(sc.P, -1)
+        scale = max(a.abs().max().item(), 1e-30)
+        changed = ((a - b).abs().max(dim=1).values / scale) > 2e-5
+        assert not (changed & ~ra.shared_borderline_gaussians).any(), k
+        assert not (changed & ~rb.shared_borderline_gaussians).any(), k
+        covered_strictly_more |= bool((changed & ~ra.borderline_gaussians).any())
+    # tier 1 alone (the flags of rounds 1-4) does NOT cover what a flipped alpha changes: the neighbours at the pixel move too
+    assert covered_strictly_more
 
 
 def test_c_oracle_clamped_projection_and_ring_camera():

@@ -1,107 +1,22 @@
-"""Randomised parity sweep (not a test): N random small scenes — Gaussian count, image size (ragged), SH degree, multi-scale
-filters, fade, background, kernel granularity, reference-API vs fused entry — HIP forward + backward against the float32 oracle
-with the north-star tolerances of tests/parity_utils.py.  Prints one line per failure and a summary.
-usage: python tools/fuzz_parity.py [N=200] [seed=0] [truth]
-truth: every configuration is ALSO checked three ways against the float64 build of the oracle (parity_utils.check_against_truth:
-HIP-vs-truth <= 1.25 x oracle-vs-truth + 1e-6 per tensor and for the forward) and the violations are counted separately."""
-import os, sys, random, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests"),
-          os.path.join(ROOT, "tools")):
-    sys.path.insert(0, p)
-import torch
-import scenes
-import diff_gaussian_rasterization as dgr
-from oracle import oracle_ctypes as oc
-from parity_utils import check_against_truth, check_backward, check_forward, hip_render, small_scene
+"""Randomised three-way parity sweep (long runs; the asserted 320-configuration version is tests/test_fuzz_parity_gpu.py).
+usage: python tools/fuzz_parity.py [N=1000] [seed=0] [summary.json]
+Prints one line per exceedance with its class (tests/fuzz_cases.py) and the summary; writes it as JSON when a path is given."""
+import json
+import os
+import sys
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-TRUTH = len(sys.argv) > 3 and sys.argv[3] == "truth"
-bad = truth_bad = truth_bad2 = truth_flip = 0
-hip_worst = 0.0
-for it in range(N):
-    P = rng.choice([1, 2, 7, 63, 64, 65, 200, 777, 1500, 4001, 9000])
-    W, H = rng.randint(1, 260), rng.randint(1, 200)
-    deg = rng.randint(0, 3)
-    ms = rng.random() < 0.5
-    fade = rng.choice([0.0, 0.5, 1.0])
-    gran = rng.choice([0, 1, 2])
-    bwd_gen = rng.choice([0, 1, 2])
-    fwd_var = rng.choice([0, 0, 1, 3, 4, 5, 6])
-    seed = rng.randint(0, 10 ** 6)
-    cfg = dict(P=P, W=W, H=H, deg=deg, ms=ms, fade=fade, gran=gran, bwd_gen=bwd_gen, fwd_var=fwd_var, seed=seed)
-    try:
-        sc, cam = small_scene(P, W, H, seed, sh_degree=deg, multiscale=ms,
-                              **({"scale_k": 0.004 * 1920.0 / max(W, 8) * 0.3} if ms else {}))
-        st = dict(filter_small=ms, filter_large=ms, fade_size=fade)
-        bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
-        dL = scenes.grad_seed(W, H, seed % 97)
-        pg = dgr._C.lib.msgs_set_blend_granularity(gran)
-        pb = dgr._C.lib.msgs_set_backward_generation(bwd_gen)
-        pf = dgr._C.lib.msgs_set_forward_variant(fwd_var)
-        try:
-            out, pc, m2 = hip_render(sc, cam, st, bg, dL)
-        finally:
-            dgr._C.lib.msgs_set_blend_granularity(pg)
-            dgr._C.lib.msgs_set_forward_variant(pf)
-            dgr._C.lib.msgs_set_backward_generation(pb)
-        orc = oc.rasterize(pc.seen, cam, st, bg)
-        og = oc.backward(orc, dL)
-        if TRUTH:
-            dist = check_against_truth(str(cfg), pc.seen, cam, st, bg, dL, out, pc, m2, orc, og, enforce=False)
-            grads = {k: v for k, v in dist.items() if k != "forward"}
-            if any(h > 1.25 * o + 1e-6 for h, o in dist.values()):
-                truth_bad += 1
-            # the north star's own terms: within 1e-4 (gradients) / 1e-5 (forward) of the TRUTH, or no farther than the oracle
-            worst = max(grads.items(), key=lambda kv: kv[1][0] - max(1.25 * kv[1][1] + 1e-6, 1e-4))
-            if worst[1][0] > max(1.25 * worst[1][1] + 1e-6, 1e-4) or dist["forward"][0] > max(1.25 * dist["forward"][1] + 1e-6, 1e-5):
-                truth_bad2 += 1
-                # mechanism: does a pixel where HIP and the oracle verifiably took DIFFERENT discrete decisions (a borderline
-                # pixel with |dcolor| > 1e-5) lie inside the footprint of a clean Gaussian?  (the oracle flags the Gaussian whose own
-                # alpha sits at 1/255, not the ones that share the pixel)
-                dcol = (out["render"].detach().cpu() - orc.color).abs().max(dim=0).values
-                flipped = orc.borderline.bool() & (dcol > 1e-5)
-                nflip = int(flipped.sum())
-                truth_flip += 1 if nflip else 0
-                print("TRUTH", cfg, worst[0], "HIP %.3e oracle %.3e" % worst[1], "forward HIP %.3e oracle %.3e" % dist["forward"],
-                      "flipped borderline pixels", nflip)
-            hip_worst = max(hip_worst, max(h for h, _ in grads.values()))
-        check_forward(out, orc, str(cfg))
-        check_backward(pc, m2, og, str(cfg), flagged=orc.borderline_gaussians)
-    except Exception as e:                                  # noqa: BLE001
-        bad += 1
-        print("FAIL", cfg, repr(e)[:160])
-        msg = str(e)
-        if "grad scaling" in msg or "grad rotation" in msg:
-            # is it the float32 floor of the reference algorithm itself?  the same oracle source compiled with FMA contraction
-            # (tools/parity_floor.py) against the plain oracle, same tensor, same exclusions
-            try:
-                import parity_floor as pf
-                so = pf.build_fma_oracle()
-                og2 = pf.with_oracle_lib(so, lambda: oc.backward(oc.rasterize(pc.seen, cam, st, bg), dL))
-                clean = ~orc.borderline_gaussians
-                for k in ("scales", "rotations"):
-                    ref = og[k].double()
-                    d = (og2[k].double() - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values
-                    print(f"     oracle vs FMA-contracted oracle, {k}: {(d[clean].max() / ref.abs().max().clamp_min(1e-30)).item():.3e}")
-                # and both float32 evaluations against the float64 autograd truth of the same pipeline
-                from oracle import torch_oracle as to
-                t_out, tg = to.forward_backward_tiled(pc.seen, cam, st, bg, dL)
-                flagged = orc.borderline_gaussians | (t_out["radii"] != orc.radii)
-                w_hip = check_backward(pc, m2, {k: v.float() for k, v in tg.items()}, "truth", flagged=flagged, rtol=1.0)
-                for k, kk in (("scales", "scaling"), ("rotations", "rotation")):
-                    ref = tg[k].double()
-                    d = (og[k].double().reshape(ref.shape) - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values
-                    e_orc = (d[~flagged].max() / ref.abs().max().clamp_min(1e-30)).item()
-                    print(f"     vs float64 truth, {kk}: oracle_f32 {e_orc:.3e}   HIP {w_hip[kk]:.3e}")
-            except Exception as e2:                         # noqa: BLE001
-                print("     (floor check failed:", repr(e2)[:160], ")")
-        elif "borderline" not in msg and bad <= 3:
-            traceback.print_exc()
-print(f"fuzz: {N - bad} / {N} configurations within tolerance")
-if TRUTH:
-    print(f"fuzz three-way: {N - truth_bad} / {N} configurations with HIP no farther from the float64 truth than 1.25 x the float32 "
-          f"oracle + 1e-6 on every tensor; {N - truth_bad2} / {N} with every HIP gradient within max(1e-4, 1.25 x oracle + 1e-6) of the "
-          f"truth and the forward within max(1e-5, ...) — {truth_flip} of the others contain a borderline pixel at which HIP and the "
-          f"oracle took different decisions; largest HIP-vs-truth gradient distance of the sweep {hip_worst:.3e}")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ms-gs_amd"), os.path.join(ROOT, "ms-gs_amd", "host"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import fuzz_cases  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+results, s = fuzz_cases.run_sweep(N, seed)
+print("fuzz summary:", json.dumps(s, indent=1))
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as f:
+        json.dump({"n": N, "seed": seed, "summary": s,
+                   "exceedances": [{"cfg": r["cfg"], "status": r["status"], "detail": r["detail"]}
+                                   for r in results if r["status"] != "pass"]}, f, indent=1)
+raise SystemExit(1 if s["unexplained"] else 0)
