@@ -26,12 +26,12 @@
  *
  * Threading: re-entrant (forward is called from the Python main thread, backward from PyTorch's
  * autograd thread).  Not stateless:
- *   - four PROCESS-WIDE mode flags: msgs_set_deterministic, msgs_set_backward_generation, msgs_set_blend_granularity,
- *     msgs_set_forward_variant (the last three only choose between kernels that give the same results);
+ *   - five PROCESS-WIDE mode flags: msgs_set_deterministic, msgs_set_backward_generation, msgs_set_blend_granularity,
+ *     msgs_set_forward_variant, msgs_set_occlusion (the last four only choose between code paths that give the same results);
  *   - environment switches latched on first use (process-wide, for A/B measurements; every one only selects between
  *     code paths with the same results): MSGS_BLOCKING_SYNC, MSGS_NO_SPECULATIVE_STAGE2, MSGS_BWD_LPT,
  *     MSGS_SORT_TILE_PASSES, MSGS_SORT_NO_COMPACT, MSGS_SORT_ONESWEEP, MSGS_SORT_SCAN_TABLE, MSGS_SORT_DIRECT_SCATTER,
- *     MSGS_FINE_SB, MSGS_FINE_SPLIT (full list with meanings: INTEGRATION.md §3);
+ *     MSGS_FINE_SB, MSGS_FINE_SPLIT, MSGS_NO_OCCLUSION, MSGS_OCC_BLOCK (full list with meanings: INTEGRATION.md §3);
  *   - one 64-byte pinned status block per calling host thread for the calls that WAIT for the instance count
  *     (msgs_forward, msgs_forward_stage1), and one per msgs_status_t handle for msgs_forward_launch /
  *     msgs_forward_finish — any number of forwards may be in flight from one host thread on any streams, one per handle.
@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 8
+#define MSGS_ABI_VERSION 9
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -312,6 +312,22 @@ int msgs_set_blend_granularity(int32_t mode);
  * the same order: outputs are bit-identical; for the parity tests and A/B measurements (none of 3-6 beats 1: DESIGN.md 4.1).
  * Initial value from MSGS_FWD_GEN.  Returns the previous value. */
 int msgs_set_forward_variant(int32_t variant);
+
+/* Exact per-tile occlusion cut-off (round 5; process-wide switch, on by default, initial value off with MSGS_NO_OCCLUSION=1).
+ * Between the per-Gaussian stage and the depth sort the forward finds, per block of tiles, the view depth behind which every
+ * pixel of the block has provably met the reference's termination rule T (1 - alpha) < 1e-4 — from the Gaussians whose
+ * alpha >= 1/255 level set contains the whole block, their smallest alpha over it, and the product of (1 - alpha_min) front to
+ * back with a factor 2 of slack — and neither counts, emits nor sorts the tile instances behind it.  The lists the pixels
+ * walk are unchanged entry for entry: every output and gradient is bit-identical to the uncut path; only the instance count D
+ * shrinks (the multi-scale model rendered without its filters, /root/reference/render.py:32: 427 M -> a few million at
+ * 1080p).  msgs_set_occlusion returns the previous value.
+ * msgs_occlusion_stats reads what the pass did for the forward that last wrote `geom`: out_host[8] = {ran (0 / 1), Gaussians
+ * with more than 96 tile instances, cover candidates sampled from them (at most 16 384), cover blocks that received a cut-off,
+ * cover blocks of the view, tiles per side of a cover block, smallest and largest cut-off (float32 bits of a view depth;
+ * 0xFFFFFFFF = a block stayed open)}.  (The instances removed = the instance count of the same view with the pass switched
+ * off minus the one with it on.)  Synchronises `stream`; not re-entrant (a diagnostic). */
+int msgs_set_occlusion(int32_t on);
+int msgs_occlusion_stats(const void* geom, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream);
 
 /* msgs_forward: both stages in ONE call.  The caller passes `binning` and `scratch2` sized for a GUESS of the instance count
  * (the previous frame's D plus a margin).  Stage 1 is launched, stage 2 is launched right behind it on those buffers — sized for

@@ -110,6 +110,7 @@ int msgs_get_deterministic(void) { return g_deterministic.load(); }
 int msgs_set_backward_generation(int32_t gen) { return set_backward_generation(gen); }
 int msgs_set_blend_granularity(int32_t mode) { return set_blend_granularity(mode); }
 int msgs_set_forward_variant(int32_t variant) { return set_forward_variant(variant); }
+int msgs_set_occlusion(int32_t on) { return set_occlusion(on); }
 
 }  // extern "C"
 
@@ -206,17 +207,25 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     const ViewParams vp = make_view_params(view);
     const Timer tm{timing, s};
 
-    // K1 also clears the depth sort's group-sum table (saves a fill launch)
-    ZeroJob zj1{nullptr, 0, nullptr, 0};
+    // K1 also clears the depth sort's group-sum table (saves a fill launch) and the header of the occlusion cut-off
+    // (enabled = 0, no candidates: what the emit reads when the pass does not run)
+    ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.occ_hdr), sizeof(OccHeader) / 4};
     const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
+    // exact per-tile occlusion cut-off (occlusion.hip): on unless switched off
+    const bool occlusion = get_occlusion() != 0;
+    uint32_t* heavy_list = occlusion ? (uint32_t*)(scratch + SL.heavy_list) : nullptr;
+    uint32_t* heavy_count = occlusion ? (uint32_t*)(scratch + SL.heavy_count) : nullptr;
     tm.begin(MSGS_K_PREPROCESS);
-    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1));
+    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, heavy_list, heavy_count));
+    if (occlusion)      // (timed with K1: three small launches, ~7 us when nothing closes)
+        HIP_TRY(launch_occlusion(vp, P, geom, heavy_list, heavy_count, (OccCand*)(scratch + SL.occ_cand), s));
     tm.end(MSGS_K_PREPROCESS);
     if ((rc = debug_sync(view, s))) return rc;
 
-    // depth order of the Gaussians (not rendered -> key 0xFFFFFFFF -> sorted last, zero tiles)
+    // depth order of the Gaussians (not rendered -> key 0xFFFFFFFF -> sorted last, zero tiles); the sorted keys stay in geom:
+    // the emit compares them with the tiles' cut-off keys
     tm.begin(MSGS_K_DEPTH_SORT);
-    HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(scratch + SL.keys_a),
+    HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(geom + GL.skey),
                              (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed,
                              (uint32_t*)(geom + GL.nvalid)));
     tm.end(MSGS_K_DEPTH_SORT);
@@ -666,6 +675,39 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
     HIP_TRY(hipStreamSynchronize(s));
     out_host[0] = (int64_t)host[0];
     out_host[1] = (int64_t)host[1];
+    return MSGS_OK;
+}
+
+int msgs_occlusion_stats(const void* geom_v, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream) {
+    if (!geom_v || !out_host || P <= 0) return MSGS_ERR_INVALID_ARG;
+    if (geom_bytes < msgs_geom_bytes(P)) return MSGS_ERR_CAPACITY;
+    const GeomLayout GL(P);
+    OccHeader h;
+    hipStream_t s = (hipStream_t)stream;
+    static uint32_t table[OCC_MAX_BLOCKS];               // (diagnostic entry: serialised by the synchronisation below)
+    HIP_TRY(hipMemcpyAsync(&h, (const char*)geom_v + GL.occ_hdr, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 8; ++k) out_host[k] = 0;
+    out_host[0] = h.enabled;
+    if (!h.enabled) return MSGS_OK;
+    const int n_blocks = (int)(h.nbx * h.nby);
+    if (n_blocks < 0 || n_blocks > OCC_MAX_BLOCKS) return MSGS_ERR_INTERNAL;
+    HIP_TRY(hipMemcpyAsync(table, (const char*)geom_v + GL.occ_cut, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    int closed = 0;
+    for (int k = 0; k < n_blocks; ++k) {
+        closed += table[k] != 0xFFFFFFFFu;
+        lo = table[k] < lo ? table[k] : lo;
+        hi = table[k] > hi ? table[k] : hi;
+    }
+    out_host[1] = h.n_heavy;
+    out_host[2] = h.n_cand;
+    out_host[3] = closed;
+    out_host[4] = n_blocks;
+    out_host[5] = 1u << h.block_log2;
+    out_host[6] = lo;
+    out_host[7] = hi;
     return MSGS_OK;
 }
 

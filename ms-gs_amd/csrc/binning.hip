@@ -42,17 +42,31 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
     const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
+    // occlusion cut-off (occlusion.hip): a tile whose cut-off depth key lies in front of this Gaussian's key receives no
+    // instance of it — the same predicate the recount applied to the counts the scan summed
+    const OccHeader* occ = reinterpret_cast<const OccHeader*>(geom + L.occ_hdr);
+    const bool occ_on = occ->enabled != 0u && occ->any_closed != 0u;             // block-uniform (scalar loads)
+    __shared__ OccTable T;                                 // cut-off key per cover block (loaded only when something closed)
+    const int occ_lb = (int)occ->block_log2, occ_nbx = (int)occ->nbx;
 
     if (D_dev) D = (int64_t)*D_dev;      // speculative stage 2: min(instance count, capacity), from the scan
     const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
     const int r0 = blockIdx.x * blockDim.x;
     if (r0 >= V) return;
+    uint32_t cut_min = 0xFFFFFFFFu;
+    if (occ_on) {
+        occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), occ_nbx, (int)occ->nby);
+        cut_min = T.cut_min;
+    }
     const int r = r0 + threadIdx.x;
     const int rlast = min(r0 + (int)blockDim.x, V) - 1;
     uint32_t gi = 0, count = 0;
     int64_t off = 0;
     // the count of rank r is the difference of consecutive scanned offsets (coalesced; no gather of tiles[order[r]])
+    uint32_t kmine = 0;
     if (r < V) { gi = order[r]; off = offs[r]; count = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - off); }
+    if (cut_min != 0xFFFFFFFFu && r < V) kmine = reinterpret_cast<const uint32_t*>(geom + L.skey)[r];
+    const bool cut_check = kmine > cut_min;       // some tile may be closed in front of this Gaussian
     s_gi[threadIdx.x] = gi;
     if (threadIdx.x == 0) s_range[0] = off;
     if (r == rlast) s_range[1] = min((int64_t)off + count, D);
@@ -66,13 +80,17 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     // lanes wait made the emit 4.3 ms for the 427 M instances of a multi-scale model rendered without its filters
     // (render.py's defaults; 145 k Gaussians wider than 256 px), i.e. 0.8 TB/s of stores.
     constexpr uint32_t HEAVY_MIN = 96;
-    const bool heavy = count > HEAVY_MIN;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (count) { q0 = binrec[gi].q0; q1 = binrec[gi].q1; }
+    // a Gaussian behind some cut-off with a large rect walks its tiles with the whole wave as well, however few of them are
+    // left: one thread skipping thousands of closed tiles would hold its wave for as long
+    const uint32_t rect_area = ((__float_as_uint(q1.w) & 0xFFFFu) - (__float_as_uint(q1.z) & 0xFFFFu)) *
+                               ((__float_as_uint(q1.w) >> 16) - (__float_as_uint(q1.z) >> 16));
+    const bool heavy = count > HEAVY_MIN || (count > 0 && cut_check && rect_area > 64u);
     auto put = [&](int64_t at, uint32_t k, uint32_t g_id, uint32_t owner) {
         if (staged) { s_keys[at - blk_lo] = (KeyT)k; s_own[at - blk_lo] = (uint8_t)owner; }
         else { keys[at] = (OutT)k; ids[at] = g_id; }
     };
-    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-    if (count) { q0 = binrec[gi].q0; q1 = binrec[gi].q1; }
     if (count && !heavy) {
         const int64_t end = min((int64_t)off + count, D);
         const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
@@ -82,9 +100,11 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
         const bool test = tau2 > -1.0e38f;
         const LevelSetRows ls = test ? levelset_rows_setup(q0.z, q0.w, conC, tau2) : LevelSetRows{};
         for (int ty = miny; ty < maxy && off < end; ++ty) {
+            if (cut_check && T.rowmax[ty >> occ_lb] < kmine) continue;          // this row of blocks is closed at this depth
             int tlo = minx, thi = maxx - 1;
             if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi)) continue;
             for (int tx = tlo; tx <= thi && off < end; ++tx) {
+                if (cut_check && T.cut[(ty >> occ_lb) * occ_nbx + (tx >> occ_lb)] < kmine) continue;
                 put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
                 ++off;
             }
@@ -105,6 +125,8 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
             const uint32_t h_owner = (uint32_t)((threadIdx.x & ~63) + src);
             const int64_t h_off = ((int64_t)__shfl((int)(uint32_t)(off >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)off, src);
             const uint32_t h_count = (uint32_t)__shfl((int)count, src);
+            const uint32_t h_key = (uint32_t)__shfl((int)kmine, src);
+            const bool h_check = h_key > cut_min;
             const int64_t h_end = min(h_off + (int64_t)h_count, D);
             const float gx_ = __shfl(q0.x, src), gy_ = __shfl(q0.y, src), cA = __shfl(q0.z, src), cBh = __shfl(q0.w, src);
             const float cC = __shfl(q1.x, src), tau2 = __shfl(q1.y, src);
@@ -117,17 +139,30 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
                 const int ty = row0 + lane;
                 int tlo = minx, thi = maxx - 1;
                 bool hit = ty < maxy;
+                if (hit && h_check) hit = T.rowmax[ty >> occ_lb] >= h_key;   // rows of blocks that are closed at this depth
                 if (hit && test) hit = levelset_row_interval(ls, gx_, gy_, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi);
                 const int n_row = hit ? thi - tlo + 1 : 0;
-                const int nrows = min(64, maxy - row0);
-                for (int r = 0; r < nrows && at < h_end; ++r) {        // wave-uniform: row r of this group of 64
+                uint64_t rows = __ballot(n_row > 0);
+                while (rows && at < h_end) {                           // wave-uniform: the rows that receive something
+                    const int r = __ffsll((long long)rows) - 1;
+                    rows &= rows - 1;
                     const int n_r = __shfl(n_row, r);
-                    if (n_r == 0) continue;
                     const int tlo_r = __shfl(tlo, r);
                     const uint32_t kbase = (uint32_t)((row0 + r) * vp.gx + tlo_r);
-                    for (int j = lane; j < n_r; j += 64)
-                        if (at + j < h_end) put(at + j, kbase + (uint32_t)j, h_gi, h_owner);
-                    at += n_r;
+                    if (!h_check) {
+                        for (int j = lane; j < n_r; j += 64)
+                            if (at + j < h_end) put(at + j, kbase + (uint32_t)j, h_gi, h_owner);
+                        at += n_r;
+                    } else {                                           // only the tiles still open at this depth, compacted
+                        for (int j0 = 0; j0 < n_r; j0 += 64) {
+                            const int j = j0 + lane;
+                            const bool keep = j < n_r && T.cut[((row0 + r) >> occ_lb) * occ_nbx + ((tlo_r + j) >> occ_lb)] >= h_key;
+                            const uint64_t km = __ballot(keep);
+                            const int64_t pos = at + __popcll(km & ((1ull << lane) - 1ull));
+                            if (keep && pos < h_end) put(pos, kbase + (uint32_t)j, h_gi, h_owner);
+                            at += __popcll(km);
+                        }
+                    }
                 }
             }
             for (int64_t a = at + lane; a < h_end; a += 64) put(a, (uint32_t)(vp.gx * vp.gy), h_gi, h_owner);   // surplus -> sentinel

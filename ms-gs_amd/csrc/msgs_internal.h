@@ -50,8 +50,41 @@ constexpr int DET_INST_FLOATS = 9;      // per tile entry in deterministic mode:
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// ---------------------------------------------------------------------------------------------
+// Per-tile occlusion cut-off (occlusion.hip; round 5).  A Gaussian whose alpha >= 1/255 level set contains a whole block of
+// tiles blends into EVERY pixel of it with at least alpha_min (the value at the far corner); once the product of
+// (1 - alpha_min) over such covers, front to back, has fallen below 1e-4 — with a factor 2 of slack — every pixel of the block
+// has met the termination rule T (1 - alpha) < 1e-4, and no entry behind that depth is ever evaluated there:
+// those instances are not counted, emitted or sorted.  Outputs, n_contrib and all gradients are bit-identical to the uncut
+// path.  What it buys: the multi-scale model rendered without its filters (render.py's defaults) has 427 M instances of which a
+// few million are traversed.
+// Region inside `geom` (fixed size: msgs_geom_bytes(P) does not know the image): header + one cut-off depth key per cover
+// BLOCK of B x B tiles, B = the smallest power of two from MSGS_OCC_BLOCK (default 4) up for which the grid has at most
+// OCC_MAX_BLOCKS blocks — the table then fits the LDS of the two kernels that look tiles up in it (emit, recount).
+// ---------------------------------------------------------------------------------------------
+constexpr int OCC_MAX_BLOCKS = 2048;
+constexpr int OCC_MAX_CAND = 16384;         // cover candidates kept per view (a deterministic sample when there are more)
+constexpr uint32_t OCC_HEAVY_MIN = 96;      // tile instances a Gaussian needs to be a cover candidate (= emit's wave path)
+constexpr int OCC_BUCKETS = 2048;           // depth buckets of the front-to-back accumulation: key >> 19, i.e. 1/16 octave
+constexpr int OCC_KEY_SHIFT = 19;
+constexpr uint32_t OCC_KEY_BASE = 0x3E4CCCCDu >> OCC_KEY_SHIFT;   // bucket of depth 0.2 (the near cull, Q1)
+struct OccHeader {
+    uint32_t n_cand;          // cover candidates the gather kept (<= OCC_MAX_CAND)
+    uint32_t any_closed;      // non-zero when some cover block received a finite cut-off (plain stores of 1 by the cover kernel)
+    uint32_t n_heavy;         // Gaussians with more than OCC_HEAVY_MIN tile instances (n_cand of them are sampled as covers)
+    uint32_t enabled;         // 1 when the pass ran for this view
+    uint32_t block_log2;      // log2 of the tiles per side of a cover block
+    uint32_t nbx;             // cover blocks per row of blocks
+    uint32_t nby;             // rows of cover blocks (nbx * nby <= OCC_MAX_BLOCKS)
+    uint32_t pad[9];          // (no instance statistics: one atomic per wave on a shared word cost 0.4 ms on a view that
+                              //  drops 420 M instances; run the view with msgs_set_occlusion(0) to learn the uncut count)
+};
+static_assert(sizeof(OccHeader) == 64, "OccHeader layout");
+// candidate record: { px, py, kA, kB | kC, log2 o, key bits, gaussian id }
+struct __attribute__((aligned(32))) OccCand { float4 c0, c1; };
+
 struct GeomLayout {
-    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, total;
+    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, skey, occ_hdr, occ_cut, total;
     __host__ __device__ explicit GeomLayout(int64_t P) {
         size_t o = 0;
         rec = o;    o = align256(o + sizeof(GaussRec) * P);
@@ -62,8 +95,12 @@ struct GeomLayout {
         weight = o; o = align256(o + 4 * P);        // multi-scale fade weight
         order = o;  o = align256(o + 4 * P);        // Gaussian ids in depth order
         offs = o;   o = align256(o + 4 * P);        // exclusive scan of tiles[order[r]]
-        nvalid = o;                                 // one word: V = Gaussians that stayed in the (compacting) depth sort —
-        total = o + 256;                            // order[0..V) / offs[0..V) are the ranks the scan and the emit cover
+        nvalid = o; o += 256;                       // one word: V = Gaussians that stayed in the (compacting) depth sort —
+                                                    // order[0..V) / offs[0..V) are the ranks the scan and the emit cover
+        skey = o;   o = align256(o + 4 * P);        // depth keys in depth order (the sort's key output): emit's cut-off test
+        occ_hdr = o; o = align256(o + sizeof(OccHeader));
+        occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth key per cover block (0xFFFFFFFF = open)
+        total = o;
     }
 };
 
@@ -100,13 +137,19 @@ struct SortScratch {
 };
 
 struct Stage1Scratch {
-    size_t keys_a, sort, scan_partials, total_out, total;
+    size_t sort, scan_partials, total_out, heavy_list, heavy_count, occ_cand, total;
     __host__ __device__ explicit Stage1Scratch(int64_t P) {
         size_t o = 0;
-        keys_a = o;        o = align256(o + 4 * (size_t)(P > 0 ? P : 1));
+        const size_t Pn = (size_t)(P > 0 ? P : 1);
+        const size_t waves = 4 * ((Pn + 255) / 256);          // wave slots of preprocess_kernel's grid
         sort = o;          o = align256(o + SortScratch(P).total);
         scan_partials = o; o = align256(o + 8 * (size_t)(scan_blocks(P > 0 ? P : 1) + 2));
         total_out = o;     o = align256(o + 64);    // {scan total} and the collected status block
+        // occlusion cut-off: cover candidates as preprocess_kernel leaves them (per wave: up to 64 Gaussian ids + a count),
+        // and their gathered records (one per candidate)
+        heavy_list = o;    o = align256(o + 4 * 64 * waves);
+        heavy_count = o;   o = align256(o + 4 * waves);
+        occ_cand = o;      o = align256(o + sizeof(OccCand) * OCC_MAX_CAND);
         total = o;
     }
 };
@@ -284,6 +327,44 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return v;
 }
 
+// The cover-block table of the occlusion cut-off in LDS, with what its two readers (recount, emit) ask first: the smallest
+// and the largest cut-off key and the largest key per ROW of blocks (a Gaussian whose depth key is larger has nothing to emit
+// in that row of blocks).  Called by all threads of the block; ends with a barrier.
+struct OccTable {
+    uint32_t cut[OCC_MAX_BLOCKS];
+    uint32_t rowmax[OCC_MAX_BLOCKS];      // (nby entries used)
+    uint32_t red[2][16];
+    uint32_t cut_min, cut_max;
+};
+__device__ __forceinline__ void occ_table_load(OccTable& t, const uint32_t* __restrict__ occ_cut, int nbx, int nby) {
+    const int n = nbx * nby;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int q = threadIdx.x; q < n; q += blockDim.x) {
+        const uint32_t c = occ_cut[q];
+        t.cut[q] = c;
+        lo = min(lo, c);
+        hi = max(hi, c);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) { t.red[0][threadIdx.x >> 6] = lo; t.red[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    for (int by = threadIdx.x; by < nby; by += blockDim.x) {
+        uint32_t m = 0u;
+        for (int bx = 0; bx < nbx; ++bx) m = max(m, t.cut[by * nbx + bx]);
+        t.rowmax[by] = m;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t a = 0xFFFFFFFFu, b = 0u;
+        for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) { a = min(a, t.red[0][w]); b = max(b, t.red[1][w]); }
+        t.cut_min = a;
+        t.cut_max = b;
+    }
+    __syncthreads();
+}
+
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------
@@ -319,8 +400,18 @@ inline ViewParams make_view_params(const msgs_view_t* v) {
 struct ZeroJob { uint32_t* p0; size_t n0; uint32_t* p1; size_t n1; };
 
 // preprocess.hip
+// heavy_list / heavy_count (nullable): per wave of the grid, the ids of its Gaussians with more than OCC_HEAVY_MIN tile
+// instances (cover candidates of the occlusion cut-off) and their number
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0});
+                             char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0},
+                             uint32_t* heavy_list = nullptr, uint32_t* heavy_count = nullptr);
+// occlusion.hip: gather the candidates, accumulate the covers per block of tiles front to back, recount the Gaussians behind a
+// cut-off (tiles[] / key[] of `geom` are updated in place, before the depth sort)
+hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint32_t* heavy_list, const uint32_t* heavy_count,
+                            OccCand* cand, hipStream_t s);
+int set_occlusion(int on);                // occlusion.hip: process-wide switch (MSGS_NO_OCCLUSION=1 initially off); returns previous
+int get_occlusion();
+int occlusion_block_log2(int gx, int gy);  // log2(tiles per side of a cover block) for a gx x gy grid (MSGS_OCC_BLOCK: minimum, default 4)
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s, bool textbook = false);

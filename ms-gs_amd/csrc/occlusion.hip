@@ -1,0 +1,347 @@
+// occlusion.hip — exact per-tile occlusion cut-off in front of the depth sort and the emit (round 5).
+//
+// The reference emits, sorts and walks every (tile, Gaussian) instance of a view; a pixel stops walking its tile's list at the
+// first entry where T (1 - alpha) < 1e-4.  When a multi-scale MS-GS model is rendered WITHOUT its
+// pixel-size filters (/root/reference/render.py:32 and the evaluation loop /root/reference/train.py:488-496 call render() with
+// the default flags) the coarse-level Gaussians — scaled x4 .. x64 — are all drawn at level 0: 427 M instances at 1080p for
+// 1 M Gaussians, of which a few million are ever walked, because a handful of opaque giants in front terminates every pixel.
+//
+// What this pass proves and uses.  Let a Gaussian's alpha >= 1/255 level set contain a whole block of tiles.  alpha is a
+// concave function of the pixel offset in the log domain, so its minimum over the block's pixel centres is at one of the four
+// corner pixels: alpha_min.  EVERY pixel of the block then blends the Gaussian with alpha >= alpha_min (it is not skipped: the
+// skip rule is alpha < 1/255), i.e. its transmittance behind that entry is at most (1 - alpha_min) times the one in front.
+// With the covers of a block taken front to back, the first depth at which  prod (1 - alpha_min) < 0.5e-4  (the rule's 1e-4
+// with a factor 2 of slack for float32 rounding on either side) is a depth behind which NO pixel of the block evaluates
+// anything: every one of them has met the termination test at or before that entry.  Instances behind it are dropped from the
+// tile counts (here, before the depth sort and the scan) and from the emit (binning.hip).  The lists every pixel actually walks
+// are unchanged, entry for entry: image, n_contrib, final_T and every gradient are bit-identical to the uncut path
+// (tests/test_occlusion_gpu.py).  Any SUBSET of the covers gives a valid (later) cut-off, so the pass may ignore what it
+// likes: it only looks at Gaussians with more than OCC_HEAVY_MIN tile instances, only at blocks they cover completely, and it
+// accumulates per depth BUCKET (1/16 octave of view depth) instead of per rank — the cut-off is the far end of the bucket in
+// which the product crosses.  Integer (fixed-point) sums: the result does not depend on the order the candidates arrive in.
+//
+// Three launches between preprocess_kernel and the depth sort:
+//   occ_gather_kernel    compacts the per-wave candidate lists K1 left behind into records (one atomic per wave that has any)
+//   occ_cover_kernel     one workgroup per block of tiles: bucketed sums of -log2(1 - alpha_min), prefix, cut-off key per tile
+//   occ_recount_kernel   Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in
+//                        place; a Gaussian left without instances leaves the depth sort: key 0xFFFFFFFF)
+// On a view where nothing closes (the BASELINE C3 headline: 363 candidates) the three cost ~7 us: the first reads 62 KB of
+// counts, the second walks six candidates per block, the third leaves at once.
+#include "msgs_internal.h"
+
+#include <atomic>
+#include <cstdlib>
+
+namespace msgs {
+
+namespace {
+
+std::atomic<int> g_occlusion{[] { const char* e = getenv("MSGS_NO_OCCLUSION"); return (e && e[0] == '1') ? 0 : 1; }()};
+
+constexpr float OCC_LOG2_T = 13.287712f + 1.0f;        // -log2(1e-4) + one bit of slack (factor 2 on the product)
+constexpr float OCC_FIX = 2048.0f;                     // fixed-point scale of the bucket sums (2^-11 bits)
+constexpr uint32_t OCC_THRESHOLD = (uint32_t)(OCC_LOG2_T * OCC_FIX) + 1u;
+// (sums stay below 2^32: a cover adds at most -log2(0.01) * 2048 = 13 607, and a view has fewer than 2^31 / 13 607 candidates
+//  per bucket in any scene this library accepts — P < 2^31 — while the prefix saturates below)
+
+// Candidate gather: ONE launch, no atomics, deterministic positions.  preprocess_kernel left, per wave slot, the ids of its
+// heavy Gaussians and their number.  Every workgroup owns 256 consecutive slots (one per thread); it sums ALL slot counts itself
+// (62 KB at 1 M Gaussians, L2-resident: cheaper than a second launch) to learn the total and the number of candidates in front
+// of its own slots, so that a candidate's position in index order is known without communication.  At most OCC_MAX_CAND
+// candidates are kept: every stride-th one in index order — a deterministic sample that is uncorrelated with depth.  A subset
+// of the covers still gives a valid cut-off (header comment); with the sample it lies at most about one depth bucket farther.
+constexpr int OCC_GATHER_SLOTS = 256;       // wave slots per workgroup (one per thread)
+
+__global__ __launch_bounds__(256) void occ_gather_kernel(int P, const char* __restrict__ geom,
+                                                         const uint32_t* __restrict__ heavy_list,
+                                                         const uint32_t* __restrict__ heavy_count, int n_slots,
+                                                         OccHeader* __restrict__ hdr, OccCand* __restrict__ cand,
+                                                         uint32_t block_log2, uint32_t nbx, uint32_t nby) {
+    __shared__ uint16_t s_kept[OCC_GATHER_SLOTS * 64];     // (local slot << 6) | index in the slot
+    __shared__ uint32_t s_prefix[OCC_GATHER_SLOTS];
+    __shared__ uint32_t s_red[2][4], s_scan[4], s_kscan[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot0 = blockIdx.x * OCC_GATHER_SLOTS;
+    // total and the part in front of this workgroup's slots (4 counts per load)
+    uint32_t before = 0, total = 0;
+    const int n4 = n_slots >> 2;                        // n_slots is a multiple of 4
+    const uint4* c4 = reinterpret_cast<const uint4*>(heavy_count);
+    for (int q = threadIdx.x; q < n4; q += 256) {
+        const uint4 v = c4[q];
+        const uint32_t sum = v.x + v.y + v.z + v.w;
+        total += sum;
+        if (4 * q < slot0) before += sum;               // slot0 is a multiple of 4
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        total += (uint32_t)__shfl_xor((int)total, off);
+        before += (uint32_t)__shfl_xor((int)before, off);
+    }
+    if (lane == 0) { s_red[0][wv] = total; s_red[1][wv] = before; }
+    __syncthreads();
+    total = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    before = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    const uint32_t stride = total > (uint32_t)OCC_MAX_CAND ? (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND : 1u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // (the header was zeroed by preprocess_kernel)
+        hdr->n_cand = (total + stride - 1) / stride;
+        hdr->n_heavy = total;
+        hdr->enabled = 1u;
+        hdr->block_log2 = block_log2;
+        hdr->nbx = nbx;
+        hdr->nby = nby;
+    }
+    if (total == 0) return;
+    const int slot = slot0 + threadIdx.x;
+    const uint32_t cnt = slot < n_slots ? heavy_count[slot] : 0u;
+    // position (index order) of this slot's first candidate, and of its first KEPT candidate in the workgroup's list:
+    // positions g in [first, first + cnt) with g % stride == 0 are kept
+    auto block_exclusive = [&](uint32_t v, uint32_t* s_w, uint32_t* block_total) {
+        uint32_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int k = 0; k < wv; ++k) base += s_w[k];
+        *block_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        return base + inc - v;
+    };
+    uint32_t dummy;
+    const uint32_t first = before + block_exclusive(cnt, s_scan, &dummy);
+    s_prefix[threadIdx.x] = first;
+    const uint32_t g0 = ((first + stride - 1) / stride) * stride;
+    const uint32_t kept = g0 < first + cnt ? (first + cnt - 1 - g0) / stride + 1 : 0u;
+    uint32_t kept_total;
+    uint32_t at = block_exclusive(kept, s_kscan, &kept_total);         // <= 256 * 64 entries
+    for (uint32_t g = g0; g < first + cnt; g += stride) s_kept[at++] = (uint16_t)((threadIdx.x << 6) | (g - first));
+    __syncthreads();
+    const GeomLayout L(P);
+    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
+    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + L.rec);
+    const uint32_t* key = reinterpret_cast<const uint32_t*>(geom + L.key);
+    for (uint32_t e = threadIdx.x; e < kept_total; e += 256) {
+        const uint32_t code = s_kept[e];
+        const uint32_t ls = code >> 6, j = code & 63u;
+        const uint32_t gi = heavy_list[(size_t)(slot0 + ls) * 64 + j];
+        const BinRec b = binrec[gi];
+        OccCand c;
+        c.c0 = b.q0;                                                                  // px, py, kA, kB(half)
+        c.c1 = make_float4(b.q1.x, rec[gi].r1.y, __uint_as_float(key[gi]), __uint_as_float(gi));   // kC, log2 o, depth key, id
+        cand[(s_prefix[ls] + j) / stride] = c;
+    }
+}
+
+// fixed-point weight -log2(1 - alpha_min) of candidate c over the pixel-centre rectangle [x0, x1] x [y0, y1], 0 when the
+// level set does not contain the rectangle
+__device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, float x1, float y0, float y1) {
+#pragma clang fp contract(off)
+    const float px = c.c0.x, py = c.c0.y, A = c.c0.z, Bh = c.c0.w, Cc = c.c1.x, l2o = c.c1.y;
+    const float dxa = px - x0, dxb = px - x1, dya = py - y0, dyb = py - y1;
+    // f(d) = A dx^2 + 2 Bh dx dy + C dy^2 = log2 G(d) <= 0, concave: its minimum over the rectangle is at a corner
+    const float fa = A * dxa * dxa, fb = A * dxb * dxb, ga = Cc * dya * dya, gb = Cc * dyb * dyb;
+    const float f00 = fa + ga + 2.0f * Bh * dxa * dya, f01 = fa + gb + 2.0f * Bh * dxa * dyb;
+    const float f10 = fb + ga + 2.0f * Bh * dxb * dya, f11 = fb + gb + 2.0f * Bh * dxb * dyb;
+    const float fmin = fminf(fminf(f00, f01), fminf(f10, f11));
+    // log2 of the smallest alpha any pixel of the rectangle sees, pushed DOWN by more than the kernels' float32 evaluation of
+    // the same quantity can differ: 4e-3 absolute (0.3 % on alpha) + 1e-6 of the magnitude of the terms that cancel in it
+    // (an elongated, rotated footprint far from its centre: the three monomials are large and of mixed sign)
+    const float mag = fmaxf(fabsf(fa), fabsf(fb)) + fmaxf(fabsf(ga), fabsf(gb)) +
+                      2.0f * fabsf(Bh) * fmaxf(fabsf(dxa), fabsf(dxb)) * fmaxf(fabsf(dya), fabsf(dyb));
+    const float la = fmin + l2o - (1e-6f * mag + 4e-3f);
+    if (!(la >= -7.99f)) return 0u;                     // alpha_min must clear 1/255 (log2 = -7.9944) or a pixel may SKIP it
+    const float amin = fminf(0.99f, exp2f(la));
+    const float w = -log2f(1.0f - amin);                // >= 0.0057
+    return (uint32_t)(w * (OCC_FIX * 0.999f));          // rounded down
+}
+
+// one workgroup per block of B x B tiles
+constexpr int OCC_COVER_THREADS = 512;
+__global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams vp, int B, int nbx, OccHeader* __restrict__ hdr,
+                                                                      const OccCand* __restrict__ cand,
+                                                                      uint32_t* __restrict__ occ_cut) {
+    __shared__ uint32_t s_b[OCC_BUCKETS];
+    __shared__ uint32_t s_wave[OCC_COVER_THREADS / 64];
+    __shared__ uint32_t s_cross;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int tx0 = bx * B, ty0 = by * B;
+    const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
+    const uint32_t n = hdr->n_cand;
+    uint32_t cut = 0xFFFFFFFFu;
+    bool closed = false;
+    if (n >= 3) {                                       // (a cover weighs at most 6.65 bits: fewer than three cannot close anything)
+        for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_COVER_THREADS) s_b[k] = 0u;
+        if (threadIdx.x == 0) s_cross = 0xFFFFFFFFu;
+        __syncthreads();
+        const float x0 = (float)(tx0 * TILE), y0 = (float)(ty0 * TILE);
+        const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);   // pixels inside the image
+        auto add = [&](const OccCand& cc) {
+            const uint32_t w = cover_weight(cc, x0, x1, y0, y1);
+            if (w) {
+                const uint32_t kb = __float_as_uint(cc.c1.z) >> OCC_KEY_SHIFT;
+                const uint32_t b = kb > OCC_KEY_BASE ? min(kb - OCC_KEY_BASE, (uint32_t)(OCC_BUCKETS - 1)) : 0u;
+                atomicAdd(&s_b[b], w);
+            }
+        };
+        uint32_t c = threadIdx.x;
+        for (; c + OCC_COVER_THREADS < n; c += 2 * OCC_COVER_THREADS) {      // two records in flight per thread
+            const OccCand ca = cand[c], cb = cand[c + OCC_COVER_THREADS];
+            add(ca);
+            add(cb);
+        }
+        if (c < n) add(cand[c]);
+        __syncthreads();
+        // front-to-back prefix over the buckets: thread t owns PER consecutive buckets
+        constexpr int PER = OCC_BUCKETS / OCC_COVER_THREADS;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { v[k] = min(s_b[threadIdx.x * PER + k], 0x00FFFFFFu); sum += v[k]; }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int k = 0; k < wv; ++k) run += s_wave[k];
+        uint32_t cross = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            run += v[k];
+            if (cross == 0xFFFFFFFFu && run >= OCC_THRESHOLD) cross = (uint32_t)(threadIdx.x * PER + k);
+        }
+        if (cross != 0xFFFFFFFFu) atomicMin(&s_cross, cross);
+        __syncthreads();
+        const uint32_t q = s_cross;
+        // everything with a key up to the far end of the crossing bucket stays; the last bucket also holds the keys clamped
+        // into it, so a crossing there closes nothing
+        closed = q < (uint32_t)(OCC_BUCKETS - 1);
+        if (closed) cut = ((q + OCC_KEY_BASE + 1u) << OCC_KEY_SHIFT) - 1u;
+    }
+    if (threadIdx.x == 0) {
+        occ_cut[blockIdx.x] = cut;
+        if (closed) hdr->any_closed = 1u;               // plain store (every writer writes the same value): no atomics here — the
+    }                                                   // readers reduce the table themselves (occ_table_load)
+}
+
+// Gaussians behind the nearest cut-off count their instances again: the same per-row level-set extents and margin as the
+// count in preprocess_kernel, restricted to the tiles whose block's cut-off they are in front of.  Index order (before the
+// depth sort).  The block table sits in LDS.  Small footprints (rect of at most OCC_LIGHT_RECT tiles) are recounted by their own
+// thread — a bounded loop of LDS look-ups; larger ones by their whole wave: lane <-> tile row for the row extents, then only the
+// rows whose row of blocks is still open at this depth, with the lanes on consecutive tiles.
+constexpr int OCC_LIGHT_RECT = 64;
+__global__ __launch_bounds__(256) void occ_recount_kernel(ViewParams vp, int P, char* __restrict__ geom) {
+    __shared__ OccTable T;
+    const GeomLayout L(P);
+    OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + L.occ_hdr);
+    if (hdr->any_closed == 0u) return;                                  // nothing closed in this view
+    const int lb = (int)hdr->block_log2, nbx = (int)hdr->nbx;
+    occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), nbx, (int)hdr->nby);
+    const uint32_t cut_min = T.cut_min, cut_max = T.cut_max;
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(geom + L.tiles);
+    uint32_t* key = reinterpret_cast<uint32_t*>(geom + L.key);
+    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0, k = 0;
+    if (i < P) { cnt = tiles[i]; k = key[i]; }
+    const bool affected = cnt > 0 && k > cut_min;
+    const bool all_behind = affected && k > cut_max;                    // behind the cut-off of EVERY block (none stayed open)
+    const bool work = affected && !all_behind;
+    uint32_t newcnt = all_behind ? 0u : cnt;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (work) {
+        q0 = binrec[i].q0; q1 = binrec[i].q1;
+        const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
+        minx = rcx & 0xFFFF; miny = rcx >> 16; maxx = rcy & 0xFFFF; maxy = rcy >> 16;
+    }
+    const bool light = work && (maxx - minx) * (maxy - miny) <= OCC_LIGHT_RECT;
+    if (light) {
+        const float tau2 = q1.y;
+        const bool test = tau2 > -1.0e38f;
+        const LevelSetRows ls = test ? levelset_rows_setup(q0.z, q0.w, q1.x, tau2) : LevelSetRows{};
+        uint32_t c = 0;
+        for (int ty = miny; ty < maxy; ++ty) {
+            if (T.rowmax[ty >> lb] < k) continue;
+            int tlo = minx, thi = maxx - 1;
+            if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi)) continue;
+            const int brow = (ty >> lb) * nbx;
+            for (int tx = tlo; tx <= thi; ++tx) c += T.cut[brow + (tx >> lb)] >= k ? 1u : 0u;
+        }
+        newcnt = c;
+    }
+    uint64_t todo = __ballot(work && !light);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t h_key = (uint32_t)__shfl((int)k, src);
+        const float gx_ = __shfl(q0.x, src), gy_ = __shfl(q0.y, src), cA = __shfl(q0.z, src), cBh = __shfl(q0.w, src);
+        const float cC = __shfl(q1.x, src), tau2 = __shfl(q1.y, src);
+        const int h_minx = __shfl(minx, src), h_miny = __shfl(miny, src), h_maxx = __shfl(maxx, src), h_maxy = __shfl(maxy, src);
+        const bool test = tau2 > -1.0e38f;
+        const LevelSetRows ls = test ? levelset_rows_setup(cA, cBh, cC, tau2) : LevelSetRows{};
+        uint32_t c = 0;                                                 // wave-uniform
+        for (int row0 = h_miny; row0 < h_maxy; row0 += 64) {
+            const int ty = row0 + lane;
+            int tlo = h_minx, thi = h_maxx - 1;
+            bool hit = ty < h_maxy && T.rowmax[min(ty, vp.gy - 1) >> lb] >= h_key;
+            if (hit && test) hit = levelset_row_interval(ls, gx_, gy_, ty, h_minx, h_maxx, LEVELSET_MARGIN_COUNT, tlo, thi);
+            const int n_row = hit ? thi - tlo + 1 : 0;
+            uint64_t rows = __ballot(n_row > 0);                        // only the rows that can still receive something
+            while (rows) {
+                const int r = __ffsll((long long)rows) - 1;
+                rows &= rows - 1;
+                const int n_r = __shfl(n_row, r), tlo_r = __shfl(tlo, r);
+                const int brow = ((row0 + r) >> lb) * nbx;
+                for (int j0 = 0; j0 < n_r; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool keep = j < n_r && T.cut[brow + ((tlo_r + j) >> lb)] >= h_key;
+                    c += (uint32_t)__popcll(__ballot(keep));
+                }
+            }
+        }
+        if (lane == src) newcnt = c;
+    }
+    if (affected) {
+        tiles[i] = newcnt;
+        if (newcnt == 0) key[i] = 0xFFFFFFFFu;                          // leaves the (compacting) depth sort
+    }
+}
+
+}  // namespace
+
+int set_occlusion(int on) { return g_occlusion.exchange(on ? 1 : 0); }
+int get_occlusion() { return g_occlusion.load(); }
+int occlusion_block_log2(int gx, int gy) {
+    static const int lb_min = [] {
+        const char* e = getenv("MSGS_OCC_BLOCK");
+        const int v = e ? atoi(e) : 4;
+        return v >= 16 ? 4 : v >= 8 ? 3 : v >= 4 ? 2 : v >= 2 ? 1 : 0;
+    }();
+    int lb = lb_min;
+    while ((int64_t)((gx + (1 << lb) - 1) >> lb) * ((gy + (1 << lb) - 1) >> lb) > OCC_MAX_BLOCKS) ++lb;
+    return lb;
+}
+
+hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint32_t* heavy_list, const uint32_t* heavy_count,
+                            OccCand* cand, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    const GeomLayout L(P);
+    OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + L.occ_hdr);
+    const int n_slots = 4 * ((P + 255) / 256);
+    const int lb = occlusion_block_log2(vp.gx, vp.gy), B = 1 << lb;
+    const int nbx = (vp.gx + B - 1) / B, nby = (vp.gy + B - 1) / B;
+    hipLaunchKernelGGL(occ_gather_kernel, dim3((n_slots + OCC_GATHER_SLOTS - 1) / OCC_GATHER_SLOTS), dim3(256), 0, s, P,
+                       (const char*)geom, heavy_list, heavy_count, n_slots, hdr, cand, (uint32_t)lb, (uint32_t)nbx,
+                       (uint32_t)nby);
+    hipLaunchKernelGGL(occ_cover_kernel, dim3(nbx * nby), dim3(OCC_COVER_THREADS), 0, s, vp, B, nbx, hdr, (const OccCand*)cand,
+                       reinterpret_cast<uint32_t*>(geom + L.occ_cut));
+    hipLaunchKernelGGL(occ_recount_kernel, dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom);
+    return hipGetLastError();
+}
+
+}  // namespace msgs

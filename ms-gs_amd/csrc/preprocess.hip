@@ -422,7 +422,9 @@ template <bool SPLIT_ROWS>
 __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gaussians_t g,
                                                          int32_t* __restrict__ radii,
                                                          float* __restrict__ pixel_sizes,
-                                                         char* __restrict__ geom, ZeroJob zj) {
+                                                         char* __restrict__ geom, ZeroJob zj,
+                                                         uint32_t* __restrict__ heavy_list,
+                                                         uint32_t* __restrict__ heavy_count) {
     __shared__ float s_rows[4][64 * HALF_LDS];
     __shared__ uint8_t s_idx[4][64];
     const int P = g.P;
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     int32_t out_radius = 0;
     float out_psize = 0.f;
     uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, out_flags = 0;
-    float out_weight = 0.f;
+    float out_weight = 0.f, out_tau2 = -3.0e38f;
 
     // ---- phase A: geometry, pixel size, multi-scale filters (one lane per Gaussian) ----
     bool alive = false;
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                                        __uint_as_float((uint32_t)maxx | ((uint32_t)maxy << 16)));
         }
         out_radius = (int32_t)my_radius;
+        out_tau2 = tau2;
         out_tiles = count;
         out_key = count ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
         out_flags |= 8u;
@@ -609,6 +612,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         key[i] = out_key;
         flags[i] = out_flags;
         weight[i] = out_weight;
+    }
+    // cover candidates of the occlusion cut-off (occlusion.hip): the Gaussians with many tile instances, per wave — no
+    // atomics, no counter to clear; occ_gather_kernel compacts the lists.  (A form that cannot be bounded, tau2 = -3e38, is
+    // never a candidate: its level set is not an ellipse.)
+    if (heavy_count) {
+        const bool hv = out_tiles > OCC_HEAVY_MIN && out_tau2 > -1.0e38f;
+        const uint64_t m = __ballot(hv);
+        const size_t slot = (size_t)blockIdx.x * 4 + wv;
+        if (hv) heavy_list[slot * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        if (lane == 0) heavy_count[slot] = (uint32_t)__popcll(m);
     }
 }
 
@@ -1059,12 +1072,14 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s, ZeroJob zj) {
+                             char* geom, hipStream_t s, ZeroJob zj, uint32_t* heavy_list, uint32_t* heavy_count) {
     if (g.P == 0) return hipSuccess;
     if (g.raw_params != 0 && g.shs == nullptr)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
+                           heavy_list, heavy_count);
     else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj);
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
+                           heavy_list, heavy_count);
     return hipGetLastError();
 }
 

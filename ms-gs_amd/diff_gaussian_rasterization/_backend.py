@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("MSGS_HIP_LIB") or next(
     (p for p in (os.path.join(_PKG, "libmsgs_hip.so"),) if os.path.exists(p)),
     os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd")
@@ -109,6 +109,10 @@ def _load():
     lib.msgs_set_blend_granularity.argtypes = [C.c_int32]
     lib.msgs_set_forward_variant.restype = C.c_int
     lib.msgs_set_forward_variant.argtypes = [C.c_int32]
+    lib.msgs_set_occlusion.restype = C.c_int
+    lib.msgs_set_occlusion.argtypes = [C.c_int32]
+    lib.msgs_occlusion_stats.restype = C.c_int
+    lib.msgs_occlusion_stats.argtypes = [vp, sz, C.c_int32, C.POINTER(C.c_int64), vp]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, vp, sz, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
@@ -189,7 +193,8 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
            "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
            "msgs_blend_lane_stats", "msgs_backward_per_gaussian", "msgs_set_forward_variant",
-           "msgs_status_create", "msgs_status_destroy", "msgs_forward_launch", "msgs_forward_finish")
+           "msgs_status_create", "msgs_status_destroy", "msgs_forward_launch", "msgs_forward_finish",
+           "msgs_set_occlusion", "msgs_occlusion_stats")
 
 
 def check(rc, where):

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/msgs.h but not exported"
     assert set(dgr._C.EXPORTS) == set(names)
-    assert lib.msgs_abi_version() == dgr._C.ABI_VERSION == 8
+    assert lib.msgs_abi_version() == dgr._C.ABI_VERSION == 9
     assert b"exactly one" in lib.msgs_error_string(-1)
 
 

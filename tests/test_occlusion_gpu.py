@@ -1,0 +1,208 @@
+"""Exact per-tile occlusion cut-off (ms-gs_amd/csrc/occlusion.hip; msgs_set_occlusion): instances behind the depth at which
+every pixel of a block of tiles has provably terminated are neither counted, emitted nor sorted — and nothing a pixel walks
+changes.  Every test renders the same inputs with the pass on and off and demands BIT-IDENTICAL results: image, depth,
+acc_pixel_size, radii, pixel_sizes, the per-pixel state the backward reads (final_T, n_contrib) and every gradient.  Size
+-independent property at the full BASELINE sizes (the multi-scale C3 model without its filters — render.py's defaults, 427 M
+instances uncut — and C5), randomised small scenes with opaque giants in front, and the adversarial corners: covers whose
+smallest alpha sits at the 1/255 skip threshold, elongated rotated covers, covers that end inside a tile block."""
+import ctypes as C
+
+import pytest
+import torch
+
+import scenes
+from parity_utils import PIPE
+
+pytestmark = pytest.mark.gpu
+LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+OUT_KEYS = ("render", "acc_pixel_size", "depth", "radii", "pixel_sizes")
+PLAIN = dict(filter_small=False, filter_large=False, fade_size=1.0)
+
+
+def _stats(ctx):
+    import diff_gaussian_rasterization as dgr
+    geom = ctx.state[0]
+    o = (C.c_int64 * 8)()
+    dgr._C.check(dgr._C.lib.msgs_occlusion_stats(C.c_void_p(geom.data_ptr()), geom.numel(), ctx.call.P, o,
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "msgs_occlusion_stats")
+    import struct
+    depth = lambda bits: None if bits in (0, 0xFFFFFFFF) else round(struct.unpack("f", struct.pack("I", bits))[0], 4)
+    return dict(ran=int(o[0]), heavy=int(o[1]), candidates=int(o[2]), closed_blocks=int(o[3]), blocks=int(o[4]), block=int(o[5]),
+                cut_min_depth=depth(int(o[6])), cut_max_depth=depth(int(o[7])))
+
+
+def _run(sc, cam, st, bg, dL, occlusion, backward=True, fused=False):
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render, render_fused
+    from synthetic_model import SyntheticGaussians
+    prev = dgr._C.lib.msgs_set_occlusion(1 if occlusion else 0)
+    try:
+        dgr._last_instances.clear()
+        pc = SyntheticGaussians(sc, "cuda", requires_grad=backward)
+        fn = render_fused if fused else render
+        if backward:
+            out = fn(cam, pc, PIPE, bg, **st)
+            out["render"].backward(dL)
+        else:
+            with torch.no_grad():
+                out = fn(cam, pc, PIPE, bg, **st)
+        torch.cuda.synchronize()
+        ctx = out["render"].grad_fn if backward else None
+        D = ctx.state[3] if ctx is not None else None
+        stats = _stats(ctx) if ctx is not None else None
+        W, H = cam.image_width, cam.image_height
+        per_pixel = None
+        if ctx is not None:          # final_T [N] f32 at offset 0, n_contrib [N] u32 at the next 256-byte boundary (ImageLayout)
+            image = ctx.state[2]
+            n4 = 4 * W * H
+            a = (n4 + 255) & ~255
+            per_pixel = (image[:n4].clone(), image[a:a + n4].clone())
+        return out, pc, D, stats, per_pixel
+    finally:
+        dgr._C.lib.msgs_set_occlusion(prev)
+
+
+def _assert_identical(a, b, what, backward=True):
+    (oa, pa, _, _, ppa), (ob, pb, _, _, ppb) = a, b
+    for k in OUT_KEYS:
+        assert torch.equal(oa[k], ob[k]), (what, k)
+    if backward:
+        assert torch.equal(ppa[0], ppb[0]) and torch.equal(ppa[1], ppb[1]), (what, "final_T / n_contrib")
+        assert torch.equal(oa["viewspace_points"].grad, ob["viewspace_points"].grad), (what, "means2D grad")
+        for n in LEAVES:
+            assert torch.equal(getattr(pa, n).grad, getattr(pb, n).grad), (what, n)
+
+
+def _giants_scene(P, W, H, seed, n_giants, giant_scale, giant_opacity=None, elongate=1.0):
+    """a frustum scene with `n_giants` screen-filling Gaussians mixed into its depth range"""
+    sc = scenes.frustum_scene(P, W, H, seed=seed, scale_k=0.004 * 1920.0 / W * 0.5)
+    g = torch.Generator().manual_seed(seed + 1)
+    idx = torch.randperm(P, generator=g)[:n_giants]
+    z = sc.means3D[idx, 2].abs().clamp_min(0.6)
+    sc.means3D[idx, 2] = z
+    sc.means3D[idx, 0] *= 0.3
+    sc.means3D[idx, 1] *= 0.3
+    s = giant_scale * z[:, None] * (0.7 + 0.6 * torch.rand(n_giants, 3, generator=g))
+    s[:, 0] *= elongate
+    sc.scales[idx] = s
+    if giant_opacity is not None:
+        sc.opacities[idx, 0] = giant_opacity if torch.is_tensor(giant_opacity) else torch.full((n_giants,), float(giant_opacity))
+    return sc
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_filters_off_c3_model_is_bit_identical_and_sheds_its_dead_instances(fused):
+    """BASELINE C3's multi-scale model rendered with render.py's default flags: 427 M instances uncut."""
+    sc, cam, _ = scenes.config("C3")
+    cam = cam.to("cuda")
+    bg = torch.zeros(3, device="cuda")
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 2).cuda()
+    on = _run(sc, cam, PLAIN, bg, dL, True, fused=fused)
+    off = _run(sc, cam, PLAIN, bg, dL, False, fused=fused)
+    _assert_identical(on, off, "C3 filters off")
+    print(f"[occlusion] C3 filters off: D {off[2]} -> {on[2]}, {on[3]}")
+    assert off[3]["ran"] == 0 and on[3]["ran"] == 1
+    assert on[2] < off[2] // 10, (on[2], off[2])          # the point of the pass
+
+
+def test_headline_c3_and_c5_are_bit_identical():
+    for name, seed in (("C3", 2), ("C5", 5)):
+        sc, cam, st = scenes.config(name)
+        cam = cam.to("cuda")
+        bg = torch.zeros(3, device="cuda")
+        dL = scenes.grad_seed(cam.image_width, cam.image_height, seed).cuda()
+        on = _run(sc, cam, st, bg, dL, True)
+        off = _run(sc, cam, st, bg, dL, False)
+        _assert_identical(on, off, name)
+        print(f"[occlusion] {name}: D {off[2]} -> {on[2]}, {on[3]}")
+        assert on[2] <= off[2]
+        del on, off
+        torch.cuda.empty_cache()
+
+
+def test_4k_without_filters():
+    """every fifth Gaussian of the C5 model at 3840x2160 with render.py's flags (the whole model has more than 2^32 - 1
+    instances uncut: refused, tests/test_max_size_gpu.py)"""
+    sc, cam, _ = scenes.config("C5")
+    sc = sc.subset(torch.arange(0, sc.P, 5))
+    cam = cam.to("cuda")
+    bg = torch.tensor([0.2, 0.3, 0.1], device="cuda")
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 5).cuda()
+    on = _run(sc, cam, PLAIN, bg, dL, True)
+    off = _run(sc, cam, PLAIN, bg, dL, False)
+    _assert_identical(on, off, "4K filters off")
+    print(f"[occlusion] 4K, C5 / 5, filters off: D {off[2]} -> {on[2]}, {on[3]}")
+    assert on[2] < off[2] // 10
+
+
+@pytest.mark.parametrize("gran,bwd_gen", [(0, 0), (1, 1), (1, 2), (2, 0)])
+def test_random_scenes_with_giants_in_front(gran, bwd_gen):
+    import diff_gaussian_rasterization as dgr
+    lib = dgr._C.lib
+    pg, pb = lib.msgs_set_blend_granularity(gran), lib.msgs_set_backward_generation(bwd_gen)
+    try:
+        closed_somewhere = 0
+        for seed in range(12):
+            g = torch.Generator().manual_seed(1000 + seed)
+            W = int(torch.randint(300, 900, (1,), generator=g))       # (a cover candidate needs more than 96 tile instances)
+            H = int(torch.randint(220, 600, (1,), generator=g))
+            P = int(torch.randint(300, 6000, (1,), generator=g))
+            n_g = int(torch.randint(5, 120, (1,), generator=g))
+            op = None if seed % 3 == 0 else (0.2 + 0.79 * torch.rand(n_g, generator=g))
+            sc = _giants_scene(P, W, H, seed, n_g, giant_scale=float(0.2 + 1.5 * torch.rand(1, generator=g)), giant_opacity=op,
+                               elongate=float(torch.tensor([1.0, 1.0, 4.0, 12.0])[seed % 4]))
+            cam = scenes.front_camera(W, H).to("cuda")
+            bg = torch.rand(3, generator=g).cuda()
+            dL = scenes.grad_seed(W, H, seed).cuda()
+            on = _run(sc, cam, PLAIN, bg, dL, True)
+            off = _run(sc, cam, PLAIN, bg, dL, False)
+            _assert_identical(on, off, (seed, W, H, P, n_g))
+            assert on[2] <= off[2]
+            closed_somewhere += 1 if on[3]["closed_blocks"] else 0
+        assert closed_somewhere >= 4          # the scenes do exercise the cut
+    finally:
+        lib.msgs_set_blend_granularity(pg)
+        lib.msgs_set_backward_generation(pb)
+
+
+def test_covers_at_the_skip_threshold_and_partial_covers():
+    """Adversarial: stacks of identical screen-filling covers whose alpha at the far corner of a block sits within 1 % of 1/255
+    on either side (a pixel that SKIPS an entry does not lose transmittance to it: such a cover must not count), and covers
+    that end inside a block.  20 opacities around the threshold x both sides."""
+    W, H = 256, 192
+    cam = scenes.front_camera(W, H).to("cuda")
+    bg = torch.tensor([0.3, 0.6, 0.9], device="cuda")
+    dL = scenes.grad_seed(W, H, 7).cuda()
+    base = scenes.frustum_scene(1500, W, H, seed=77, scale_k=0.004 * 1920.0 / W * 0.5)
+    n = 40
+    for k in range(10):
+        sc = scenes.Scene(**{f: (v.clone() if torch.is_tensor(v) else v) for f, v in base.__dict__.items()})
+        idx = torch.arange(n)
+        sc.means3D[idx] = torch.tensor([0.0, 0.0, 1.0]) + 0.001 * torch.arange(n)[:, None] * torch.tensor([0.0, 0.0, 1.0])
+        sigma_px = 60.0 + 25.0 * k                    # footprint sigma in pixels: from "ends inside the image" to "fills it"
+        f = 1000.0 * W / 1920.0
+        sc.scales[idx] = torch.full((n, 3), sigma_px / f)
+        sc.rotations[idx] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+        # alpha at the image corner = o * exp(-r^2 / (2 sigma^2)); choose o so that it straddles 1/255 over the stack
+        r2 = (W / 2) ** 2 + (H / 2) ** 2
+        o_thr = (1.0 / 255.0) / torch.exp(torch.tensor(-r2 / (2 * sigma_px ** 2)))
+        sc.opacities[idx, 0] = (o_thr * (0.99 + 0.02 * torch.rand(n, generator=torch.Generator().manual_seed(k)))).clamp(1e-3, 0.99)
+        on = _run(sc, cam, PLAIN, bg, dL, True)
+        off = _run(sc, cam, PLAIN, bg, dL, False)
+        _assert_identical(on, off, ("threshold covers", k))
+
+
+def test_pyramid_levels_and_filters_on_are_unchanged():
+    """the training path (filters on, fade 0) at three pyramid levels of the C3 scene, and the switch really switches"""
+    import diff_gaussian_rasterization as dgr
+    sc, _, st = scenes.config("C3")
+    sc = sc.subset(torch.arange(0, sc.P, 5))
+    for k in (0, 2, 4):
+        W, H = int(1920 / 2 ** k), int(1080 / 2 ** k)
+        cam = scenes.front_camera(W, H).to("cuda")
+        bg = torch.zeros(3, device="cuda")
+        dL = scenes.grad_seed(W, H, 40 + k).cuda()
+        on = _run(sc, cam, st, bg, dL, True)
+        off = _run(sc, cam, st, bg, dL, False)
+        _assert_identical(on, off, ("pyramid", k))
+    assert dgr._C.lib.msgs_set_occlusion(1) == 1
