@@ -74,6 +74,11 @@ typedef struct msgs_view {
     int32_t filter_large;     /* bool */
     int32_t prefiltered;      /* bool (accepted; the reference always passes False)                  */
     int32_t debug;            /* bool: synchronise + return the first HIP error after every stage   */
+    int32_t skip_occlusion;   /* bool (not a reference field): this call renders without the occlusion cut-off pass even when
+                               * msgs_set_occlusion is on — same outputs, only the instance count differs; a caller that
+                               * renders similar views in a loop skips the pass (three small launches) while msgs_forward_info
+                               * says it found nothing to cut, and re-probes now and then                                  */
+    int32_t reserved0;        /* 0 */
     const float* bg;          /* [3]   device                                                        */
     const float* viewmatrix;  /* [16]  device; world_view_transform = W2C^T row-major (cameras.py:54) */
     const float* projmatrix;  /* [16]  device; full_proj_transform (cameras.py:55-56)                */
@@ -327,6 +332,10 @@ int msgs_set_forward_variant(int32_t variant);
  * 0xFFFFFFFF = a block stayed open)}.  (The instances removed = the instance count of the same view with the pass switched
  * off minus the one with it on.)  Synchronises `stream`; not re-entrant (a diagnostic). */
 int msgs_set_occlusion(int32_t on);
+/* What the last forward that RETURNED ITS INSTANCE COUNT on the calling host thread (msgs_forward, msgs_forward_stage1,
+ * msgs_forward_finish) learned besides the count — the words travel with it, no extra device access: out_host[0] = cover
+ * candidates of its occlusion pass (0 when the pass did not run), out_host[1] = 1 when the pass closed at least one block. */
+int msgs_forward_info(int64_t* out_host);
 int msgs_occlusion_stats(const void* geom, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream);
 
 /* msgs_forward: both stages in ONE call.  The caller passes `binning` and `scratch2` sized for a GUESS of the instance count

@@ -179,8 +179,11 @@ struct PendingCount {
     hipStream_t stream = nullptr;
     uint64_t ticket = 0;
     volatile uint64_t* host = nullptr;
-    const uint64_t* status_dev = nullptr;   // device copy of {D, flags}: the fallback when the flag never lands
+    const uint64_t* status_dev = nullptr;   // device copy of {D, flags, info}: the fallback when the flag never lands
 };
+
+// {cover candidates, any block closed} of the last forward whose count this host thread collected (msgs_forward_info)
+thread_local uint64_t t_last_info = 0;
 
 static bool blocking_sync() {
     static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
@@ -212,7 +215,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.occ_hdr), sizeof(OccHeader) / 4};
     const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
     // exact per-tile occlusion cut-off (occlusion.hip): on unless switched off
-    const bool occlusion = get_occlusion() != 0;
+    const bool occlusion = get_occlusion() != 0 && view->skip_occlusion == 0;
     uint32_t* heavy_list = occlusion ? (uint32_t*)(scratch + SL.heavy_list) : nullptr;
     uint32_t* heavy_count = occlusion ? (uint32_t*)(scratch + SL.heavy_count) : nullptr;
     tm.begin(MSGS_K_PREPROCESS);
@@ -248,7 +251,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
                                classic ? status_dev : nullptr, classic && polled ? sb.dev : nullptr, ticket,
                                (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
-                               spec ? (uint64_t)spec->capacity : 0));
+                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr)));
     tm.end(MSGS_K_SCAN);
     if (!classic) {        // look-back sort / scan variants: watchdog flags join the status in a final tiny kernel
         const SortScratch SSL(P);
@@ -273,10 +276,10 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
 // Waits until the count of `pend` has landed (polls the pinned words; falls back to a device copy + synchronise).
 int forward_stage1_wait(PendingCount& pend, int64_t* num_instances_host) {
     *num_instances_host = 0;
-    if (!pend.active) return MSGS_OK;             // P == 0
+    if (!pend.active) { t_last_info = 0; return MSGS_OK; }      // P == 0
     pend.active = false;
     hipStream_t s = pend.stream;
-    uint64_t host_status[2] = {0, 0};
+    uint64_t host_status[3] = {0, 0, 0};
     if (pend.polled) {
         volatile uint64_t* hv = pend.host;
         const uint64_t ticket = pend.ticket;
@@ -292,12 +295,13 @@ int forward_stage1_wait(PendingCount& pend, int64_t* num_instances_host) {
                 }
             }
         }
-        if (hv[2] == ticket) { host_status[0] = hv[0]; host_status[1] = hv[1]; }
+        if (hv[2] == ticket) { host_status[0] = hv[0]; host_status[1] = hv[1]; host_status[2] = hv[3]; }
     } else {
         HIP_TRY(hipMemcpyAsync(host_status, pend.status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     const uint64_t total = host_status[0];
+    t_last_info = host_status[2];
     if (host_status[1] != 0) return MSGS_ERR_INTERNAL;
     if (total > 0xFFFFFFFFull) return MSGS_ERR_TOO_MANY;
     *num_instances_host = (int64_t)total;
@@ -678,6 +682,13 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
     return MSGS_OK;
 }
 
+int msgs_forward_info(int64_t* out_host) {
+    if (!out_host) return MSGS_ERR_INVALID_ARG;
+    out_host[0] = (int64_t)(t_last_info & 0xFFFFFFFFull);
+    out_host[1] = (int64_t)(t_last_info >> 32) != 0 ? 1 : 0;
+    return MSGS_OK;
+}
+
 int msgs_occlusion_stats(const void* geom_v, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream) {
     if (!geom_v || !out_host || P <= 0) return MSGS_ERR_INVALID_ARG;
     if (geom_bytes < msgs_geom_bytes(P)) return MSGS_ERR_CAPACITY;
@@ -694,12 +705,14 @@ int msgs_occlusion_stats(const void* geom_v, size_t geom_bytes, int32_t P, int64
     if (n_blocks < 0 || n_blocks > OCC_MAX_BLOCKS) return MSGS_ERR_INTERNAL;
     HIP_TRY(hipMemcpyAsync(table, (const char*)geom_v + GL.occ_cut, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // cut-offs are depth buckets (0xFFFF = open): reported as the depth key at the far end of the bucket
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     int closed = 0;
     for (int k = 0; k < n_blocks; ++k) {
-        closed += table[k] != 0xFFFFFFFFu;
-        lo = table[k] < lo ? table[k] : lo;
-        hi = table[k] > hi ? table[k] : hi;
+        const uint32_t key = table[k] >= 0xFFFFu ? 0xFFFFFFFFu : (((table[k] + OCC_KEY_BASE + 1u) << OCC_KEY_SHIFT) - 1u);
+        closed += key != 0xFFFFFFFFu;
+        lo = key < lo ? key : lo;
+        hi = key > hi ? key : hi;
     }
     out_host[1] = h.n_heavy;
     out_host[2] = h.n_cand;

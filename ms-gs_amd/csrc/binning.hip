@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     // the count of rank r is the difference of consecutive scanned offsets (coalesced; no gather of tiles[order[r]])
     uint32_t kmine = 0;
     if (r < V) { gi = order[r]; off = offs[r]; count = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - off); }
-    if (cut_min != 0xFFFFFFFFu && r < V) kmine = reinterpret_cast<const uint32_t*>(geom + L.skey)[r];
+    if (cut_min != 0xFFFFFFFFu && r < V) kmine = occ_bucket(reinterpret_cast<const uint32_t*>(geom + L.skey)[r]);   // depth bucket
     const bool cut_check = kmine > cut_min;       // some tile may be closed in front of this Gaussian
     s_gi[threadIdx.x] = gi;
     if (threadIdx.x == 0) s_range[0] = off;

@@ -99,7 +99,7 @@ struct GeomLayout {
                                                     // order[0..V) / offs[0..V) are the ranks the scan and the emit cover
         skey = o;   o = align256(o + 4 * P);        // depth keys in depth order (the sort's key output): emit's cut-off test
         occ_hdr = o; o = align256(o + sizeof(OccHeader));
-        occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth key per cover block (0xFFFFFFFF = open)
+        occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth bucket per cover block (0xFFFF = open)
         total = o;
     }
 };
@@ -328,20 +328,26 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 }
 
 // The cover-block table of the occlusion cut-off in LDS, with what its two readers (recount, emit) ask first: the smallest
-// and the largest cut-off key and the largest key per ROW of blocks (a Gaussian whose depth key is larger has nothing to emit
-// in that row of blocks).  Called by all threads of the block; ends with a barrier.
+// and the largest cut-off and the largest per ROW of blocks (a Gaussian that lies deeper has nothing to emit in that row of
+// blocks).  Cut-offs are depth BUCKETS (occ_bucket of a depth key; 0xFFFF = the block stayed open): a Gaussian reaches a block
+// iff its own bucket is <= the block's.  4.6 KB of LDS.  Called by all threads of the block; ends with a barrier.
+constexpr int OCC_MAX_BLOCK_ROWS = 256;
+__device__ __forceinline__ uint32_t occ_bucket(uint32_t depth_key) {
+    const uint32_t kb = depth_key >> OCC_KEY_SHIFT;
+    return kb > OCC_KEY_BASE ? min(kb - OCC_KEY_BASE, (uint32_t)(OCC_BUCKETS - 1)) : 0u;
+}
 struct OccTable {
-    uint32_t cut[OCC_MAX_BLOCKS];
-    uint32_t rowmax[OCC_MAX_BLOCKS];      // (nby entries used)
+    uint16_t cut[OCC_MAX_BLOCKS];
+    uint16_t rowmax[OCC_MAX_BLOCK_ROWS];
     uint32_t red[2][16];
     uint32_t cut_min, cut_max;
 };
 __device__ __forceinline__ void occ_table_load(OccTable& t, const uint32_t* __restrict__ occ_cut, int nbx, int nby) {
     const int n = nbx * nby;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    uint32_t lo = 0xFFFFu, hi = 0u;
     for (int q = threadIdx.x; q < n; q += blockDim.x) {
-        const uint32_t c = occ_cut[q];
-        t.cut[q] = c;
+        const uint32_t c = min(occ_cut[q], 0xFFFFu);
+        t.cut[q] = (uint16_t)c;
         lo = min(lo, c);
         hi = max(hi, c);
     }
@@ -353,11 +359,11 @@ __device__ __forceinline__ void occ_table_load(OccTable& t, const uint32_t* __re
     __syncthreads();
     for (int by = threadIdx.x; by < nby; by += blockDim.x) {
         uint32_t m = 0u;
-        for (int bx = 0; bx < nbx; ++bx) m = max(m, t.cut[by * nbx + bx]);
-        t.rowmax[by] = m;
+        for (int bx = 0; bx < nbx; ++bx) m = max(m, (uint32_t)t.cut[by * nbx + bx]);
+        t.rowmax[by] = (uint16_t)m;
     }
     if (threadIdx.x == 0) {
-        uint32_t a = 0xFFFFFFFFu, b = 0u;
+        uint32_t a = 0xFFFFu, b = 0u;
         for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) { a = min(a, t.red[0][w]); b = max(b, t.red[1][w]); }
         t.cut_min = a;
         t.cut_max = b;
@@ -439,7 +445,8 @@ bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit);
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s,
                               uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0,
-                              const uint32_t* n_ptr = nullptr, uint32_t* clamped_total = nullptr, uint64_t clamp = 0);
+                              const uint32_t* n_ptr = nullptr, uint32_t* clamped_total = nullptr, uint64_t clamp = 0,
+                              const uint32_t* extra = nullptr);   // extra: two device words forwarded with the status
 bool use_classic_sort();
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
                                  uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);

@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, flo
 }
 
 // one workgroup per block of B x B tiles
-constexpr int OCC_COVER_THREADS = 512;
+constexpr int OCC_COVER_THREADS = 256;
 __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams vp, int B, int nbx, OccHeader* __restrict__ hdr,
                                                                       const OccCand* __restrict__ cand,
                                                                       uint32_t* __restrict__ occ_cut) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams
     const int tx0 = bx * B, ty0 = by * B;
     const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
     const uint32_t n = hdr->n_cand;
-    uint32_t cut = 0xFFFFFFFFu;
+    uint32_t cut = 0xFFFFu;                             // depth bucket behind which the block is dead (0xFFFF: open)
     bool closed = false;
     if (n >= 3) {                                       // (a cover weighs at most 6.65 bits: fewer than three cannot close anything)
         for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_COVER_THREADS) s_b[k] = 0u;
@@ -177,11 +177,7 @@ __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams
         const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);   // pixels inside the image
         auto add = [&](const OccCand& cc) {
             const uint32_t w = cover_weight(cc, x0, x1, y0, y1);
-            if (w) {
-                const uint32_t kb = __float_as_uint(cc.c1.z) >> OCC_KEY_SHIFT;
-                const uint32_t b = kb > OCC_KEY_BASE ? min(kb - OCC_KEY_BASE, (uint32_t)(OCC_BUCKETS - 1)) : 0u;
-                atomicAdd(&s_b[b], w);
-            }
+            if (w) atomicAdd(&s_b[occ_bucket(__float_as_uint(cc.c1.z))], w);
         };
         uint32_t c = threadIdx.x;
         for (; c + OCC_COVER_THREADS < n; c += 2 * OCC_COVER_THREADS) {      // two records in flight per thread
@@ -216,10 +212,10 @@ __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams
         if (cross != 0xFFFFFFFFu) atomicMin(&s_cross, cross);
         __syncthreads();
         const uint32_t q = s_cross;
-        // everything with a key up to the far end of the crossing bucket stays; the last bucket also holds the keys clamped
-        // into it, so a crossing there closes nothing
+        // everything up to and including the crossing bucket stays; the last bucket also holds the keys clamped into it, so a
+        // crossing there closes nothing
         closed = q < (uint32_t)(OCC_BUCKETS - 1);
-        if (closed) cut = ((q + OCC_KEY_BASE + 1u) << OCC_KEY_SHIFT) - 1u;
+        if (closed) cut = q;
     }
     if (threadIdx.x == 0) {
         occ_cut[blockIdx.x] = cut;
@@ -233,7 +229,9 @@ __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams
 // thread — a bounded loop of LDS look-ups; larger ones by their whole wave: lane <-> tile row for the row extents, then only the
 // rows whose row of blocks is still open at this depth, with the lanes on consecutive tiles.
 constexpr int OCC_LIGHT_RECT = 64;
-__global__ __launch_bounds__(256) void occ_recount_kernel(ViewParams vp, int P, char* __restrict__ geom) {
+constexpr int OCC_RECOUNT_THREADS = 1024;     // (few, fat workgroups: on a view where nothing closed every one of them only reads
+                                              //  the header and leaves)
+__global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewParams vp, int P, char* __restrict__ geom) {
     __shared__ OccTable T;
     const GeomLayout L(P);
     OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + L.occ_hdr);
@@ -247,7 +245,7 @@ __global__ __launch_bounds__(256) void occ_recount_kernel(ViewParams vp, int P, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0, k = 0;
-    if (i < P) { cnt = tiles[i]; k = key[i]; }
+    if (i < P) { cnt = tiles[i]; k = occ_bucket(key[i]); }             // k: this Gaussian's depth bucket
     const bool affected = cnt > 0 && k > cut_min;
     const bool all_behind = affected && k > cut_max;                    // behind the cut-off of EVERY block (none stayed open)
     const bool work = affected && !all_behind;
@@ -323,7 +321,9 @@ int occlusion_block_log2(int gx, int gy) {
         return v >= 16 ? 4 : v >= 8 ? 3 : v >= 4 ? 2 : v >= 2 ? 1 : 0;
     }();
     int lb = lb_min;
-    while ((int64_t)((gx + (1 << lb) - 1) >> lb) * ((gy + (1 << lb) - 1) >> lb) > OCC_MAX_BLOCKS) ++lb;
+    while ((int64_t)((gx + (1 << lb) - 1) >> lb) * ((gy + (1 << lb) - 1) >> lb) > OCC_MAX_BLOCKS ||
+           ((gy + (1 << lb) - 1) >> lb) > OCC_MAX_BLOCK_ROWS)
+        ++lb;
     return lb;
 }
 
@@ -340,7 +340,8 @@ hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint3
                        (uint32_t)nby);
     hipLaunchKernelGGL(occ_cover_kernel, dim3(nbx * nby), dim3(OCC_COVER_THREADS), 0, s, vp, B, nbx, hdr, (const OccCand*)cand,
                        reinterpret_cast<uint32_t*>(geom + L.occ_cut));
-    hipLaunchKernelGGL(occ_recount_kernel, dim3((P + 255) / 256), dim3(256), 0, s, vp, P, geom);
+    hipLaunchKernelGGL(occ_recount_kernel, dim3((P + OCC_RECOUNT_THREADS - 1) / OCC_RECOUNT_THREADS), dim3(OCC_RECOUNT_THREADS), 0, s, vp,
+                       P, geom);
     return hipGetLastError();
 }
 

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
                                                             uint64_t* __restrict__ status = nullptr,
                                                             volatile uint64_t* host = nullptr, uint64_t ticket = 0,
                                                             uint32_t* __restrict__ clamped_total = nullptr,
-                                                            uint64_t clamp = 0) {
+                                                            uint64_t clamp = 0,
+                                                            const uint32_t* __restrict__ extra = nullptr) {
     __shared__ uint64_t s_w[4];
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -141,10 +142,13 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
         partials[nb] = s_carry;
         if (total_out) *total_out = s_carry;
         if (clamped_total) *clamped_total = (uint32_t)(s_carry < clamp ? s_carry : clamp);   // speculative stage 2's D
-        if (status) { status[0] = s_carry; status[1] = 0; }
+        // `extra`: two device words that travel with the count (the occlusion pass's {candidates, any block closed})
+        const uint64_t info = extra ? ((uint64_t)extra[0] | ((uint64_t)extra[1] << 32)) : 0ull;
+        if (status) { status[0] = s_carry; status[1] = 0; status[2] = info; }
         if (host) {
             host[0] = s_carry;
             host[1] = 0;
+            host[3] = info;
             __threadfence_system();
             host[2] = ticket;
         }
@@ -642,9 +646,11 @@ __global__ void collect_status_kernel(const uint64_t* __restrict__ total, const 
     const uint64_t e = (uint64_t)(sort_err ? *sort_err : 0u) | ((uint64_t)(scan_err ? *scan_err : 0u) << 32);
     out[0] = t;
     out[1] = e;
+    out[2] = 0;                     // (no occlusion info on this route)
     if (host) {                     // pinned, device-mapped host words {total, flags, ticket}: the host polls `ticket`
         host[0] = t;
         host[1] = e;
+        host[3] = 0;
         __threadfence_system();
         host[2] = ticket;
     }
@@ -660,11 +666,11 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
                               uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr, uint32_t* clamped_total,
-                              uint64_t clamp) {
+                              uint64_t clamp, const uint32_t* extra) {
     const int64_t nb = scan_blocks(n > 0 ? n : 1);
     if (n <= 0) {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total, status,
-                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp);
+                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
         return hipGetLastError();
     }
     if (!use_classic_sort()) {
@@ -681,7 +687,7 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
                        stage ? out : (uint32_t*)nullptr, n_ptr);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
-                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp);
+                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
                        stage ? (const uint32_t*)nullptr : gather, out, n, partials, n_ptr);
     return hipGetLastError();

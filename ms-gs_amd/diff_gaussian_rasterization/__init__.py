@@ -194,7 +194,7 @@ class _Call:
         self.view = _C.View(self.H, self.W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                             float(rs.fade_size), int(rs.sh_degree), self.K,
                             int(bool(rs.filter_small)), int(bool(rs.filter_large)), int(bool(rs.prefiltered)),
-                            int(bool(rs.debug)), _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
+                            int(bool(rs.debug)), 0, 0, _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
         # mode 1: raw parameters everywhere; mode 2: activated inputs + raw quaternions, gradients chained to the raw
         # parameters inside msgs_backward (include/msgs.h, msgs_gaussians_t::raw_params)
         self.rot_raw = _f32c(rotations_raw) if rotations_raw is not None else None
@@ -264,6 +264,40 @@ def set_deterministic(on=True):
 # leave every following call with stage-2 grids and buffers many times too large): it halves its excess over the last count
 # on every call; views whose counts differ by up to ~28 % alternate without outgrowing it.
 _last_instances = {}
+
+
+# Occlusion cut-off pass (include/msgs.h, msgs_set_occlusion): three small launches between the per-Gaussian stage and the depth
+# sort — ~15 us on a view where they find nothing to cut, milliseconds saved where opaque covers hide most of the scene (a
+# multi-scale model rendered without its filters, /root/reference/render.py:32).  The outputs never depend on it.  Policy per
+# (device, P, W, H, filters) key:
+#   "adaptive" (default)  the pass runs on the first call and then on every OCCLUSION_PROBE_PERIOD-th call; in between it runs only
+#                         while the last probe closed at least one block (msgs_forward_info: the answer travels with the count)
+#   "always" / "never"    MSGS_OCCLUSION_POLICY, or assign diff_gaussian_rasterization.occlusion_policy
+occlusion_policy = os.environ.get("MSGS_OCCLUSION_POLICY", "adaptive")
+OCCLUSION_PROBE_PERIOD = 32
+_occ_countdown = {}          # key -> calls left before the next probe (absent / 0: run the pass)
+
+
+def _occlusion_skip(key):
+    if occlusion_policy == "always":
+        return False
+    if occlusion_policy == "never":
+        return True
+    return _occ_countdown.get(key, 0) > 0
+
+
+def _occlusion_note(key, skipped):
+    """after the instance count of a forward has been collected on this thread"""
+    if occlusion_policy != "adaptive":
+        return
+    if skipped:
+        _occ_countdown[key] = _occ_countdown.get(key, 1) - 1
+        return
+    info = (C.c_int64 * 2)()
+    _C.lib.msgs_forward_info(info)
+    if len(_occ_countdown) > 256:
+        _occ_countdown.clear()
+    _occ_countdown[key] = 0 if info[1] else OCCLUSION_PROBE_PERIOD - 1
 
 
 _size_cache = {}
@@ -370,6 +404,7 @@ class _PendingForward:
             D = int(D.value)
             guess = self.guess
             _last_instances[self.key] = max(D, (guess + D) // 2) if guess is not None else D
+            _occlusion_note(self.key, getattr(self, "skip_occ", False))
             if not done.value:                          # first frame of this shape, or the scene grew past the margin
                 dev, W, H = call.device, call.W, call.H
                 color, acc_ps, depth = self.outs
@@ -408,6 +443,8 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
     lib = _C.lib
     key = (dev.index, P, W, H, call.view.filter_small, call.view.filter_large)
     pending = getattr(_deferred, "pending", None)
+    skip_occ = _occlusion_skip(key)
+    call.view.skip_occlusion = int(skip_occ)
     with _on_device(dev):
         cur = torch.cuda.current_stream(dev)
         stream = C.c_void_p(cur.cuda_stream)
@@ -448,6 +485,7 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
                 raise
             state = _PendingForward(call, status, cur, key, guess, geom, binning, image, (color, acc_ps, depth), grad_rec, keep,
                                     backward_follows, scratch1)
+            state.skip_occ = skip_occ
             pending.append(state)
             return color, acc_ps, depth, radii, pixel_sizes, state
         tmp = _bytes(_a256(n_s1) + n_s2, dev)
@@ -462,6 +500,7 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
         _last_instances[key] = max(D, (guess + D) // 2) if guess is not None else D
+        _occlusion_note(key, skip_occ)
         del scratch1, scratch2, tmp
         if not done.value:                              # first frame of this shape, or the scene grew past the margin
             binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)

@@ -30,6 +30,7 @@ class View(C.Structure):
                 ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("filter_small", C.c_int32), ("filter_large", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("skip_occlusion", C.c_int32), ("reserved0", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 
@@ -109,6 +110,8 @@ def _load():
     lib.msgs_set_blend_granularity.argtypes = [C.c_int32]
     lib.msgs_set_forward_variant.restype = C.c_int
     lib.msgs_set_forward_variant.argtypes = [C.c_int32]
+    lib.msgs_forward_info.restype = C.c_int
+    lib.msgs_forward_info.argtypes = [C.POINTER(C.c_int64)]
     lib.msgs_set_occlusion.restype = C.c_int
     lib.msgs_set_occlusion.argtypes = [C.c_int32]
     lib.msgs_occlusion_stats.restype = C.c_int
@@ -194,7 +197,7 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
            "msgs_blend_lane_stats", "msgs_backward_per_gaussian", "msgs_set_forward_variant",
            "msgs_status_create", "msgs_status_destroy", "msgs_forward_launch", "msgs_forward_finish",
-           "msgs_set_occlusion", "msgs_occlusion_stats")
+           "msgs_set_occlusion", "msgs_occlusion_stats", "msgs_forward_info")
 
 
 def check(rc, where):

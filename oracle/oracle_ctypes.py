@@ -22,6 +22,7 @@ class View(C.Structure):
                 ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("filter_small", C.c_int32), ("filter_large", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("skip_occlusion", C.c_int32), ("reserved0", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 
@@ -227,7 +228,7 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     v = View(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(scale_modifier),
              float(settings.get("fade_size", 1.0)), int(scene.sh_degree), int(K),
              int(bool(settings.get("filter_small", False))), int(bool(settings.get("filter_large", False))),
-             0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
+             0, 0, 0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
     g = Gaussians(P, 0, _ptr(t["means3D"]), _ptr(t["shs"]), _ptr(t["col"]), _ptr(t["opac"]),
                   _ptr(t["scales"]), _ptr(t["rot"]), _ptr(t["cov"]), _ptr(t["maxps"]), _ptr(t["minps"]),
                   _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]), None, None, None)

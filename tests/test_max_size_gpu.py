@@ -92,7 +92,51 @@ def test_rows_beyond_2_pow_31_elements(entry):
     torch.cuda.empty_cache()
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _occlusion(on):
+    """the occlusion cut-off (msgs_set_occlusion) sheds exactly the instances these scenes are made of: the index-width tests
+    switch it off, and one test shows what it does to the same scene"""
+    import diff_gaussian_rasterization as dgr
+    prev = dgr._C.lib.msgs_set_occlusion(1 if on else 0)
+    try:
+        yield
+    finally:
+        dgr._C.lib.msgs_set_occlusion(prev)
+
+
 def test_more_than_2_pow_32_instances_is_an_error_not_a_wrap():
+    with _occlusion(False):
+        _more_than_2_pow_32_instances_is_an_error_not_a_wrap()
+
+
+def test_the_occlusion_cut_off_renders_the_scene_that_has_too_many_instances():
+    """the same 4.5e9-instance scene with the cut-off on (the default): every pixel terminates after 14 of the 140 000 covers, the
+    instances behind that depth are never counted, and the call SUCCEEDS — image and depth bit-equal to the 100 nearest alone"""
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    W, H = 3840, 2160
+    n, near = 140_000, 100
+    sc, cam = small_scene(n, W, H, 5, sh_degree=0)
+    sc.means3D[:, 0] = 0.0
+    sc.means3D[:, 1] = 0.0
+    sc.means3D[:, 2] = torch.linspace(4.0, 6.0, n)
+    sc.scales[:] = 50.0
+    sc.opacities[:] = 0.5
+    dev = torch.device("cuda")
+    camd, bg = cam.to(dev), torch.zeros(3, device=dev)
+    st = dict(filter_small=False, filter_large=False, fade_size=0.0)
+    with _occlusion(True), torch.no_grad():
+        ref = render(camd, SyntheticGaussians(sc.subset(torch.arange(near)), dev, requires_grad=False), PIPE, bg, **st)
+        out = render(camd, SyntheticGaussians(sc, dev, requires_grad=False), PIPE, bg, **st)
+    torch.cuda.synchronize()
+    assert torch.equal(out["render"], ref["render"]) and torch.equal(out["depth"], ref["depth"])
+    assert int((out["radii"] > 0).sum()) == n
+
+
+def _more_than_2_pow_32_instances_is_an_error_not_a_wrap():
     """140 000 Gaussians that each cover all 32 400 tiles of a 3840x2160 image: 4.5e9 (tile, Gaussian) instances.  The scanned
     offsets are 32-bit (like the reference's); the grand total is 64-bit and the call must report it as an error
     ("more than 2^32-1 tile instances", MSGS_ERR_TOO_MANY) — after a speculative stage 2 that stayed inside its buffers —
@@ -143,6 +187,11 @@ def test_more_than_2_pow_32_instances_is_an_error_not_a_wrap():
 
 
 def test_instance_count_between_2_pow_31_and_2_pow_32():
+    with _occlusion(False):
+        _instance_count_between_2_pow_31_and_2_pow_32()
+
+
+def _instance_count_between_2_pow_31_and_2_pow_32():
     """80 000 screen-filling Gaussians at 3840x2160: 2.59e9 instances, past every signed 32-bit index in the emit, the tile sort
     (31 GB of key / id buffers) and the range search.  Opacity 0.5 everywhere: every pixel terminates after 14 Gaussians, so
     the image and the gradients must be those of the 100 nearest Gaussians alone — bit-equal image, i.e. the sort put the

@@ -36,6 +36,7 @@ def _run(sc, cam, st, bg, dL, occlusion, backward=True, fused=False):
     from gaussian_renderer import render, render_fused
     from synthetic_model import SyntheticGaussians
     prev = dgr._C.lib.msgs_set_occlusion(1 if occlusion else 0)
+    prev_policy, dgr.occlusion_policy = dgr.occlusion_policy, "always"      # (the wrapper's adaptive skipping is tested below)
     try:
         dgr._last_instances.clear()
         pc = SyntheticGaussians(sc, "cuda", requires_grad=backward)
@@ -60,6 +61,7 @@ def _run(sc, cam, st, bg, dL, occlusion, backward=True, fused=False):
         return out, pc, D, stats, per_pixel
     finally:
         dgr._C.lib.msgs_set_occlusion(prev)
+        dgr.occlusion_policy = prev_policy
 
 
 def _assert_identical(a, b, what, backward=True):
@@ -206,3 +208,36 @@ def test_pyramid_levels_and_filters_on_are_unchanged():
         off = _run(sc, cam, st, bg, dL, False)
         _assert_identical(on, off, ("pyramid", k))
     assert dgr._C.lib.msgs_set_occlusion(1) == 1
+
+
+def test_adaptive_policy_probes_then_skips_then_probes_again():
+    """diff_gaussian_rasterization.occlusion_policy = "adaptive" (the default): the pass runs on the first call of a (model size,
+    image, filters) key; while a probe finds nothing to cut the next OCCLUSION_PROBE_PERIOD - 1 calls skip it
+    (msgs_view_t.skip_occlusion), and while it does cut, every call runs it.  Same image either way."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render
+    from synthetic_model import SyntheticGaussians
+    assert dgr.occlusion_policy == "adaptive"
+    W, H = 480, 320
+    cam = scenes.front_camera(W, H).to("cuda")
+    bg = torch.zeros(3, device="cuda")
+    quiet = scenes.frustum_scene(3000, W, H, seed=5, scale_k=0.004 * 1920.0 / W * 0.3)          # nothing to cut
+    walls = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.9)                # opaque covers in front
+    info = (C.c_int64 * 2)()
+    for sc, cuts in ((quiet, False), (walls, True)):
+        dgr._occ_countdown.clear()
+        dgr._last_instances.clear()
+        pc = SyntheticGaussians(sc, "cuda", requires_grad=False)
+        ran, imgs = [], []
+        with torch.no_grad():
+            for it in range(dgr.OCCLUSION_PROBE_PERIOD + 2):
+                out = render(cam, pc, PIPE, bg, **PLAIN)
+                dgr._C.lib.msgs_forward_info(info)
+                ran.append(int(info[0]) > 0 or int(info[1]) > 0)
+                imgs.append(out["render"])
+        assert all(torch.equal(imgs[0], im) for im in imgs[1:])
+        if cuts:
+            assert all(ran), ran
+        else:            # candidates may be zero on a quiet scene: look at the wrapper's own bookkeeping instead
+            key = next(iter(dgr._occ_countdown))
+            assert dgr._occ_countdown[key] == dgr.OCCLUSION_PROBE_PERIOD - 2, dgr._occ_countdown
