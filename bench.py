@@ -74,6 +74,31 @@ def settle_gc():
     gc.disable()
 
 
+def period_median(fn, steps, warmup, sync):
+    """Median PERIOD of `steps` back-to-back calls of fn(): one HIP event in front of every call and one behind the last, on the
+    current stream; period k = time from event k to event k + 1.  Unlike an event pair around each call this also counts the gap
+    in which the GPU waits for a host that cannot keep up (C1 / C2-sized steps), and unlike one wall-clock interval over the
+    whole loop it is a median: one host stall (a cgroup throttle, a page fault) inside a 20-step loop moves a mean by 30 %
+    (round 4: train_iteration 1.72 ms in the driver's run against 1.35-1.39 ms everywhere else) and a median not at all.
+    Returns (median ms, sorted periods)."""
+    import torch
+    settle_gc()
+    for _ in range(warmup):
+        fn()
+    sync()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    with quiet_gc():
+        for k in range(steps):
+            evs[k].record()
+            fn()
+        evs[steps].record()
+        sync()
+    ts = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(steps))
+    n = len(ts)
+    med = ts[n // 2] if n % 2 else 0.5 * (ts[n // 2 - 1] + ts[n // 2])
+    return med, ts
+
+
 def _self_launch_if_needed():
     """`python3 bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N
     ranks HERE, as fresh child processes — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
@@ -206,7 +231,7 @@ def cpu_baseline(scenes, scene, settings, W, H, runs=2):
                       f"C++/OpenMP oracle: the {cores} usable host cores (best of {runs} runs) and one thread (one run)"}
 
 
-def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
+def pyramid_timing(scenes, pc, settings, bg, dev, steps=11, warmup=3):
     """What MS-GS is for, measured the reference's way (train.py:488-496,541 logs render_time per scale; viewer.py:67-81 and
     render_traj.py:99-105 time a forward-only render() between synchronisations): the SAME 1 M-Gaussian scene at the pyramid
     levels k = 0..6 ((W, H) = (int(1920 / 2^k), int(1080 / 2^k)), utils/camera_utils.py:38-39):
@@ -216,17 +241,7 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
     from gaussian_renderer import PIPE, render, render_fused
 
     def timed(fn):
-        settle_gc()
-        for _ in range(warmup):
-            fn()
-        torch.cuda.synchronize()
-        with quiet_gc():
-            t = time.perf_counter()
-            for _ in range(steps):
-                fn()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t
-        return round(1e3 * dt / steps, 4)
+        return round(period_median(fn, steps, warmup, torch.cuda.synchronize)[0], 4)
 
     fb, on, off, sizes, vis, fused_fb, fused_on = [], [], [], [], [], [], []
     aa = dict(filter_small=True, filter_large=True, fade_size=1.0)
@@ -255,6 +270,33 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
         sizes.append([W, H])
     for p_ in pc.parameters():
         p_.grad = None
+    # the filters-off render at level 0 with and without the occlusion cut-off (review item 2): instance counts and times
+    occ = None
+    try:
+        import diff_gaussian_rasterization as dgr
+        W0, H0 = sizes[0]
+        cam0_ = scenes.front_camera(W0, H0).to(dev)
+        key0 = (dev.index, int(pc.get_xyz.shape[0]), W0, H0, 0, 0)
+
+        def count_and_time(policy, switch):
+            prev_p, dgr.occlusion_policy = dgr.occlusion_policy, policy
+            prev_s = dgr._C.lib.msgs_set_occlusion(switch)
+            try:
+                dgr._last_instances.pop(key0, None)
+                with torch.no_grad():
+                    t_ = period_median(lambda: render(cam0_, pc, PIPE, bg, **plain), 5, 3, torch.cuda.synchronize)[0]
+                return int(dgr._last_instances.get(key0, -1)), round(t_, 4)
+            finally:
+                dgr._C.lib.msgs_set_occlusion(prev_s)
+                dgr.occlusion_policy = prev_p
+        d_on, t_on = count_and_time("always", 1)
+        d_off, t_off = count_and_time("never", 0)
+        occ = {"instances": d_on, "ms": t_on, "instances_uncut": d_off, "ms_uncut": t_off,
+               "what": "level 0, render.py's default flags: with the exact per-tile occlusion cut-off (default) and with it switched off "
+                       "(msgs_set_occlusion(0)); bit-identical images (tests/test_occlusion_gpu.py)"}
+        torch.cuda.empty_cache()
+    except Exception as e:      # informational
+        occ = {"error": repr(e)}
     # Informational, NOT the BASELINE scene: the same model after MS-GS's own bookkeeping has seen it.  The C3 recipe (SURVEY
     # 8(d)) gives min_pixel_sizes to half of the level-0 Gaussians only; in a trained MS-GS model update_pixel_sizes
     # (scene/gaussian_model.py:663-686) has given one to every level-0 Gaussian that was ever visible — its smallest observed
@@ -295,12 +337,13 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=10, warmup=3):
              "what": "render() + backward() per pyramid level k = 0..6 of the C3 scene, training settings; render_fused_ms = the "
                      "same through the raw-parameter entry (activations and SH concatenation inside the kernels)"},
             {"levels": sizes, "filters_on": on, "filters_off": off, "render_fused_filters_on": fused_on,
+             "filters_off_occlusion": occ,
              "what": "forward-only render() under no_grad per pyramid level (viewer.py:67-81 convention): filters_on = "
                      "--anti_alias (both filters, fade_size 1.0), filters_off = render.py defaults; render_fused_filters_on = "
                      "the raw-parameter entry with the viewer's filters"})
 
 
-def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8, rounds=5):
+def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8, rounds=7):
     """ms per view of sweeps over `views` views of the same model with two of them in flight (ViewPipeline: the forward of view
     i+1 enqueued before the backward of view i on the other stream, no host wait for the instance counts, getters once per sweep,
     gradients summed inside the per-Gaussian backward kernel), against the same sweep done the reference's way — one view after
@@ -314,18 +357,8 @@ def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8
         for p_ in pc.parameters():
             p_.grad = None
 
-    def timed(fn):
-        settle_gc()
-        for _ in range(max(1, warmup // 2)):
-            fn()
-        torch.cuda.synchronize()
-        with quiet_gc():
-            t = time.perf_counter()
-            for _ in range(rounds):
-                fn()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t
-        return round(1e3 * dt / rounds / views, 4)
+    def timed(fn):      # median sweep period / views
+        return round(period_median(fn, rounds, max(1, warmup // 2), torch.cuda.synchronize)[0] / views, 4)
 
     bwd = lambda i, pkg: pkg["render"].backward(dL)
 
@@ -385,6 +418,90 @@ def two_view_timing(pc, cam, bg, dL, settings, W, H, warmup, whole_step, views=8
     return out
 
 
+def algorithmic_bytes(P, W, H, D, D_trav, V):
+    """SURVEY 8(d) per-kernel ALGORITHMIC bytes of one forward + backward (SH degree 3): P Gaussians, V rendered, D tile
+    instances, D_trav = sum over tiles of the longest list prefix a pixel of the tile walks, N pixels."""
+    N = W * H
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    S_sh = 12 * 16
+    tb = max(1, math.ceil(math.log2(tiles)))
+    return {"preprocess": P * (117 + S_sh) + V * 79, "scan": 8 * P, "emit": 12 * D,
+            "sort(depth+tile)": D * (24 * math.ceil((32 + tb) / 8) + 8), "ranges": 8 * D + 8 * tiles,
+            "blend_fwd": 48 * D_trav + 28 * N + 8 * tiles, "blend_bwd": 48 * D_trav + 20 * N + 36 * V,
+            "preprocess_bwd": V * (309 + 36 + 24) + V * 236}
+
+
+def binning_counts(dgr, ctx, P, dev):
+    """(D, D_trav, V) of the forward whose autograd node is `ctx` (msgs_binning_stats)"""
+    import ctypes as C
+    geom, binning, image, D = ctx.state
+    scratch = torch.empty(256, dtype=torch.uint8, device=dev)
+    o = (C.c_int64 * 2)()
+    dgr._C.check(dgr._C.lib.msgs_binning_stats(C.byref(ctx.call.view), P, C.c_void_p(ctx.radii.data_ptr()),
+                                               C.c_void_p(binning.data_ptr()), binning.numel(),
+                                               C.c_void_p(image.data_ptr()), image.numel(),
+                                               C.c_void_p(scratch.data_ptr()), scratch.numel(), o,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stats")
+    return int(D), int(o[0]), int(o[1])
+
+
+def config_leg(name, scenes, dev, steps=20, warmup=3):
+    """One of the other BASELINE configs through the same call surface (render() + backward of the fixed dL/dimage), for the
+    driver's line: median period of `steps` steps, instance counts, per-kernel HIP-event times, whole-step algorithmic bytes
+    against HBM, peak device memory.  C2 = BASELINE configs[1] (100 k Gaussians, 800x800, SH 3); C5 = configs[4] (5 M, 3840x2160,
+    multi-scale levels, filters on)."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import PIPE, render
+    from synthetic_model import SyntheticGaussians
+    sc, cam, st = scenes.config(name)
+    W, H, P = cam.image_width, cam.image_height, sc.P
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    pc = SyntheticGaussians(sc, dev, requires_grad=True)
+    cam = cam.to(dev)
+    bg = torch.zeros(3, device=dev)
+    dL = scenes.grad_seed(W, H, {"C2": 1, "C5": 5}.get(name, 0)).to(dev)
+
+    def step():
+        for p_ in pc.parameters():
+            p_.grad = None
+        out = render(cam, pc, PIPE, bg, **st)
+        out["render"].backward(dL)
+        return out
+    med, ts = period_median(step, steps, warmup, torch.cuda.synchronize)
+    timers = [dgr._C.KernelTimer() for _ in range(3)]
+    for t_ in timers:
+        dgr._C.set_timer(t_)
+        step()
+    dgr._C.set_timer(None)
+    torch.cuda.synchronize()
+    acc = {}
+    for t_ in timers:
+        for k, v in t_.read_ms().items():
+            if v >= 0:
+                acc.setdefault(k, []).append(v)
+    kernels = {k: round(float(np.mean(v)), 4) for k, v in acc.items()}
+    out = step()
+    torch.cuda.synchronize()
+    D, D_trav, V = binning_counts(dgr, out["render"].grad_fn, P, dev)
+    alg = algorithmic_bytes(P, W, H, D, D_trav, V)
+    total = float(sum(alg.values()))
+    peak = int(torch.cuda.max_memory_allocated(dev))
+    res = {"workload": {"C2": "BASELINE configs[1]: 100k Gaussians, 800x800, SH3, fwd+bwd",
+                        "C5": "BASELINE configs[4]: 5M Gaussians, 3840x2160, multi-scale levels, filter_small+filter_large"}.get(name, name),
+           "ms_per_step": round(med, 4), "min_ms": round(ts[0], 4), "p90_ms": round(ts[int(0.9 * (len(ts) - 1))], 4),
+           "value": round(W * H / 1e6 / (med * 1e-3), 3), "unit": "Mpixels/s", "steps": steps,
+           "how": "median period of the timed steps (HIP events in front of every step)",
+           "gaussians": P, "width": W, "height": H, "instances": D, "D_trav": D_trav, "rendered": V, "kernel_ms": kernels,
+           "sum_kernel_ms": round(float(sum(kernels.values())), 4),
+           "whole_step": {"algorithmic_bytes": int(total), "GBps": round(total / (med * 1e-3) / 1e9, 1),
+                          "frac": round(total / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "peak_device_bytes": peak}
+    del pc, out, dL
+    torch.cuda.empty_cache()
+    return res
+
+
 def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup, multi_view=True):
     import torch.nn.functional as F
     from gaussian_renderer import render
@@ -396,17 +513,7 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
     out = {}
 
     def timed(fn):
-        settle_gc()
-        for _ in range(warmup):
-            fn()
-        torch.cuda.synchronize()
-        with quiet_gc():
-            t = time.perf_counter()
-            for _ in range(steps):
-                fn()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t
-        return 1e3 * dt / steps
+        return period_median(fn, steps, warmup, torch.cuda.synchronize)[0]
 
     model = SyntheticGaussians(scene, dev)
     opt = FusedAdam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
@@ -455,7 +562,8 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
         del model, opt
     except Exception as e:      # informational
         out["ms_per_view_8_views_per_optimizer_step"] = repr(e)
-    out["note"] = "C3 scene, fixed U(0,1) target, lambda_dssim 0.2, level 0, statistics on; informational"
+    out["note"] = ("C3 scene, fixed U(0,1) target, lambda_dssim 0.2, level 0, statistics on; informational; every figure is the "
+                   "median period of the timed iterations (period_median)")
     return out
 
 
@@ -470,6 +578,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C5 legs (configs)")
     ap.add_argument("--no-two-view", action="store_true",
                     help="skip the informational two-views-in-flight block (tools/profile_round.sh: its co-resident kernels "
                          "would enter the per-kernel averages of the profile)")
@@ -929,30 +1038,87 @@ def main():
             valu = None
             sq = committed("sq")
             sq_source = committed.source
+            # instruction mix of the hot loops as the compiler emitted them (tools/isa_mix.py at build time -> build/isa_mix.json;
+            # the copy committed under profiles/ is the fallback when the build directory did not travel)
+            isa, isa_source = None, None
+            for cand_ in [os.path.join(ROOT, "ms-gs_amd", "build", "isa_mix.json")] + sorted(
+                    __import__("glob").glob(os.path.join(ROOT, "profiles", "r*_isa_mix.json")), reverse=True):
+                try:
+                    isa = json.load(open(cand_))
+                    isa_source = os.path.relpath(cand_, ROOT)
+                    break
+                except Exception:
+                    continue
+            cyc = (isa or {}).get("cycles_per_class", {"plain": 2.2, "half": 4.25, "trans": 8.1, "salu": 2.0, "lds": 4.0, "vmem": 2.0})
+            SIMD_HZ = 1024 * 2.4e9
+
+            def cyc_of(c):
+                return sum(float(c.get(k, 0.0)) * cyc[k] for k in cyc)
             if sq and "SQ_INSTS_VALU" in sq:
-                mix = {"blend_fwd": (18.5 / 23.5, 4.0 / 23.5, 1.0 / 23.5),
-                       "blend_bwd": (0.64, 0.31, 0.05)}[dom]
+                if isa and dom == "blend_fwd":
+                    mix = tuple(isa["blend_fwd"]["valu_mix"])
+                elif isa and dom == "blend_bwd" and stats and "blend_bwd_lanes" in stats and isa["blend_bwd"].get("per_reduction"):
+                    # dynamic VALU mix of the backward: visits x entry overhead + quadrant evaluations x quadrant step +
+                    # reductions x reduction, with the counting replica's numbers of this very scene
+                    bl, ib = stats["blend_bwd_lanes"], isa["blend_bwd"]
+                    tot = {k: bl["tile_entry_visits"] * ib["per_entry_visit"][k] + bl["quadrant_entry_evaluations"] * ib["per_quadrant_step"][k]
+                           + bl["visits_with_a_contribution"] * ib["per_reduction"][k] for k in ("plain", "half", "trans")}
+                    nv_ = sum(tot.values())
+                    mix = (tot["plain"] / nv_, tot["half"] / nv_, tot["trans"] / nv_)
+                else:
+                    mix = {"blend_fwd": (18.5 / 23.5, 4.0 / 23.5, 1.0 / 23.5), "blend_bwd": (0.64, 0.31, 0.05)}[dom]
                 nv, ns = float(sq["SQ_INSTS_VALU"]), float(sq.get("SQ_INSTS_SALU", 0.0))
                 nl = float(sq.get("SQ_INSTS_LDS", 0.0))
-                cyc_v = mix[0] * 2.2 + mix[1] * 4.25 + mix[2] * 8.1
-                cycles = nv * cyc_v + ns * 2.0 + nl * 4.0
-                floor_ms = cycles / (1024 * 2.4e9) * 1e3
+                cyc_v = mix[0] * cyc["plain"] + mix[1] * cyc["half"] + mix[2] * cyc["trans"]
+                cycles = nv * cyc_v + ns * cyc["salu"] + nl * cyc["lds"]
+                floor_ms = cycles / SIMD_HZ * 1e3
                 valu = {"valu_wave_instructions": nv, "salu_wave_instructions": ns, "lds_wave_instructions": nl,
+                        "valu_mix_plain_half_trans": [round(m_, 4) for m_ in mix],
                         "cycles_per_valu_instruction_of_this_mix": round(cyc_v, 3),
                         "issue_floor_ms": round(floor_ms, 4), "frac_of_issue_floor": round(floor_ms / kernels[dom], 4),
-                        "valu_only_floor_ms": round(nv * cyc_v / (1024 * 2.4e9) * 1e3, 4),
+                        "valu_only_floor_ms": round(nv * cyc_v / SIMD_HZ * 1e3, 4),
                         "model": "sum over classes of wave-instructions x calibrated cycles per instruction per SIMD "
-                                 "(VALU mix, scalar 2.0, LDS 4.0) / (1024 SIMDs x 2.4 GHz)",
-                        "source": f"{sq_source} + profiles/r2_valu_calibration.txt"}
+                                 "(VALU mix, scalar 2.0, LDS 4.0) / (1024 SIMDs x 2.4 GHz); NOT an efficiency — it prices the "
+                                 "kernel's OWN instruction count, so any issue-bound kernel scores ~1: see useful_issue",
+                        "source": f"{sq_source} + profiles/r2_valu_calibration.txt + {isa_source or 'hand-counted mix (no isa_mix.json)'}"}
+            # USEFUL issue: the time the vector units would need for the pairs that actually contribute, at the per-pair
+            # instruction cost of this very ISA with every lane useful and no per-entry overhead — what the hardware could do
+            # for this work — over the measured kernel time.  forward: pairs that blended x VALU of one (wave, entry) step / 64;
+            # backward: pairs that contributed a gradient x VALU of one quadrant step / 64.
+            useful = None
+            if isa and stats and "blend_fwd_lanes" in stats and kernels.get("blend_fwd") and kernels.get("blend_bwd"):
+                f_ms = stats["blend_fwd_lanes"]["lanes_blended"] / 64.0 * isa["blend_fwd"]["valu_cycles_per_wave_entry"] / SIMD_HZ * 1e3
+                useful = {"blend_fwd": {"contributing_pairs": stats["blend_fwd_lanes"]["lanes_blended"],
+                                        "valu_per_64_pairs": round(isa["blend_fwd"]["valu_per_wave_entry"], 2),
+                                        "useful_ms": round(f_ms, 4), "kernel_ms": kernels["blend_fwd"],
+                                        "frac": round(f_ms / kernels["blend_fwd"], 4)}}
+                pair_ms = f_ms
+                if "blend_bwd_lanes" in stats:
+                    b_ms = stats["blend_bwd_lanes"]["lanes_contributing"] / 64.0 * isa["blend_bwd"]["valu_cycles_per_quadrant_step"] / SIMD_HZ * 1e3
+                    useful["blend_bwd"] = {"contributing_pairs": stats["blend_bwd_lanes"]["lanes_contributing"],
+                                           "valu_per_64_pairs": round(isa["blend_bwd"]["valu_per_quadrant_step"], 2),
+                                           "useful_ms": round(b_ms, 4), "kernel_ms": kernels["blend_bwd"],
+                                           "frac": round(b_ms / kernels["blend_bwd"], 4)}
+                    pair_ms += b_ms
+                    # the same ISA counts x the replica's counts reproduce the kernel: a check of the model, not a new number
+                    bl, ib = stats["blend_bwd_lanes"], isa["blend_bwd"]
+                    if ib.get("per_reduction"):
+                        model_ms = (bl["tile_entry_visits"] * cyc_of(ib["per_entry_visit"]) + bl["quadrant_entry_evaluations"] * cyc_of(ib["per_quadrant_step"])
+                                    + bl["visits_with_a_contribution"] * cyc_of(ib["per_reduction"])) / SIMD_HZ * 1e3
+                        useful["blend_bwd"]["isa_x_replica_model_ms"] = round(model_ms, 4)
+                    fl = stats["blend_fwd_lanes"]
+                    useful["blend_fwd"]["isa_x_replica_model_ms"] = round(fl["wave_entry_evaluations"] * isa["blend_fwd"]["cycles_per_wave_entry"] / SIMD_HZ * 1e3, 4)
+                useful["blend_fwd_plus_bwd"] = {"useful_ms": round(pair_ms, 4), "kernel_ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4),
+                                                "frac": round(pair_ms / (kernels["blend_fwd"] + kernels["blend_bwd"]), 4)}
+                useful["what"] = ("contributing (pixel, Gaussian) pairs x VALU instructions of one per-pair step in the emitted ISA / 64 lanes "
+                                  "x calibrated cycles / (1024 SIMDs x 2.4 GHz), over the HIP-event kernel time: the share of the kernel's "
+                                  "time that is arithmetic on pairs that count; the rest is idle lanes, per-entry overhead (fetch, masks, "
+                                  "loop control) and, in the backward, the cross-lane reduction and the atomics")
+                useful["source"] = isa_source
             # every SURVEY 8(d) row against HBM, from the same HIP-event kernel times: the HBM-bound kernels read against
             # HBM, the issue-bound blend pair against both
-            S_sh = 12 * 16
-            tb = max(1, math.ceil(math.log2(tiles)))
             Dn, Vn = stats["D"], stats["V"]
-            alg_all = {"preprocess": P * (117 + S_sh) + Vn * 79, "scan": 8 * P, "emit": 12 * Dn,
-                       "sort(depth+tile)": Dn * (24 * math.ceil((32 + tb) / 8) + 8), "ranges": 8 * Dn + 8 * tiles,
-                       "blend_fwd": alg["blend_fwd"], "blend_bwd": alg["blend_bwd"],
-                       "preprocess_bwd": Vn * (309 + 36 + 24) + Vn * 236}
+            alg_all = algorithmic_bytes(P, W, H, Dn, stats["D_trav"], Vn)
             kms = dict(kernels)
             kms["sort(depth+tile)"] = kernels.get("depth_sort", 0.0) + kernels.get("tile_sort", 0.0)
             per_kernel = {k: {"algorithmic_bytes": int(b), "ms": round(kms[k], 4),
@@ -988,7 +1154,7 @@ def main():
                              "culling) / the driver-timed step / 8 TB/s; K4 priced as the reference's 64-bit-key sort"}
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom], "valu_issue": valu,
+                    "algorithmic_bytes": alg[dom], "avg_kernel_ms": kernels[dom], "valu_issue": valu, "useful_issue": useful,
                     "blend_fwd_plus_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
                                            "algorithmic_bytes": alg["blend_fwd"] + alg["blend_bwd"],
                                            "ms": round(kernels["blend_fwd"] + kernels["blend_bwd"], 4)},
@@ -1019,18 +1185,10 @@ def main():
                     for p_ in pc.parameters():
                         p_.grad = None
                     render_fused(cam, pc, PIPE, bg, **settings)["render"].backward(dL)
-                settle_gc()
-                for _ in range(args.warmup):
-                    fused_step()
-                torch.cuda.synchronize()
-                with quiet_gc():
-                    tf = time.perf_counter()
-                    for _ in range(args.steps):
-                        fused_step()
-                    torch.cuda.synchronize()
-                    tf = (time.perf_counter() - tf) / args.steps
+                tf = 1e-3 * period_median(fused_step, max(args.steps, 20), args.warmup, torch.cuda.synchronize)[0]
                 result["fused_path"] = {"ms_per_step": round(1e3 * tf, 4), "value": round(W * H / 1e6 / tf, 3),
-                                        "unit": "Mpixels/s", "entry": "GaussianRasterizer.forward_raw"}
+                                        "unit": "Mpixels/s", "entry": "GaussianRasterizer.forward_raw",
+                                        "how": "median period of >= 20 steps"}
             except Exception as e:
                 result["fused_path"] = {"error": repr(e)}
             # informational: the same workload with TWO views in flight (host/multi_view.py; review item 1).  Eight copies of the
@@ -1050,6 +1208,17 @@ def main():
             except Exception as e:
                 result["train_iteration"] = {"error": repr(e)}
         result["binning"] = stats
+        # the other single-GPU BASELINE configs, driver-visible (review item 4): C2 and C5 through the same call surface
+        if world == 1 and (P, W, H) == (1_000_000, 1920, 1080) and not args.no_configs:
+            result["configs"] = {}
+            pc = dL = call_out = None           # (the closures above keep the names alive: drop the tensors, not the names)
+            gc.collect()
+            torch.cuda.empty_cache()
+            for name in ("C2", "C5"):
+                try:
+                    result["configs"][name] = config_leg(name, scenes, dev)
+                except Exception as e:      # informational
+                    result["configs"][name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(scenes, scene, settings, W, H)
