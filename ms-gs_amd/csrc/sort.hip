@@ -155,6 +155,68 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
     }
 }
 
+// Two-kernel scan (default since round 5): scan_reduce_kernel leaves one total per block; every block of THIS kernel sums the
+// totals in front of it itself (nb <= a few thousand values, L2-resident: 1 - 5 loads per thread) instead of waiting for a
+// one-block kernel in between, and block 0 — which sums ALL of them — publishes the grand total first thing: device word,
+// clamped copy for a speculative stage 2, status words and the polled host words.  One launch less per forward (~5 us).
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_fused_kernel(const uint32_t* in, uint32_t* out, int64_t n,
+                                                                        const uint64_t* __restrict__ partials, int64_t nb,
+                                                                        const uint32_t* __restrict__ n_ptr,
+                                                                        uint64_t* __restrict__ total_out,
+                                                                        uint64_t* __restrict__ status,
+                                                                        volatile uint64_t* host, uint64_t ticket,
+                                                                        uint32_t* __restrict__ clamped_total, uint64_t clamp,
+                                                                        const uint32_t* __restrict__ extra) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint64_t s_sum[4];
+    if (n_ptr) n = (int64_t)*n_ptr;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // blocks behind the data (n_ptr < grid capacity) still need nothing; block 0 always runs (it owns the publication)
+    const int64_t chunk0 = (int64_t)blockIdx.x * SCAN_CHUNK;
+    if (blockIdx.x != 0 && chunk0 >= n) return;
+    const int64_t upto = blockIdx.x == 0 ? nb : (int64_t)blockIdx.x;       // block 0: the grand total
+    uint64_t acc = 0;
+    for (int64_t q = threadIdx.x; q < upto; q += SCAN_THREADS) acc += partials[q];
+    for (int off = 32; off > 0; off >>= 1)
+        acc += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)acc, off);
+    if (lane == 0) s_sum[w] = acc;
+    __syncthreads();
+    const uint64_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    uint64_t base = sum;
+    if (blockIdx.x == 0) {
+        base = 0;
+        if (threadIdx.x == 0) {
+            if (total_out) *total_out = sum;
+            if (clamped_total) *clamped_total = (uint32_t)(sum < clamp ? sum : clamp);
+            const uint64_t info = extra ? ((uint64_t)extra[0] | ((uint64_t)extra[1] << 32)) : 0ull;
+            if (status) { status[0] = sum; status[1] = 0; status[2] = info; }
+            if (host) {
+                host[0] = sum;
+                host[1] = 0;
+                host[3] = info;
+                __threadfence_system();
+                host[2] = ticket;
+            }
+        }
+        if (chunk0 >= n) return;
+    }
+    const int64_t tb = chunk0 + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    scan_load_items(in, tb, n, v);
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) tsum += v[k];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(tsum, s_wave, &total) + (uint32_t)base;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t x = v[k];
+        v[k] = run;
+        run += x;
+    }
+    scan_store_items(out, tb, n, v);
+}
+
 // `in` may alias `out` (in-place: every thread reads its SCAN_ITEMS values before it writes them)
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather,
                                                                   uint32_t* out, int64_t n,
@@ -686,6 +748,14 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     const bool stage = gather != nullptr && out != in;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
                        stage ? out : (uint32_t*)nullptr, n_ptr);
+    // MSGS_SCAN_THREE_KERNELS=1: the round-1..4 route (reduce, one-block scan of the totals, apply) for A/B runs
+    static const bool three = [] { const char* e = getenv("MSGS_SCAN_THREE_KERNELS"); return e && e[0] == '1'; }();
+    if (!three && (stage || gather == nullptr)) {
+        hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s,
+                           stage ? (const uint32_t*)out : in, out, n, (const uint64_t*)partials, nb, n_ptr, total, status,
+                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
                        (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
