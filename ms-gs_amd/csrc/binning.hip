@@ -82,11 +82,12 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     constexpr uint32_t HEAVY_MIN = 96;
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
     if (count) { q0 = binrec[gi].q0; q1 = binrec[gi].q1; }
-    // a Gaussian behind some cut-off with a large rect walks its tiles with the whole wave as well, however few of them are
-    // left: one thread skipping thousands of closed tiles would hold its wave for as long
+    // a Gaussian behind some cut-off with a very large rect walks its tiles with the whole wave as well, however few of them
+    // are left; up to OCC_LIGHT_RECT tiles of rect its own thread does it, skipping closed rows of blocks and closed blocks
+    // whole (the wave path handles ONE Gaussian at a time: a wave of 64 medium footprints took 64 turns, 0.48 ms per view)
     const uint32_t rect_area = ((__float_as_uint(q1.w) & 0xFFFFu) - (__float_as_uint(q1.z) & 0xFFFFu)) *
                                ((__float_as_uint(q1.w) >> 16) - (__float_as_uint(q1.z) >> 16));
-    const bool heavy = count > HEAVY_MIN || (count > 0 && cut_check && rect_area > 64u);
+    const bool heavy = count > HEAVY_MIN || (count > 0 && cut_check && rect_area > (uint32_t)OCC_LIGHT_RECT);
     auto put = [&](int64_t at, uint32_t k, uint32_t g_id, uint32_t owner) {
         if (staged) { s_keys[at - blk_lo] = (KeyT)k; s_own[at - blk_lo] = (uint8_t)owner; }
         else { keys[at] = (OutT)k; ids[at] = g_id; }
@@ -103,10 +104,25 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
             if (cut_check && T.rowmax[ty >> occ_lb] < kmine) continue;          // this row of blocks is closed at this depth
             int tlo = minx, thi = maxx - 1;
             if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi)) continue;
-            for (int tx = tlo; tx <= thi && off < end; ++tx) {
-                if (cut_check && T.cut[(ty >> occ_lb) * occ_nbx + (tx >> occ_lb)] < kmine) continue;
-                put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
-                ++off;
+            if (!cut_check) {
+                for (int tx = tlo; tx <= thi && off < end; ++tx) {
+                    put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
+                    ++off;
+                }
+            } else {                                       // cover block by cover block: a closed one is skipped whole
+                const int brow = (ty >> occ_lb) * occ_nbx;
+                int tx = tlo;
+                while (tx <= thi && off < end) {
+                    const int bend = min(thi, (((tx >> occ_lb) + 1) << occ_lb) - 1);
+                    if (T.cut[brow + (tx >> occ_lb)] >= kmine) {
+                        for (; tx <= bend && off < end; ++tx) {
+                            put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
+                            ++off;
+                        }
+                    } else {
+                        tx = bend + 1;
+                    }
+                }
             }
         }
         // count >= emitted by construction (larger margin in the count): park the surplus slots on the sentinel tile
@@ -121,16 +137,16 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
         while (hv) {
             const int src = __ffsll((long long)hv) - 1;
             hv &= hv - 1;
-            const uint32_t h_gi = (uint32_t)__shfl((int)gi, src);
+            const uint32_t h_gi = lane_bcast(gi, src);
             const uint32_t h_owner = (uint32_t)((threadIdx.x & ~63) + src);
-            const int64_t h_off = ((int64_t)__shfl((int)(uint32_t)(off >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)off, src);
-            const uint32_t h_count = (uint32_t)__shfl((int)count, src);
-            const uint32_t h_key = (uint32_t)__shfl((int)kmine, src);
+            const int64_t h_off = ((int64_t)lane_bcast((uint32_t)(off >> 32), src) << 32) | lane_bcast((uint32_t)off, src);
+            const uint32_t h_count = lane_bcast(count, src);
+            const uint32_t h_key = lane_bcast(kmine, src);
             const bool h_check = h_key > cut_min;
             const int64_t h_end = min(h_off + (int64_t)h_count, D);
-            const float gx_ = __shfl(q0.x, src), gy_ = __shfl(q0.y, src), cA = __shfl(q0.z, src), cBh = __shfl(q0.w, src);
-            const float cC = __shfl(q1.x, src), tau2 = __shfl(q1.y, src);
-            const uint32_t rcx = __float_as_uint(__shfl(q1.z, src)), rcy = __float_as_uint(__shfl(q1.w, src));
+            const float gx_ = lane_bcast(q0.x, src), gy_ = lane_bcast(q0.y, src), cA = lane_bcast(q0.z, src), cBh = lane_bcast(q0.w, src);
+            const float cC = lane_bcast(q1.x, src), tau2 = lane_bcast(q1.y, src);
+            const uint32_t rcx = __float_as_uint(lane_bcast(q1.z, src)), rcy = __float_as_uint(lane_bcast(q1.w, src));
             const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
             const bool test = tau2 > -1.0e38f;
             const LevelSetRows ls = test ? levelset_rows_setup(cA, cBh, cC, tau2) : LevelSetRows{};
@@ -146,8 +162,8 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
                 while (rows && at < h_end) {                           // wave-uniform: the rows that receive something
                     const int r = __ffsll((long long)rows) - 1;
                     rows &= rows - 1;
-                    const int n_r = __shfl(n_row, r);
-                    const int tlo_r = __shfl(tlo, r);
+                    const int n_r = lane_bcast(n_row, r);
+                    const int tlo_r = lane_bcast(tlo, r);
                     const uint32_t kbase = (uint32_t)((row0 + r) * vp.gx + tlo_r);
                     if (!h_check) {
                         for (int j = lane; j < n_r; j += 64)

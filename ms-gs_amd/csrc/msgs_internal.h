@@ -313,6 +313,14 @@ __device__ __forceinline__ float cross_row_allreduce_bperm(float x, int addr16, 
     return x;
 }
 
+// broadcast of lane `src` (wave-uniform) without the LDS crossbar: __shfl with a run-time lane index compiles to ds_bpermute_b32
+// (an LDS round trip per value); with a uniform index v_readlane_b32 does it in one VALU-to-SGPR move
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 // every lane receives the wave total
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
     v += dpp_mov<0xB1>(v);            // xor 1
@@ -332,6 +340,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // blocks).  Cut-offs are depth BUCKETS (occ_bucket of a depth key; 0xFFFF = the block stayed open): a Gaussian reaches a block
 // iff its own bucket is <= the block's.  4.6 KB of LDS.  Called by all threads of the block; ends with a barrier.
 constexpr int OCC_MAX_BLOCK_ROWS = 256;
+constexpr int OCC_LIGHT_RECT = 1024;        // tiles of rect up to which a Gaussian behind a cut-off is walked by its own thread
 __device__ __forceinline__ uint32_t occ_bucket(uint32_t depth_key) {
     const uint32_t kb = depth_key >> OCC_KEY_SHIFT;
     return kb > OCC_KEY_BASE ? min(kb - OCC_KEY_BASE, (uint32_t)(OCC_BUCKETS - 1)) : 0u;

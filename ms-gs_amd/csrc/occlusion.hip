@@ -225,10 +225,9 @@ __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams
 
 // Gaussians behind the nearest cut-off count their instances again: the same per-row level-set extents and margin as the
 // count in preprocess_kernel, restricted to the tiles whose block's cut-off they are in front of.  Index order (before the
-// depth sort).  The block table sits in LDS.  Small footprints (rect of at most OCC_LIGHT_RECT tiles) are recounted by their own
-// thread — a bounded loop of LDS look-ups; larger ones by their whole wave: lane <-> tile row for the row extents, then only the
+// depth sort).  The block table sits in LDS.  Footprints with a rect of at most OCC_LIGHT_RECT tiles are recounted by their own
+// thread — rows of blocks and blocks that are closed at this depth are skipped whole; larger ones by their whole wave: lane <-> tile row for the row extents, then only the
 // rows whose row of blocks is still open at this depth, with the lanes on consecutive tiles.
-constexpr int OCC_LIGHT_RECT = 64;
 constexpr int OCC_RECOUNT_THREADS = 1024;     // (few, fat workgroups: on a view where nothing closed every one of them only reads
                                               //  the header and leaves)
 __global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewParams vp, int P, char* __restrict__ geom) {
@@ -268,7 +267,11 @@ __global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewPa
             int tlo = minx, thi = maxx - 1;
             if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi)) continue;
             const int brow = (ty >> lb) * nbx;
-            for (int tx = tlo; tx <= thi; ++tx) c += T.cut[brow + (tx >> lb)] >= k ? 1u : 0u;
+            for (int tx = tlo; tx <= thi;) {                             // cover block by cover block
+                const int bend = min(thi, (((tx >> lb) + 1) << lb) - 1);
+                if (T.cut[brow + (tx >> lb)] >= k) c += (uint32_t)(bend - tx + 1);
+                tx = bend + 1;
+            }
         }
         newcnt = c;
     }
@@ -276,10 +279,10 @@ __global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewPa
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const uint32_t h_key = (uint32_t)__shfl((int)k, src);
-        const float gx_ = __shfl(q0.x, src), gy_ = __shfl(q0.y, src), cA = __shfl(q0.z, src), cBh = __shfl(q0.w, src);
-        const float cC = __shfl(q1.x, src), tau2 = __shfl(q1.y, src);
-        const int h_minx = __shfl(minx, src), h_miny = __shfl(miny, src), h_maxx = __shfl(maxx, src), h_maxy = __shfl(maxy, src);
+        const uint32_t h_key = lane_bcast(k, src);
+        const float gx_ = lane_bcast(q0.x, src), gy_ = lane_bcast(q0.y, src), cA = lane_bcast(q0.z, src), cBh = lane_bcast(q0.w, src);
+        const float cC = lane_bcast(q1.x, src), tau2 = lane_bcast(q1.y, src);
+        const int h_minx = lane_bcast(minx, src), h_miny = lane_bcast(miny, src), h_maxx = lane_bcast(maxx, src), h_maxy = lane_bcast(maxy, src);
         const bool test = tau2 > -1.0e38f;
         const LevelSetRows ls = test ? levelset_rows_setup(cA, cBh, cC, tau2) : LevelSetRows{};
         uint32_t c = 0;                                                 // wave-uniform
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewPa
             while (rows) {
                 const int r = __ffsll((long long)rows) - 1;
                 rows &= rows - 1;
-                const int n_r = __shfl(n_row, r), tlo_r = __shfl(tlo, r);
+                const int n_r = lane_bcast(n_row, r), tlo_r = lane_bcast(tlo, r);
                 const int brow = ((row0 + r) >> lb) * nbx;
                 for (int j0 = 0; j0 < n_r; j0 += 64) {
                     const int j = j0 + lane;
