@@ -63,7 +63,8 @@ __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_
 // OCC_MAX_BLOCKS blocks — the table then fits the LDS of the two kernels that look tiles up in it (emit, recount).
 // ---------------------------------------------------------------------------------------------
 constexpr int OCC_MAX_BLOCKS = 2048;
-constexpr int OCC_MAX_CAND = 16384;         // cover candidates kept per view (a deterministic sample when there are more)
+constexpr int OCC_MAX_CAND = 32768;         // cover candidates kept per view: the NEAREST ones, whole depth buckets (or, when the
+                                            // nearest bucket alone holds more, every stride-th of all in index order)
 constexpr uint32_t OCC_HEAVY_MIN = 96;      // tile instances a Gaussian needs to be a cover candidate (= emit's wave path)
 constexpr int OCC_BUCKETS = 2048;           // depth buckets of the front-to-back accumulation: key >> 19, i.e. 1/16 octave
 constexpr int OCC_KEY_SHIFT = 19;
@@ -76,7 +77,9 @@ struct OccHeader {
     uint32_t block_log2;      // log2 of the tiles per side of a cover block
     uint32_t nbx;             // cover blocks per row of blocks
     uint32_t nby;             // rows of cover blocks (nbx * nby <= OCC_MAX_BLOCKS)
-    uint32_t pad[9];          // (no instance statistics: one atomic per wave on a shared word cost 0.4 ms on a view that
+    uint32_t n_written;       // candidate records appended so far (positions of the depth-selected gather; ends at n_cand)
+    uint32_t depth_limit;     // depth bucket up to which candidates were kept (OCC_BUCKETS - 1: all; 0xFFFFFFFF: stride sample)
+    uint32_t pad[7];          // (no instance statistics: one atomic per wave on a shared word cost 0.4 ms on a view that
                               //  drops 420 M instances; run the view with msgs_set_occlusion(0) to learn the uncut count)
 };
 static_assert(sizeof(OccHeader) == 64, "OccHeader layout");
@@ -98,7 +101,8 @@ struct GeomLayout {
         nvalid = o; o += 256;                       // one word: V = Gaussians that stayed in the (compacting) depth sort —
                                                     // order[0..V) / offs[0..V) are the ranks the scan and the emit cover
         skey = o;   o = align256(o + 4 * P);        // depth keys in depth order (the sort's key output): emit's cut-off test
-        occ_hdr = o; o = align256(o + sizeof(OccHeader));
+        occ_hdr = o; o = align256(o + sizeof(OccHeader) + 4 * (size_t)OCC_BUCKETS);   // header + depth histogram of the
+                                                                                        // cover candidates (both cleared by K1)
         occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth bucket per cover block (0xFFFF = open)
         total = o;
     }
@@ -147,7 +151,7 @@ struct Stage1Scratch {
         total_out = o;     o = align256(o + 64);    // {scan total} and the collected status block
         // occlusion cut-off: cover candidates as preprocess_kernel leaves them (per wave: up to 64 Gaussian ids + a count),
         // and their gathered records (one per candidate)
-        heavy_list = o;    o = align256(o + 4 * 64 * waves);
+        heavy_list = o;    o = align256(o + 8 * 64 * waves);     // {Gaussian id, depth key} pairs
         heavy_count = o;   o = align256(o + 4 * waves);
         occ_cand = o;      o = align256(o + sizeof(OccCand) * OCC_MAX_CAND);
         total = o;

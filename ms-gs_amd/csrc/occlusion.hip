@@ -20,13 +20,14 @@
 // accumulates per depth BUCKET (1/16 octave of view depth) instead of per rank — the cut-off is the far end of the bucket in
 // which the product crosses.  Integer (fixed-point) sums: the result does not depend on the order the candidates arrive in.
 //
-// Three launches between preprocess_kernel and the depth sort:
-//   occ_gather_kernel    compacts the per-wave candidate lists K1 left behind into records (one atomic per wave that has any)
+// Four launches between preprocess_kernel and the depth sort:
+//   occ_hist_kernel      depth histogram of the candidates preprocess_kernel left behind, per wave slot
+//   occ_gather_kernel    keeps the nearest OCC_MAX_CAND of them (whole depth buckets) and gathers their records
 //   occ_cover_kernel     one workgroup per block of tiles: bucketed sums of -log2(1 - alpha_min), prefix, cut-off key per tile
 //   occ_recount_kernel   Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in
 //                        place; a Gaussian left without instances leaves the depth sort: key 0xFFFFFFFF)
-// On a view where nothing closes (the BASELINE C3 headline: 363 candidates) the three cost ~7 us: the first reads 62 KB of
-// counts, the second walks six candidates per block, the third leaves at once.
+// On a view where nothing closes (the BASELINE C3 headline: four candidates) they cost ~15 us; the Python wrapper then skips the
+// pass for that kind of view and probes again every 32nd call (msgs_view_t.skip_occlusion, msgs_forward_info).
 #include "msgs_internal.h"
 
 #include <atomic>
@@ -44,46 +45,108 @@ constexpr uint32_t OCC_THRESHOLD = (uint32_t)(OCC_LOG2_T * OCC_FIX) + 1u;
 // (sums stay below 2^32: a cover adds at most -log2(0.01) * 2048 = 13 607, and a view has fewer than 2^31 / 13 607 candidates
 //  per bucket in any scene this library accepts — P < 2^31 — while the prefix saturates below)
 
-// Candidate gather: ONE launch, no atomics, deterministic positions.  preprocess_kernel left, per wave slot, the ids of its
-// heavy Gaussians and their number.  Every workgroup owns 256 consecutive slots (one per thread); it sums ALL slot counts itself
-// (62 KB at 1 M Gaussians, L2-resident: cheaper than a second launch) to learn the total and the number of candidates in front
-// of its own slots, so that a candidate's position in index order is known without communication.  At most OCC_MAX_CAND
-// candidates are kept: every stride-th one in index order — a deterministic sample that is uncorrelated with depth.  A subset
-// of the covers still gives a valid cut-off (header comment); with the sample it lies at most about one depth bucket farther.
+// Cover candidates.  preprocess_kernel left, per wave slot, {id, depth key} of its heavy Gaussians and their number.  Only the
+// NEAREST candidates matter (the product crosses within the first few dozen covers of a block), so at most OCC_MAX_CAND are kept,
+// chosen by depth:
+//   occ_hist_kernel    every workgroup (256 slots, one per thread) counts its candidates per depth bucket in LDS and adds the
+//                      non-empty buckets and its total to the view's histogram / counter (cleared by preprocess_kernel)
+//   occ_gather_kernel  every workgroup prefix-sums the histogram itself, finds the deepest bucket kappa up to which the candidates
+//                      still fit, keeps its candidates with bucket <= kappa (positions: one atomic per workgroup — the ORDER of the
+//                      records is irrelevant, the cover sums are integers; the SET is deterministic) and gathers their records.
+//                      When the nearest non-empty bucket alone holds more than fit (thousands of covers at one depth), every
+//                      stride-th candidate in index order is kept instead: positions by formula from all slot counts.
 constexpr int OCC_GATHER_SLOTS = 256;       // wave slots per workgroup (one per thread)
+
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* s_w, uint32_t* block_total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < wv; ++k) base += s_w[k];
+    *block_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void occ_hist_kernel(const uint32_t* __restrict__ heavy_list,
+                                                       const uint32_t* __restrict__ heavy_count, int n_slots,
+                                                       OccHeader* __restrict__ hdr, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[OCC_BUCKETS];
+    __shared__ uint32_t s_w[4];
+    const int slot = blockIdx.x * OCC_GATHER_SLOTS + threadIdx.x;
+    const uint32_t cnt = slot < n_slots ? heavy_count[slot] : 0u;
+    uint32_t total;
+    block_exclusive_256(cnt, s_w, &total);
+    if (total == 0) return;                                             // (block-uniform)
+    for (int k = threadIdx.x; k < OCC_BUCKETS; k += 256) s_h[k] = 0u;
+    __syncthreads();
+    const uint2* e = reinterpret_cast<const uint2*>(heavy_list) + (size_t)slot * 64;
+    for (uint32_t j = 0; j < cnt; ++j) atomicAdd(&s_h[occ_bucket(e[j].y)], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < OCC_BUCKETS; k += 256)
+        if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
+    if (threadIdx.x == 0) atomicAdd(&hdr->n_heavy, total);
+}
 
 __global__ __launch_bounds__(256) void occ_gather_kernel(int P, const char* __restrict__ geom,
                                                          const uint32_t* __restrict__ heavy_list,
                                                          const uint32_t* __restrict__ heavy_count, int n_slots,
-                                                         OccHeader* __restrict__ hdr, OccCand* __restrict__ cand,
+                                                         OccHeader* __restrict__ hdr, const uint32_t* __restrict__ hist,
+                                                         OccCand* __restrict__ cand,
                                                          uint32_t block_log2, uint32_t nbx, uint32_t nby) {
     __shared__ uint16_t s_kept[OCC_GATHER_SLOTS * 64];     // (local slot << 6) | index in the slot
     __shared__ uint32_t s_prefix[OCC_GATHER_SLOTS];
-    __shared__ uint32_t s_red[2][4], s_scan[4], s_kscan[4];
+    __shared__ uint32_t s_red[2][4], s_scan[4], s_kappa, s_keep, s_base;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int slot0 = blockIdx.x * OCC_GATHER_SLOTS;
-    // total and the part in front of this workgroup's slots (4 counts per load)
-    uint32_t before = 0, total = 0;
-    const int n4 = n_slots >> 2;                        // n_slots is a multiple of 4
-    const uint4* c4 = reinterpret_cast<const uint4*>(heavy_count);
-    for (int q = threadIdx.x; q < n4; q += 256) {
-        const uint4 v = c4[q];
-        const uint32_t sum = v.x + v.y + v.z + v.w;
-        total += sum;
-        if (4 * q < slot0) before += sum;               // slot0 is a multiple of 4
+    const uint32_t total = hdr->n_heavy;                    // final: occ_hist_kernel has completed
+    // deepest bucket kappa with (candidates in buckets <= kappa) <= OCC_MAX_CAND; thread t owns 8 consecutive buckets
+    constexpr int PER = OCC_BUCKETS / 256;
+    uint32_t hv[PER], hsum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { hv[k] = hist[threadIdx.x * PER + k]; hsum += hv[k]; }
+    if (threadIdx.x == 0) { s_kappa = 0xFFFFFFFFu; s_keep = 0u; }
+    uint32_t dummy;
+    uint32_t run = block_exclusive_256(hsum, s_scan, &dummy);
+    {
+        uint32_t best = 0xFFFFFFFFu, keep = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            run += hv[k];
+            if (hv[k] && run <= (uint32_t)OCC_MAX_CAND) { best = (uint32_t)(threadIdx.x * PER + k); keep = run; }
+        }
+        if (best != 0xFFFFFFFFu) { atomicMax(&s_keep, keep); }          // cumulative counts grow with the bucket index: the
+        __syncthreads();                                                //   largest admissible cumulative count marks kappa
+        if (best != 0xFFFFFFFFu && keep == s_keep) s_kappa = best;
+        __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        total += (uint32_t)__shfl_xor((int)total, off);
-        before += (uint32_t)__shfl_xor((int)before, off);
+    const uint32_t kappa = s_kappa, keep_total = s_keep;
+    const bool by_depth = total <= (uint32_t)OCC_MAX_CAND || kappa != 0xFFFFFFFFu;
+    const uint32_t limit = total <= (uint32_t)OCC_MAX_CAND ? (uint32_t)(OCC_BUCKETS - 1) : kappa;
+    uint32_t stride = 1u, before = 0u;
+    if (!by_depth) {
+        // the nearest bucket alone is too full: every stride-th candidate in index order; the candidates in front of this
+        // workgroup's slots from ALL slot counts (62 KB at 1 M Gaussians, four counts per load)
+        stride = (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND;
+        const int n4 = n_slots >> 2;                        // n_slots is a multiple of 4
+        const uint4* c4 = reinterpret_cast<const uint4*>(heavy_count);
+        for (int q = threadIdx.x; q < n4 && 4 * q < slot0; q += 256) {
+            const uint4 v = c4[q];
+            before += v.x + v.y + v.z + v.w;
+        }
+        for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off);
+        if (lane == 0) s_red[1][wv] = before;
+        __syncthreads();
+        before = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
     }
-    if (lane == 0) { s_red[0][wv] = total; s_red[1][wv] = before; }
-    __syncthreads();
-    total = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-    before = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-    const uint32_t stride = total > (uint32_t)OCC_MAX_CAND ? (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND : 1u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {              // (the header was zeroed by preprocess_kernel)
-        hdr->n_cand = (total + stride - 1) / stride;
-        hdr->n_heavy = total;
+        hdr->n_cand = by_depth ? (total <= (uint32_t)OCC_MAX_CAND ? total : keep_total) : (total + stride - 1) / stride;
+        hdr->depth_limit = by_depth ? limit : 0xFFFFFFFFu;
         hdr->enabled = 1u;
         hdr->block_log2 = block_log2;
         hdr->nbx = nbx;
@@ -92,43 +155,39 @@ __global__ __launch_bounds__(256) void occ_gather_kernel(int P, const char* __re
     if (total == 0) return;
     const int slot = slot0 + threadIdx.x;
     const uint32_t cnt = slot < n_slots ? heavy_count[slot] : 0u;
-    // position (index order) of this slot's first candidate, and of its first KEPT candidate in the workgroup's list:
-    // positions g in [first, first + cnt) with g % stride == 0 are kept
-    auto block_exclusive = [&](uint32_t v, uint32_t* s_w, uint32_t* block_total) {
-        uint32_t inc = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-            if (lane >= off) inc += o;
-        }
-        if (lane == 63) s_w[wv] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int k = 0; k < wv; ++k) base += s_w[k];
-        *block_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        return base + inc - v;
-    };
-    uint32_t dummy;
-    const uint32_t first = before + block_exclusive(cnt, s_scan, &dummy);
+    const uint2* ent = reinterpret_cast<const uint2*>(heavy_list);
+    uint32_t kept = 0, first = 0, g0 = 0;
+    if (by_depth) {
+        for (uint32_t j = 0; j < cnt; ++j) kept += occ_bucket(ent[(size_t)slot * 64 + j].y) <= limit ? 1u : 0u;
+    } else {
+        // position (index order) of this slot's first candidate; positions g with g % stride == 0 are kept
+        first = before + block_exclusive_256(cnt, s_scan, &dummy);
+        g0 = ((first + stride - 1) / stride) * stride;
+        kept = g0 < first + cnt ? (first + cnt - 1 - g0) / stride + 1 : 0u;
+    }
     s_prefix[threadIdx.x] = first;
-    const uint32_t g0 = ((first + stride - 1) / stride) * stride;
-    const uint32_t kept = g0 < first + cnt ? (first + cnt - 1 - g0) / stride + 1 : 0u;
     uint32_t kept_total;
-    uint32_t at = block_exclusive(kept, s_kscan, &kept_total);         // <= 256 * 64 entries
-    for (uint32_t g = g0; g < first + cnt; g += stride) s_kept[at++] = (uint16_t)((threadIdx.x << 6) | (g - first));
+    uint32_t at = block_exclusive_256(kept, s_scan, &kept_total);       // <= 256 * 64 entries
+    if (by_depth) {
+        for (uint32_t j = 0; j < cnt; ++j)
+            if (occ_bucket(ent[(size_t)slot * 64 + j].y) <= limit) s_kept[at++] = (uint16_t)((threadIdx.x << 6) | j);
+        if (threadIdx.x == 0) s_base = kept_total ? atomicAdd(&hdr->n_written, kept_total) : 0u;
+    } else {
+        for (uint32_t g = g0; g < first + cnt; g += stride) s_kept[at++] = (uint16_t)((threadIdx.x << 6) | (g - first));
+    }
     __syncthreads();
     const GeomLayout L(P);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + L.rec);
-    const uint32_t* key = reinterpret_cast<const uint32_t*>(geom + L.key);
     for (uint32_t e = threadIdx.x; e < kept_total; e += 256) {
         const uint32_t code = s_kept[e];
         const uint32_t ls = code >> 6, j = code & 63u;
-        const uint32_t gi = heavy_list[(size_t)(slot0 + ls) * 64 + j];
-        const BinRec b = binrec[gi];
+        const uint2 ge = ent[(size_t)(slot0 + ls) * 64 + j];
+        const BinRec b = binrec[ge.x];
         OccCand c;
         c.c0 = b.q0;                                                                  // px, py, kA, kB(half)
-        c.c1 = make_float4(b.q1.x, rec[gi].r1.y, __uint_as_float(key[gi]), __uint_as_float(gi));   // kC, log2 o, depth key, id
-        cand[(s_prefix[ls] + j) / stride] = c;
+        c.c1 = make_float4(b.q1.x, rec[ge.x].r1.y, __uint_as_float(ge.y), __uint_as_float(ge.x));   // kC, log2 o, depth key, id
+        cand[by_depth ? s_base + e : (s_prefix[ls] + j) / stride] = c;
     }
 }
 
@@ -338,9 +397,11 @@ hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint3
     const int n_slots = 4 * ((P + 255) / 256);
     const int lb = occlusion_block_log2(vp.gx, vp.gy), B = 1 << lb;
     const int nbx = (vp.gx + B - 1) / B, nby = (vp.gy + B - 1) / B;
-    hipLaunchKernelGGL(occ_gather_kernel, dim3((n_slots + OCC_GATHER_SLOTS - 1) / OCC_GATHER_SLOTS), dim3(256), 0, s, P,
-                       (const char*)geom, heavy_list, heavy_count, n_slots, hdr, cand, (uint32_t)lb, (uint32_t)nbx,
-                       (uint32_t)nby);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(geom + L.occ_hdr + sizeof(OccHeader));
+    const dim3 gslots((n_slots + OCC_GATHER_SLOTS - 1) / OCC_GATHER_SLOTS);
+    hipLaunchKernelGGL(occ_hist_kernel, gslots, dim3(256), 0, s, heavy_list, heavy_count, n_slots, hdr, hist);
+    hipLaunchKernelGGL(occ_gather_kernel, gslots, dim3(256), 0, s, P, (const char*)geom, heavy_list, heavy_count, n_slots, hdr,
+                       (const uint32_t*)hist, cand, (uint32_t)lb, (uint32_t)nbx, (uint32_t)nby);
     hipLaunchKernelGGL(occ_cover_kernel, dim3(nbx * nby), dim3(OCC_COVER_THREADS), 0, s, vp, B, nbx, hdr, (const OccCand*)cand,
                        reinterpret_cast<uint32_t*>(geom + L.occ_cut));
     hipLaunchKernelGGL(occ_recount_kernel, dim3((P + OCC_RECOUNT_THREADS - 1) / OCC_RECOUNT_THREADS), dim3(OCC_RECOUNT_THREADS), 0, s, vp,

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         const bool hv = out_tiles > OCC_HEAVY_MIN && out_tau2 > -1.0e38f;
         const uint64_t m = __ballot(hv);
         const size_t slot = (size_t)blockIdx.x * 4 + wv;
-        if (hv) heavy_list[slot * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        if (hv) reinterpret_cast<uint2*>(heavy_list)[slot * 64 + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)i, out_key);
         if (lane == 0) heavy_count[slot] = (uint32_t)__popcll(m);
     }
 }

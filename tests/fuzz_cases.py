@@ -27,7 +27,16 @@ evidence the oracles produce (never from the kernel variant or the seed):
                               tensor: the float32 checker itself is that far from the truth there;
     float32_rounding_mode     HIP is no farther from the truth than 1.25 x the farther of the two float32 reference builds
                               (contraction off / on) + 1e-6: inside the spread of the reference algorithm's own legal float32
-                              evaluations.
+                              evaluations;
+    k8_conditioning           dL/dscaling / dL/drotation only.  K8 maps the nine per-Gaussian 2-D sums of the blend backward to
+                              the 3-D gradients through the conic -> covariance inverse, which amplifies a relative difference
+                              in the sums by the squared aspect ratio of the footprint (tests/test_k8_isolation_gpu.py: 100-850x).
+                              MEASURED per Gaussian here: the float64 truth's sums are perturbed, independently per component,
+                              by the relative distance the FLOAT32 ORACLE'S OWN sums have from them (>= one float32 ulp), and
+                              pushed through the per-Gaussian backward (msgs_backward_per_gaussian, the same K8 + K9 the oracle
+                              restates bit for bit); the exceedance is explained iff every clean Gaussian's HIP-vs-truth error
+                              is within twice the movement that perturbation causes (+ the tolerance): HIP's sums need be no
+                              worse than the float32 reference's — only their errors are not common to the three conic sums.
 Anything else is UNEXPLAINED and fails the test.
 """
 import math
@@ -41,7 +50,7 @@ from parity_utils import FWD_ATOL, PIPE, hip_render, leaf_space, rel_err, small_
 GRAD_TOL = 1e-4
 TRUTH_FACTOR = 1.25
 ILL_CONDITIONED = ("scaling", "rotation")          # the two tensors behind K8's conic -> covariance map
-CLASSES = ("shared_borderline_pixel", "oracle_f32_off_truth", "float32_rounding_mode")
+CLASSES = ("shared_borderline_pixel", "oracle_f32_off_truth", "float32_rounding_mode", "k8_conditioning")
 
 
 def draw_config(rng):
@@ -103,6 +112,60 @@ def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov):
     return out, {k: (inputs[k].grad, ok) for k, ok in names.items()}, okw
 
 
+def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space):
+    """{tensor: per-Gaussian movement [P]} of dL/dscaling / dL/drotation when the truth's nine 2-D sums are perturbed by the
+    float32 oracle's own relative distance from them (independent signs per component; the largest of four draws), through the
+    HIP per-Gaussian backward.  to_compare_space(dict of activated-space gradients) -> {name: tensor} in the space the
+    exceedance was measured in."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    from oracle import oracle_ctypes as oc
+    dev = "cuda"
+    s32 = oc.backward(orc, dL, want_sums2d=True)["sums2d"]
+    s64 = oc.backward(tru, dL, want_sums2d=True)["sums2d"]
+    rel = ((s32 - s64).abs() / s64.abs().clamp_min(1e-300)).clamp(max=1e-4)
+    rel = torch.where(s64 == 0, torch.zeros_like(rel), rel)
+    delta = rel.max(dim=1, keepdim=True).values.clamp_min(2.0 ** -23)            # per Gaussian: its worst component, >= 1 ulp
+    camd = cam.to(dev)
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev), scale_modifier=1.0, viewmatrix=camd.world_view_transform,
+        projmatrix=camd.full_proj_transform, sh_degree=seen.sh_degree, campos=camd.camera_center, prefiltered=False, debug=False, **st)
+    t = lambda x: x.to(dev).contiguous()
+    col = okw.get("colors_precomp")
+    call = dgr._Call(rs, t(seen.means3D), None if col is not None else t(seen.shs), t(col) if col is not None else None,
+                     t(seen.opacities), t(seen.scales), t(seen.rotations), None, t(seen.max_pixel_sizes), t(seen.min_pixel_sizes),
+                     None, None, t(seen.base_mask))
+    with torch.no_grad():
+        _, _, _, radii, _, (geom, _, _, _) = dgr._forward_impl(call)
+    P, K = call.P, call.K
+
+    def per_gaussian(sums):
+        e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        out = dict(means3D=e(P, 3), means2D=e(P, 3), opacities=e(P), scales=e(P, 3), rotations=e(P, 4))
+        out["colors_precomp" if col is not None else "shs"] = e(P, 3) if col is not None else e(P, K, 3)
+        p_ = lambda k: C.c_void_p(out[k].data_ptr()) if k in out else None
+        grads = dgr._C.Grads(p_("means3D"), p_("means2D"), p_("shs"), p_("colors_precomp"), p_("opacities"), p_("scales"),
+                             p_("rotations"), None, None, None, None, 0)
+        sd = sums.to(dev).contiguous()
+        dgr._C.check(dgr._C.lib.msgs_backward_per_gaussian(
+            C.byref(call.view), C.byref(call.g), C.c_void_p(radii.data_ptr()), C.c_void_p(geom.data_ptr()), geom.numel(),
+            C.c_void_p(sd.data_ptr()), C.byref(grads), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "msgs_backward_per_gaussian")
+        torch.cuda.synchronize()
+        return {k: v.cpu() for k, v in out.items()}
+    base = to_compare_space(per_gaussian(s64))
+    amp = {k: torch.zeros(P, dtype=torch.float64) for k in ILL_CONDITIONED}
+    g = torch.Generator().manual_seed(12345)
+    for _ in range(4):
+        sign = torch.where(torch.rand(s64.shape, generator=g) < 0.5, -1.0, 1.0).double()
+        moved = to_compare_space(per_gaussian(s64 * (1.0 + delta * sign)))
+        for k in ILL_CONDITIONED:
+            d = (moved[k].double() - base[k].double()).abs().reshape(P, -1).max(dim=1).values
+            amp[k] = torch.maximum(amp[k], d)
+    return amp
+
+
 def run_config(cfg):
     """-> dict(cfg, status 'pass' | one of CLASSES | 'unexplained', detail, per-tensor distances, pixel / Gaussian flag counts)"""
     import diff_gaussian_rasterization as dgr
@@ -123,11 +186,14 @@ def run_config(cfg):
             out, pc, m2 = hip_render(sc, cam, st, bg, dL)
             seen, okw = pc.seen, {}
             pairs_for = lambda og: {k: (g, ref) for k, (g, ref) in leaf_space(pc, m2, og).items()}
+            # activated-space gradients of the per-Gaussian entry -> the leaf space the exceedances are measured in
+            k8_space = lambda gd: {k: v[1] for k, v in leaf_space(pc, m2, {kk: vv for kk, vv in gd.items()}).items()}
         else:
             use_col, use_cov = cfg["entry"] in ("precomp_col", "precomp_both"), cfg["entry"] in ("precomp_cov", "precomp_both")
             out, grads, okw = _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov)
             seen = sc
             pairs_for = lambda og: {k: (g, og[ok].double()) for k, (g, ok) in grads.items()}
+            k8_space = None if use_cov else (lambda gd: {"scaling": gd["scales"], "rotation": gd["rotations"]})
     finally:
         lib.msgs_set_blend_granularity(pg)
         lib.msgs_set_backward_generation(pb)
@@ -138,6 +204,7 @@ def run_config(cfg):
     fma = oc.rasterize(seen, cam, st, bg, fma=True, **okw)
     og, tg, fg = oc.backward(orc, dL), oc.backward(tru, dL), oc.backward(fma, dL)
 
+    k8_amp = [None]
     res = dict(cfg=cfg, status="pass", detail="", pixels=W * H, borderline_pixels=int(orc.borderline.sum()),
                gaussians=P, tier1=int(orc.borderline_gaussians.sum()), tier2=int(orc.shared_borderline_gaussians.sum()))
     # ---- forward -------------------------------------------------------------------------------------------------------
@@ -208,6 +275,23 @@ def run_config(cfg):
             problems.append(("oracle_f32_off_truth", what))
         elif e["hip_tru"] <= TRUTH_FACTOR * max(e["orc_tru"], e["fma_tru"]) + 1e-6:
             problems.append(("float32_rounding_mode", what))
+        elif k in ILL_CONDITIONED and k8_space is not None:
+            try:
+                if k8_amp[0] is None:
+                    k8_amp[0] = _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, k8_space)
+                got, truth = p_o[k][0].detach().double().cpu(), p_t[k][1].double()
+                scale = max(truth.abs().max().item(), 1e-20)
+                err = (got.reshape(truth.shape) - truth).abs().reshape(P, -1).max(dim=1).values
+                ok_rows = err <= 2.0 * k8_amp[0][k] + GRAD_TOL * scale
+                clean = ~flagged1
+                if bool(ok_rows[clean].all()):
+                    worst_i = int(torch.argmax(torch.where(clean, err, torch.zeros_like(err))))
+                    problems.append(("k8_conditioning", what + f" | worst Gaussian: error {err[worst_i] / scale:.2e}, movement of the "
+                                     f"float32-sized perturbation {k8_amp[0][k][worst_i] / scale:.2e} (of the tensor's max norm)"))
+                else:
+                    problems.append(("unexplained", what + f" | {int((~ok_rows & clean).sum())} Gaussians beyond twice their K8 movement"))
+            except Exception as ex:      # noqa: BLE001 - a failing diagnosis leaves the exceedance unexplained
+                problems.append(("unexplained", what + f" | K8 diagnosis raised {ex!r}"[:200]))
         else:
             problems.append(("unexplained", what))
     res["grad"] = dist
