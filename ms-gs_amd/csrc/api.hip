@@ -251,7 +251,9 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
                                classic ? status_dev : nullptr, classic && polled ? sb.dev : nullptr, ticket,
                                (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
-                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr)));
+                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr),
+                               // the speculative stage 2's queue of heavy Gaussians starts empty (binning.hip)
+                               spec ? (uint32_t*)((char*)spec->scratch2 + Stage2Scratch(spec->capacity).heavy_q) : nullptr));
     tm.end(MSGS_K_SCAN);
     if (!classic) {        // look-back sort / scan variants: watchdog flags join the status in a final tiny kernel
         const SortScratch SSL(P);
@@ -540,8 +542,10 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
         // tile ids (and the sentinel id = number of tiles) below 65536: the emit writes, the tile sort moves and the range
         // search reads 16-bit keys — 6 instead of 8 bytes per pair and pass
         keys16 = num_tiles < 65535 && radix_sort_keys16_ok(D, 0, tile_bits(num_tiles));
+        uint32_t* heavy_q = (uint32_t*)(scratch + SL.heavy_q);
+        if (!D_dev) HIP_TRY(launch_zero(heavy_q, 4, s));     // (a speculative launch had it cleared by stage 1's scan)
         tm.begin(MSGS_K_EMIT);
-        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2, D_dev, keys16));
+        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2, D_dev, keys16, heavy_q));
         tm.end(MSGS_K_EMIT);
         if ((rc = debug_sync(view, s))) return rc;
         tm.begin(MSGS_K_TILE_SORT);

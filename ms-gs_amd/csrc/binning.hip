@@ -10,6 +10,9 @@
 // Both are HBM-streaming: 8 B written per instance (emit), 4 B read per instance (ranges).
 #include "msgs_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace msgs {
 
 namespace {
@@ -27,7 +30,8 @@ namespace {
 template <int EMIT_STAGE, typename KeyT, typename OutT = uint32_t>
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    OutT* __restrict__ keys, uint32_t* __restrict__ ids,
-                                                   int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev) {
+                                                   int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev,
+                                                   uint32_t* __restrict__ heavy_q) {
     // ranks 0 .. V-1 of the depth order are the Gaussians that stayed in the compacting depth sort (GeomLayout::nvalid)
     {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
         const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     // A Gaussian with many instances is emitted by its whole WAVE (below): one thread looping over thousands of tiles while 63
     // lanes wait made the emit 4.3 ms for the 427 M instances of a multi-scale model rendered without its filters
     // (render.py's defaults; 145 k Gaussians wider than 256 px), i.e. 0.8 TB/s of stores.
-    constexpr uint32_t HEAVY_MIN = 96;
+    constexpr uint32_t HEAVY_MIN = EMIT_HEAVY_MIN;
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
     if (count) { q0 = binrec[gi].q0; q1 = binrec[gi].q1; }
     // a Gaussian behind some cut-off with a very large rect walks its tiles with the whole wave as well, however few of them
@@ -87,12 +91,27 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     // whole (the wave path handles ONE Gaussian at a time: a wave of 64 medium footprints took 64 turns, 0.48 ms per view)
     const uint32_t rect_area = ((__float_as_uint(q1.w) & 0xFFFFu) - (__float_as_uint(q1.z) & 0xFFFFu)) *
                                ((__float_as_uint(q1.w) >> 16) - (__float_as_uint(q1.z) >> 16));
-    const bool heavy = count > HEAVY_MIN || (count > 0 && cut_check && rect_area > (uint32_t)OCC_LIGHT_RECT);
+    // In a block that writes straight to HBM the Gaussians with more than HEAVY_MIN instances are not emitted here: their ranks
+    // go into a queue and emit_heavy_kernel gives each a workgroup of its own.  (The nearest ranks of a view that is cut off by a
+    // few opaque covers are ALL such Gaussians: one wave taking 11 of them in turn, 25 us each, was 0.28 ms for 1.4 M instances.)
+    const bool queued = heavy_q != nullptr && !staged && count > HEAVY_MIN;
+    const bool heavy = !queued && (count > HEAVY_MIN || (count > 0 && cut_check && rect_area > (uint32_t)OCC_LIGHT_RECT));
+    {
+        const uint64_t qm = __ballot(queued);
+        if (qm) {
+            const int lane_ = threadIdx.x & 63;
+            uint32_t qbase = 0;
+            if (lane_ == 0) qbase = atomicAdd(heavy_q, (uint32_t)__popcll(qm));
+            qbase = lane_bcast(qbase, 0);
+            const uint32_t qi = qbase + (uint32_t)__popcll(qm & ((1ull << lane_) - 1ull));
+            if (queued && qi < (uint32_t)(D / EMIT_HEAVY_MIN + 64)) heavy_q[1 + qi] = (uint32_t)r;
+        }
+    }
     auto put = [&](int64_t at, uint32_t k, uint32_t g_id, uint32_t owner) {
         if (staged) { s_keys[at - blk_lo] = (KeyT)k; s_own[at - blk_lo] = (uint8_t)owner; }
         else { keys[at] = (OutT)k; ids[at] = g_id; }
     };
-    if (count && !heavy) {
+    if (count && !heavy && !queued) {
         const int64_t end = min((int64_t)off + count, D);
         const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
         const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
@@ -192,6 +211,103 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     }
 }
 
+// One workgroup per queued Gaussian (emit_kernel above): all four waves compute the Gaussian's row extents (lane <-> tile row,
+// 64 rows at a time) and the exclusive scan of the rows' instance counts, so every wave knows where every row starts without
+// talking to the others; wave w then writes the rows r with r % 4 == w, lanes on consecutive tiles.  Behind an occlusion cut-off
+// a row's count is its OPEN tiles (cover block by cover block, from the table in LDS) and the stores are compacted by ballot.
+template <typename OutT>
+__global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, const char* __restrict__ geom,
+                                                         OutT* __restrict__ keys, uint32_t* __restrict__ ids, int64_t D,
+                                                         const uint32_t* __restrict__ D_dev,
+                                                         const uint32_t* __restrict__ heavy_q) {
+    __shared__ OccTable T;
+    // (never more than D / EMIT_HEAVY_MIN + 1 entries: the queued Gaussians start below D and lie more than EMIT_HEAVY_MIN apart)
+    const uint32_t n = min(heavy_q[0], (uint32_t)(D / EMIT_HEAVY_MIN + 64));
+    if (blockIdx.x >= n) return;
+    const GeomLayout L(P);
+    const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
+    const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
+    const uint32_t* skey = reinterpret_cast<const uint32_t*>(geom + L.skey);
+    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
+    const OccHeader* occ = reinterpret_cast<const OccHeader*>(geom + L.occ_hdr);
+    const bool occ_on = occ->enabled != 0u && occ->any_closed != 0u;
+    const int lb = (int)occ->block_log2, nbx = (int)occ->nbx;
+    if (occ_on) occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), nbx, (int)occ->nby);
+    if (D_dev) D = (int64_t)*D_dev;
+    const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t sentinel = (uint32_t)(vp.gx * vp.gy);
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const int r = (int)heavy_q[1 + q];
+        const uint32_t gi = order[r];
+        const int64_t off = offs[r];
+        const int64_t end = min(off + (int64_t)(uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - off), D);
+        const BinRec b = binrec[gi];
+        const uint32_t kb = occ_on ? occ_bucket(skey[r]) : 0u;
+        const bool check = occ_on && kb > T.cut_min;
+        const uint32_t rcx = __float_as_uint(b.q1.z), rcy = __float_as_uint(b.q1.w);
+        const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
+        const float tau2 = b.q1.y;
+        const bool test = tau2 > -1.0e38f;
+        const LevelSetRows ls = test ? levelset_rows_setup(b.q0.z, b.q0.w, b.q1.x, tau2) : LevelSetRows{};
+        int64_t at = off;                                                  // the same in all four waves
+        for (int row0 = miny; row0 < maxy && at < end; row0 += 64) {
+            const int ty = row0 + lane;
+            int tlo = minx, thi = maxx - 1;
+            bool hit = ty < maxy;
+            if (hit && check) hit = T.rowmax[ty >> lb] >= kb;
+            if (hit && test) hit = levelset_row_interval(ls, b.q0.x, b.q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi);
+            int n_row = 0;
+            if (hit && !check) n_row = thi - tlo + 1;
+            else if (hit) {
+                const int brow = (ty >> lb) * nbx;
+                for (int tx = tlo; tx <= thi;) {
+                    const int bend = min(thi, (((tx >> lb) + 1) << lb) - 1);
+                    if (T.cut[brow + (tx >> lb)] >= kb) n_row += bend - tx + 1;
+                    tx = bend + 1;
+                }
+            }
+            int inc = n_row;                                               // row starts: exclusive scan over the lanes
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            const int chunk_total = __shfl(inc, 63);
+            const int excl = inc - n_row;
+            uint64_t rows = __ballot(n_row > 0);
+            while (rows) {
+                const int rr = __ffsll((long long)rows) - 1;
+                rows &= rows - 1;
+                if ((rr & 3) != wv) continue;
+                const int64_t start = at + lane_bcast(excl, rr);
+                const int tlo_r = lane_bcast(tlo, rr), thi_r = lane_bcast(thi, rr);
+                const uint32_t kbase = (uint32_t)((row0 + rr) * vp.gx);
+                if (!check) {
+                    for (int j = lane; tlo_r + j <= thi_r; j += 64) {
+                        const int64_t pos = start + j;
+                        if (pos < end) { keys[pos] = (OutT)(kbase + (uint32_t)(tlo_r + j)); ids[pos] = gi; }
+                    }
+                } else {
+                    const int brow = ((row0 + rr) >> lb) * nbx;
+                    int64_t p = start;
+                    for (int j0 = 0; tlo_r + j0 <= thi_r; j0 += 64) {
+                        const int tx = tlo_r + j0 + lane;
+                        const bool keep = tx <= thi_r && T.cut[brow + (tx >> lb)] >= kb;
+                        const uint64_t km = __ballot(keep);
+                        const int64_t pos = p + __popcll(km & lt);
+                        if (keep && pos < end) { keys[pos] = (OutT)(kbase + (uint32_t)tx); ids[pos] = gi; }
+                        p += __popcll(km);
+                    }
+                }
+            }
+            at += chunk_total;
+        }
+        // count >= emitted (larger margin in the count): the surplus slots go to the sentinel tile
+        for (int64_t a = at + threadIdx.x; a < end; a += 256) { keys[a] = (OutT)sentinel; ids[a] = gi; }
+    }
+}
+
 // four consecutive keys per thread (one 16-byte load); the neighbours across thread boundaries come from the adjacent lanes, across
 // wave boundaries from memory.  (One key per thread with three 4-byte loads ran at 1.5 TB/s: 14 us at C3, 150 us at C5.)
 template <typename KeyT>
@@ -235,23 +351,35 @@ __global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ ke
 }  // namespace
 
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids, int64_t D,
-                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev, bool keys16) {
+                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev, bool keys16, uint32_t* heavy_q) {
     if (P == 0 || D == 0) return hipSuccess;     // (callers fold a ZeroJob in only when D > 0)
     const bool narrow = vp.gx * vp.gy < 65535;        // tile ids and the sentinel (= number of tiles) fit 16 bits
     const dim3 grid((P + 255) / 256), block(256);
     if (keys16 && !narrow) return hipErrorInvalidValue;
+    static const bool no_queue = [] { const char* e = getenv("MSGS_EMIT_NO_QUEUE"); return e && e[0] == '1'; }();
+    if (no_queue) heavy_q = nullptr;
     if (keys16) {
         uint16_t* k16 = reinterpret_cast<uint16_t*>(keys);
         if (D > 8 * (int64_t)P)
-            hipLaunchKernelGGL((emit_kernel<12288, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev);
+            hipLaunchKernelGGL((emit_kernel<12288, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev, heavy_q);
         else
-            hipLaunchKernelGGL((emit_kernel<3072, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev);
+            hipLaunchKernelGGL((emit_kernel<3072, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev, heavy_q);
     } else if (D > 8 * (int64_t)P) {
-        if (narrow) hipLaunchKernelGGL((emit_kernel<12288, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
-        else hipLaunchKernelGGL((emit_kernel<6144, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+        if (narrow) hipLaunchKernelGGL((emit_kernel<12288, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
+        else hipLaunchKernelGGL((emit_kernel<6144, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
     } else {
-        if (narrow) hipLaunchKernelGGL((emit_kernel<3072, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
-        else hipLaunchKernelGGL((emit_kernel<3072, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev);
+        if (narrow) hipLaunchKernelGGL((emit_kernel<3072, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
+        else hipLaunchKernelGGL((emit_kernel<3072, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
+    }
+    if (heavy_q) {
+        // at most D / EMIT_HEAVY_MIN Gaussians can be queued; workgroups beyond the queue's length leave at once
+        const unsigned hb = (unsigned)std::min<int64_t>(2048, D / EMIT_HEAVY_MIN + 1);
+        if (keys16)
+            hipLaunchKernelGGL(emit_heavy_kernel<uint16_t>, dim3(hb), block, 0, s, vp, P, geom, reinterpret_cast<uint16_t*>(keys), ids, D,
+                               D_dev, (const uint32_t*)heavy_q);
+        else
+            hipLaunchKernelGGL(emit_heavy_kernel<uint32_t>, dim3(hb), block, 0, s, vp, P, geom, keys, ids, D, D_dev,
+                               (const uint32_t*)heavy_q);
     }
     return hipGetLastError();
 }

@@ -170,14 +170,20 @@ struct BinningLayout {
     }
 };
 
+// EMIT_HEAVY_MIN: instances from which a Gaussian is emitted cooperatively (by its wave inside emit_kernel, or — in the blocks
+// that write straight to HBM — by a workgroup of emit_heavy_kernel that takes it from the queue)
+constexpr uint32_t EMIT_HEAVY_MIN = 96;
 struct Stage2Scratch {
-    size_t keys_a, ids_a, sort, total;
+    size_t keys_a, ids_a, sort, heavy_q, total;
     __host__ __device__ explicit Stage2Scratch(int64_t D) {
         size_t o = 0;
         int64_t n = D > 0 ? D : 1;
         keys_a = o; o = align256(o + 4 * (size_t)n);
         ids_a = o;  o = align256(o + 4 * (size_t)n);
         sort = o;   o = align256(o + SortScratch(n).total);
+        // queue of the depth ranks whose Gaussian has more than EMIT_HEAVY_MIN instances: word 0 = their number (cleared by
+        // the scan that precedes a speculative stage 2, or by msgs_forward_stage2 itself), then at most n / EMIT_HEAVY_MIN ranks
+        heavy_q = o; o = align256(o + 4 * ((size_t)n / EMIT_HEAVY_MIN + 66));
         total = o;
     }
 };
@@ -459,7 +465,8 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s,
                               uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0,
                               const uint32_t* n_ptr = nullptr, uint32_t* clamped_total = nullptr, uint64_t clamp = 0,
-                              const uint32_t* extra = nullptr);   // extra: two device words forwarded with the status
+                              const uint32_t* extra = nullptr,    // extra: two device words forwarded with the status
+                              uint32_t* zero_word = nullptr);     // zero_word: one device word cleared on behalf of a later launch
 bool use_classic_sort();
 hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
                                  uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);
@@ -472,7 +479,9 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and b
 // keys16: the key arrays hold uint16 tile ids (grids of fewer than 65535 tiles)
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0}, const uint32_t* D_dev = nullptr,
-                       bool keys16 = false);
+                       bool keys16 = false, uint32_t* heavy_q = nullptr);
+// heavy_q (Stage2Scratch::heavy_q; word 0 must be zero when the launch starts): Gaussians with more than EMIT_HEAVY_MIN
+// instances in blocks that write straight to HBM are queued and emitted by a second launch, one workgroup per Gaussian
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
                          bool pre_zeroed = false, const uint32_t* D_dev = nullptr, bool keys16 = false);
 int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value

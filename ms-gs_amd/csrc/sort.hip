@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
                                                             volatile uint64_t* host = nullptr, uint64_t ticket = 0,
                                                             uint32_t* __restrict__ clamped_total = nullptr,
                                                             uint64_t clamp = 0,
-                                                            const uint32_t* __restrict__ extra = nullptr) {
+                                                            const uint32_t* __restrict__ extra = nullptr,
+                                                            uint32_t* __restrict__ zero_word = nullptr) {
     __shared__ uint64_t s_w[4];
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict
         if (clamped_total) *clamped_total = (uint32_t)(s_carry < clamp ? s_carry : clamp);   // speculative stage 2's D
         // `extra`: two device words that travel with the count (the occlusion pass's {candidates, any block closed})
         const uint64_t info = extra ? ((uint64_t)extra[0] | ((uint64_t)extra[1] << 32)) : 0ull;
+        if (zero_word) *zero_word = 0u;
         if (status) { status[0] = s_carry; status[1] = 0; status[2] = info; }
         if (host) {
             host[0] = s_carry;
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_fused_kernel(const ui
                                                                         uint64_t* __restrict__ status,
                                                                         volatile uint64_t* host, uint64_t ticket,
                                                                         uint32_t* __restrict__ clamped_total, uint64_t clamp,
-                                                                        const uint32_t* __restrict__ extra) {
+                                                                        const uint32_t* __restrict__ extra,
+                                                                        uint32_t* __restrict__ zero_word) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_sum[4];
     if (n_ptr) n = (int64_t)*n_ptr;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_fused_kernel(const ui
         base = 0;
         if (threadIdx.x == 0) {
             if (total_out) *total_out = sum;
+            if (zero_word) *zero_word = 0u;
             if (clamped_total) *clamped_total = (uint32_t)(sum < clamp ? sum : clamp);
             const uint64_t info = extra ? ((uint64_t)extra[0] | ((uint64_t)extra[1] << 32)) : 0ull;
             if (status) { status[0] = sum; status[1] = 0; status[2] = info; }
@@ -728,11 +732,11 @@ hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
                               uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr, uint32_t* clamped_total,
-                              uint64_t clamp, const uint32_t* extra) {
+                              uint64_t clamp, const uint32_t* extra, uint32_t* zero_word) {
     const int64_t nb = scan_blocks(n > 0 ? n : 1);
     if (n <= 0) {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total, status,
-                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
+                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word);
         return hipGetLastError();
     }
     if (!use_classic_sort()) {
@@ -753,11 +757,11 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     if (!three && (stage || gather == nullptr)) {
         hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s,
                            stage ? (const uint32_t*)out : in, out, n, (const uint64_t*)partials, nb, n_ptr, total, status,
-                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
+                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
-                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra);
+                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
                        stage ? (const uint32_t*)nullptr : gather, out, n, partials, n_ptr);
     return hipGetLastError();
