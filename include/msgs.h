@@ -74,10 +74,11 @@ typedef struct msgs_view {
     int32_t filter_large;     /* bool */
     int32_t prefiltered;      /* bool (accepted; the reference always passes False)                  */
     int32_t debug;            /* bool: synchronise + return the first HIP error after every stage   */
-    int32_t skip_occlusion;   /* bool (not a reference field): this call renders without the occlusion cut-off pass even when
-                               * msgs_set_occlusion is on — same outputs, only the instance count differs; a caller that
-                               * renders similar views in a loop skips the pass (three small launches) while msgs_forward_info
-                               * says it found nothing to cut, and re-probes now and then                                  */
+    int32_t skip_occlusion;   /* bool (not a reference field): "an ordinary view" — this call renders without the occlusion
+                               * cut-off pass (four small launches) even when msgs_set_occlusion is on, and without the queue
+                               * for Gaussians with many instances (one launch): same outputs, only the instance count may
+                               * differ; a caller that renders similar views in a loop sets it while msgs_forward_info says
+                               * the pass found nothing to cut, and re-probes now and then                                  */
     int32_t reserved0;        /* 0 */
     const float* bg;          /* [3]   device                                                        */
     const float* viewmatrix;  /* [16]  device; world_view_transform = W2C^T row-major (cameras.py:54) */

@@ -542,8 +542,11 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
         // tile ids (and the sentinel id = number of tiles) below 65536: the emit writes, the tile sort moves and the range
         // search reads 16-bit keys — 6 instead of 8 bytes per pair and pass
         keys16 = num_tiles < 65535 && radix_sort_keys16_ok(D, 0, tile_bits(num_tiles));
-        uint32_t* heavy_q = (uint32_t*)(scratch + SL.heavy_q);
-        if (!D_dev) HIP_TRY(launch_zero(heavy_q, 4, s));     // (a speculative launch had it cleared by stage 1's scan)
+        // the queue of heavy Gaussians (binning.hip: one more launch) — not on a view the caller marked as ordinary
+        // (msgs_view_t.skip_occlusion: no covers worth a pass, hence no crowd of giants in the first ranks either; the few
+        // Gaussians with many instances are then emitted by their wave inside emit_kernel, as before round 5)
+        uint32_t* heavy_q = view->skip_occlusion ? nullptr : (uint32_t*)(scratch + SL.heavy_q);
+        if (heavy_q && !D_dev) HIP_TRY(launch_zero(heavy_q, 4, s));     // (a speculative launch had it cleared by stage 1's scan)
         tm.begin(MSGS_K_EMIT);
         HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2, D_dev, keys16, heavy_q));
         tm.end(MSGS_K_EMIT);
