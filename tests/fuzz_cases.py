@@ -12,7 +12,8 @@ oracle on the same inputs:
                                the real CUDA reference (oracle/liboracle_fma.so)
 
 Criterion (north star: forward <= 1e-5 abs, gradients <= 1e-4 rel on identical inputs; BASELINE.json):
-    forward   <= 1e-5 on the pixels no oracle flags borderline, <= 2/255 on those;
+    forward   <= 1e-5 on the pixels no oracle flags borderline, <= 2/255 on those; the two auxiliary buffers (depth,
+              acc_pixel_size: sums of value x weight with values of 1 ... 30) <= 1e-5 x their value range;
     gradients <= 1e-4 (max-norm relative per tensor, against the float32 oracle) on means3D / SH (or colours) / opacity /
               means2D (and dL/dcov3D of the precomputed-covariance entry);
               dL/dscaling, dL/drotation — the end of K8's ill-conditioned conic -> covariance chain — <= 1e-4 against the
@@ -28,7 +29,8 @@ evidence the oracles produce (never from the kernel variant or the seed):
     float32_rounding_mode     HIP is no farther from the truth than 1.25 x the farther of the two float32 reference builds
                               (contraction off / on) + 1e-6: inside the spread of the reference algorithm's own legal float32
                               evaluations;
-    k8_conditioning           dL/dscaling / dL/drotation only.  K8 maps the nine per-Gaussian 2-D sums of the blend backward to
+    k8_conditioning           dL/dscaling / dL/drotation, and dL/dmeans3D (which takes one term through the same map: the
+                              projection Jacobian's dependence on the view-space position) only.  K8 maps the nine per-Gaussian 2-D sums of the blend backward to
                               the 3-D gradients through the conic -> covariance inverse, which amplifies a relative difference
                               in the sums by the squared aspect ratio of the footprint (tests/test_k8_isolation_gpu.py: 100-850x).
                               MEASURED per Gaussian here: the float64 truth's sums are perturbed, independently per component,
@@ -50,6 +52,7 @@ from parity_utils import FWD_ATOL, PIPE, hip_render, leaf_space, rel_err, small_
 GRAD_TOL = 1e-4
 TRUTH_FACTOR = 1.25
 ILL_CONDITIONED = ("scaling", "rotation")          # the two tensors behind K8's conic -> covariance map
+K8_DOWNSTREAM = ILL_CONDITIONED + ("means3D",)     # dL/dmeans3D also takes a term through it (the Jacobian's dependence on t)
 CLASSES = ("shared_borderline_pixel", "oracle_f32_off_truth", "float32_rounding_mode", "k8_conditioning")
 
 
@@ -155,12 +158,12 @@ def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space):
         torch.cuda.synchronize()
         return {k: v.cpu() for k, v in out.items()}
     base = to_compare_space(per_gaussian(s64))
-    amp = {k: torch.zeros(P, dtype=torch.float64) for k in ILL_CONDITIONED}
+    amp = {k: torch.zeros(P, dtype=torch.float64) for k in K8_DOWNSTREAM if k in base}
     g = torch.Generator().manual_seed(12345)
     for _ in range(4):
         sign = torch.where(torch.rand(s64.shape, generator=g) < 0.5, -1.0, 1.0).double()
         moved = to_compare_space(per_gaussian(s64 * (1.0 + delta * sign)))
-        for k in ILL_CONDITIONED:
+        for k in amp:
             d = (moved[k].double() - base[k].double()).abs().reshape(P, -1).max(dim=1).values
             amp[k] = torch.maximum(amp[k], d)
     return amp
@@ -193,7 +196,7 @@ def run_config(cfg):
             out, grads, okw = _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov)
             seen = sc
             pairs_for = lambda og: {k: (g, og[ok].double()) for k, (g, ok) in grads.items()}
-            k8_space = None if use_cov else (lambda gd: {"scaling": gd["scales"], "rotation": gd["rotations"]})
+            k8_space = None if use_cov else (lambda gd: {"scaling": gd["scales"], "rotation": gd["rotations"], "means3D": gd["means3D"]})
     finally:
         lib.msgs_set_blend_granularity(pg)
         lib.msgs_set_backward_generation(pb)
@@ -216,21 +219,36 @@ def run_config(cfg):
     problems = []
     if d.max().item() > 2.0 / 255.0 + 1e-5:
         problems.append(("forward_borderline", f"a borderline pixel is off by {d.max().item():.3e}"))
+    ok_fma = okpx & ~fma.borderline.bool()
+
+    def three_way(what, got, tol, o32, o64, ofma):
+        """an exceedance of a forward output against the float32 checker: where does HIP sit relative to the float64 truth and
+        to the reference algorithm's two float32 builds (the same classes as for the gradients)"""
+        sel = (lambda x, m: x[:, m]) if got.dim() == 3 else (lambda x, m: x[m])
+        mx = lambda x: x.max().item() if x.numel() else 0.0
+        e_hip = mx(sel((got.double() - o64.double()).abs(), okpx))
+        e_orc = mx(sel((o32.double() - o64.double()).abs(), okpx))
+        e_fma = mx(sel((ofma.double() - o64.double()).abs(), ok_fma))
+        msg = f"{what} vs truth HIP {e_hip:.2e} oracle {e_orc:.2e} fma {e_fma:.2e} (tolerance {tol:.2e})"
+        if e_hip <= max(tol, TRUTH_FACTOR * e_orc + 1e-6):
+            return ("oracle_f32_off_truth", msg)
+        if e_hip <= TRUTH_FACTOR * max(e_orc, e_fma) + 1e-6:
+            return ("float32_rounding_mode", msg)
+        return ("unexplained", msg)
+
     if strict > FWD_ATOL:
-        e_hip = (col.double() - tru.color).abs()[:, okpx].max().item()
-        e_orc = (orc.color.double() - tru.color).abs()[:, okpx].max().item()
-        e_fma = (fma.color.double() - tru.color).abs()[:, okpx & ~fma.borderline.bool()].max().item()
-        if e_hip <= max(FWD_ATOL, TRUTH_FACTOR * e_orc + 1e-6):
-            problems.append(("oracle_f32_off_truth", f"forward {strict:.2e} vs oracle; vs truth HIP {e_hip:.2e} oracle {e_orc:.2e}"))
-        elif e_hip <= TRUTH_FACTOR * max(e_orc, e_fma) + 1e-6:
-            problems.append(("float32_rounding_mode", f"forward vs truth HIP {e_hip:.2e} oracle {e_orc:.2e} fma {e_fma:.2e}"))
-        else:
-            problems.append(("unexplained", f"forward {strict:.2e} vs oracle; vs truth HIP {e_hip:.2e} oracle {e_orc:.2e} fma {e_fma:.2e}"))
-    for key, ref in (("acc_pixel_size", orc.acc_pixel_size), ("depth", orc.depth)):
-        dd = (out[key].detach().cpu() - ref).abs()
+        problems.append(three_way(f"forward {strict:.2e} vs oracle;", col, FWD_ATOL, orc.color, tru.color, fma.color))
+    # acc_pixel_size / depth are sums of (value x weight) with values of 1 ... 30: the tolerance scales with the value range,
+    # and an exceedance is classified three ways like the colour's (the two float32 builds of the reference algorithm
+    # themselves differ by more than 1e-5 x range on about one configuration in 3000: profiles/r5_parity.md)
+    for key in ("acc_pixel_size", "depth"):
+        ref = getattr(orc, key)
+        got = out[key].detach().cpu()
+        dd = (got - ref).abs()
         m = dd[okpx].max().item() if okpx.any() else 0.0
-        if m > FWD_ATOL * max(ref.abs().max().item(), 1.0):
-            problems.append(("unexplained", f"{key} off by {m:.3e}"))
+        tol = FWD_ATOL * max(ref.abs().max().item(), 1.0)
+        if m > tol:
+            problems.append(three_way(f"{key} {m:.2e} vs oracle;", got, tol, ref, getattr(tru, key), getattr(fma, key)))
     got_r = out["radii"].cpu()
     edge = orc.filter_edge
     if not torch.equal(got_r[~edge], orc.radii[~edge]) or \
@@ -275,7 +293,7 @@ def run_config(cfg):
             problems.append(("oracle_f32_off_truth", what))
         elif e["hip_tru"] <= TRUTH_FACTOR * max(e["orc_tru"], e["fma_tru"]) + 1e-6:
             problems.append(("float32_rounding_mode", what))
-        elif k in ILL_CONDITIONED and k8_space is not None:
+        elif k in K8_DOWNSTREAM and k8_space is not None:
             try:
                 if k8_amp[0] is None:
                     k8_amp[0] = _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, k8_space)

@@ -194,6 +194,33 @@ def test_covers_at_the_skip_threshold_and_partial_covers():
         _assert_identical(on, off, ("threshold covers", k))
 
 
+def test_a_view_that_really_closes_blocks_matches_the_oracle():
+    """the bit-identity tests compare the library with itself; here a giants scene whose blocks do close is compared with the CPU
+    oracle directly (forward <= 1e-5 off the flagged pixels, gradients <= 1e-4 on the unflagged Gaussians) with the pass forced on"""
+    import diff_gaussian_rasterization as dgr
+    from oracle import oracle_ctypes as oc
+    from parity_utils import check_backward, check_forward, hip_render
+    W, H = 420, 300
+    sc = _giants_scene(2500, W, H, 5, 60, giant_scale=1.2, giant_opacity=0.9)
+    cam = scenes.front_camera(W, H)
+    bg = torch.tensor([0.2, 0.5, 0.1])
+    dL = scenes.grad_seed(W, H, 5)
+    prev_policy, dgr.occlusion_policy = dgr.occlusion_policy, "always"
+    prev = dgr._C.lib.msgs_set_occlusion(1)
+    try:
+        dgr._last_instances.clear()
+        out, pc, m2 = hip_render(sc, cam, PLAIN, bg, dL)
+        stats = _stats(out["render"].grad_fn)
+    finally:
+        dgr._C.lib.msgs_set_occlusion(prev)
+        dgr.occlusion_policy = prev_policy
+    assert stats["ran"] and stats["closed_blocks"] > 0, stats
+    orc = oc.rasterize(pc.seen, cam, PLAIN, bg)
+    og = oc.backward(orc, dL)
+    check_forward(out, orc, "occlusion-closing")
+    check_backward(pc, m2, og, "occlusion-closing", flagged=orc.borderline_gaussians)
+
+
 def test_pyramid_levels_and_filters_on_are_unchanged():
     """the training path (filters on, fade 0) at three pyramid levels of the C3 scene, and the switch really switches"""
     import diff_gaussian_rasterization as dgr

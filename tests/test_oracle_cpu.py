@@ -127,6 +127,30 @@ def test_c_oracle_matches_autograd(variant):
              cov=variant == "cov", col=variant == "col")
 
 
+def test_fma_build_of_the_c_oracle_is_the_same_algorithm_under_the_other_rounding():
+    """liboracle_fma.so (the float32 source with FMA contraction; never the checker) differs from liboracle.so by float32
+    rounding only: same radii, forward within 1e-5 off the flagged pixels, gradients within 1e-3 on the unflagged Gaussians,
+    and it is NOT the same binary (some gradient differs in its last bits)."""
+    W, H = 72, 48
+    cam = scenes.front_camera(W, H)
+    sc = scenes.frustum_scene(600, W, H, seed=11, scale_k=_k(W))
+    bg = torch.tensor([0.1, 0.3, 0.6])
+    dL = scenes.grad_seed(W, H, 11) * W * H
+    a = oc.rasterize(sc, cam, ST0, bg)
+    b = oc.rasterize(sc, cam, ST0, bg, fma=True)
+    assert torch.equal(a.radii, b.radii)
+    ok = ~(a.borderline.bool() | b.borderline.bool())
+    assert (a.color - b.color).abs()[:, ok].max().item() < 1e-5
+    ga, gb = oc.backward(a, dL), oc.backward(b, dL)
+    clean = ~(a.shared_borderline_gaussians | b.shared_borderline_gaussians | a.borderline_gaussians | b.borderline_gaussians)
+    differs = False
+    for k in ga:
+        x, y = ga[k].reshape(sc.P, -1)[clean], gb[k].reshape(sc.P, -1)[clean]
+        assert (x - y).abs().max().item() <= 1e-3 * x.abs().max().item() + 1e-12, k
+        differs |= not torch.equal(x, y)
+    assert differs
+
+
 # ------------------------------------------------------- float64 build of the C++ oracle vs the autograd oracle ---
 @pytest.mark.parametrize("case", ["frustum", "multiscale", "clamped", "ring", "cov", "col", "sh1"])
 def test_float64_build_of_the_c_oracle_equals_the_autograd_oracle(case):
