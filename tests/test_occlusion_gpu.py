@@ -221,6 +221,58 @@ def test_a_view_that_really_closes_blocks_matches_the_oracle():
     check_backward(pc, m2, og, "occlusion-closing", flagged=orc.borderline_gaussians)
 
 
+def test_two_views_in_flight_on_a_scene_that_closes_blocks():
+    """the deferred forward (msgs_forward_launch / _finish on two streams, host/multi_view.py) with the pass on, on views whose
+    blocks close: bit-identical to the serial loop with the pass OFF — outputs, per-view means2D gradients, accumulated leaves"""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render
+    from multi_view import ViewPipeline
+    from synthetic_model import SyntheticGaussians
+    W, H = 480, 320
+    sc = _giants_scene(4000, W, H, 9, 80, giant_scale=1.0, giant_opacity=0.95)
+    cams = [scenes.front_camera(W, H).to("cuda") for _ in range(4)]
+    dLs = [scenes.grad_seed(W, H, 20 + v).cuda() for v in range(4)]
+    bg = torch.tensor([0.4, 0.1, 0.2], device="cuda")
+    prev_policy = dgr.occlusion_policy
+    try:
+        dgr.occlusion_policy = "always"
+        prev = dgr._C.lib.msgs_set_occlusion(0)
+        dgr._last_instances.clear()
+        ref_pc = SyntheticGaussians(sc, "cuda")
+        ref, ref_m2 = [], []
+        for cam, dL in zip(cams, dLs):
+            o = render(cam, ref_pc, PIPE, bg, **PLAIN)
+            o["render"].backward(dL)
+            ref.append(o)
+            ref_m2.append(o["viewspace_points"].grad.clone())
+        torch.cuda.synchronize()
+        D_off = ref[0]["render"].grad_fn.state[3]
+        dgr._C.lib.msgs_set_occlusion(1)
+        for attempt in range(2):                  # no guess yet / speculative stage 2 from the cut count
+            if attempt == 0:
+                dgr._last_instances.clear()
+            pc = SyntheticGaussians(sc, "cuda")
+            kept = []
+
+            def bwd(i, pkg):
+                pkg["render"].backward(dLs[i])
+                kept.append(pkg)
+                return pkg["viewspace_points"]
+            vs = ViewPipeline("cuda", n_streams=2).train_views(cams, pc, PIPE, bg, bwd, **PLAIN)
+            torch.cuda.synchronize()
+            for i, (o, r) in enumerate(zip(kept, ref)):
+                for k in OUT_KEYS:
+                    assert torch.equal(o[k], r[k]), (attempt, i, k)
+                assert torch.equal(vs[i].grad, ref_m2[i]), (attempt, i)
+            for n in LEAVES:
+                assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad), (attempt, n)
+            state = getattr(kept[0]["render"].grad_fn, "state", None)
+            assert state is not None and state[3] < D_off, (state and state[3], D_off)
+    finally:
+        dgr._C.lib.msgs_set_occlusion(prev)
+        dgr.occlusion_policy = prev_policy
+
+
 def test_pyramid_levels_and_filters_on_are_unchanged():
     """the training path (filters on, fade 0) at three pyramid levels of the C3 scene, and the switch really switches"""
     import diff_gaussian_rasterization as dgr
