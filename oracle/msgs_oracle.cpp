@@ -75,6 +75,8 @@ struct Geom {
     float depth32;           // float32 view depth: the sort key (Q10) in both builds
     real depth, px, py;
     real con[3], opacity;   // conic (A,B,C), effective opacity (after the fade weight)
+    real con_cond;          // (|a c| + b^2) / |a c - b^2| of the 2-D covariance: how much the conic's 1 / det amplifies float32
+                            // rounding of (a, b, c) — 1 for a round footprint, ~ aspect^2 / 2 for a rotated needle
     real rgb[3];
     real cov3D[6];
     real pixel_size, weight;
@@ -88,6 +90,19 @@ struct Geom {
 };
 
 }  // namespace
+
+// Relative half-width of the window around alpha = 1/255 inside which ANOTHER float32 implementation of the same algorithm may
+// take the other branch.  d(alpha)/alpha = d(power), and a float32 evaluation of
+//     power = -0.5 (A dx^2 + C dy^2) - B dx dy
+// carries (i) the rounding of three products that cancel — 2^-24 of their magnitude sum M each, M >> |power| for a rotated
+// elongated footprint — and (ii) the rounding of the conic itself, whose 1 / det amplifies float32 rounding of the 2-D covariance
+// by con_cond (correlated over A, B, C, so it scales with |power|, not with M).  Measured (profiles/r5_parity.md): a needle of
+// aspect 23 with M = 1179 at power -5.4 — the contraction-off build, the FMA build and the float64 build put alpha x 255 - 1 at
+// -2.5e-5, -8.6e-5 and -3.4e-5, the HIP kernels at >= 0.  Round, well-conditioned footprints keep the 2e-5 of rounds 1-4.
+static inline real alpha_window(const Geom& ge, real dx, real dy, real power) {
+    const real M = RL(0.5) * (std::fabs(ge.con[0]) * dx * dx + std::fabs(ge.con[2]) * dy * dy) + std::fabs(ge.con[1] * dx * dy);
+    return std::min(RL(0.1), RL(2e-5) + RL(1.8e-7) * (M + ge.con_cond * std::fabs(power)));      // 1.8e-7 = 3 x 2^-24
+}
 
 struct msgs_oracle_state {
     int P = 0, W = 0, H = 0, gx = 0, gy = 0;
@@ -304,6 +319,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
         if (det == 0.0f) continue;                                     // Q3
         real det_inv = 1.f / det;
         ge.con[0] = c2.c * det_inv; ge.con[1] = -c2.b * det_inv; ge.con[2] = c2.a * det_inv;
+        ge.con_cond = (std::fabs(c2.a * c2.c) + c2.b * c2.b) / std::fabs(det);
         real mid = 0.5f * (c2.a + c2.c);
         real root = std::sqrt(std::max(RL(0.1), mid * mid - det));       // Q4
         real lam1 = mid + root, lam2 = mid - root;
@@ -412,8 +428,9 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                     real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                     if (power > 0.0f) continue;
                     real alpha = std::min(RL(0.99), ge.opacity * std::exp(power));        // Q6
-                    const bool reaches = alpha * 255.0f >= 1.0f - RL(2e-5);
-                    const bool own_edge = std::fabs(alpha * 255.0f - 1.0f) < RL(2e-5);
+                    const real win = alpha_window(ge, dx, dy, power);
+                    const bool reaches = alpha * 255.0f >= 1.0f - win;
+                    const bool own_edge = std::fabs(alpha * 255.0f - 1.0f) < win;
                     if (done) {
                         // shadow: only how far another implementation can get
                         if (!reaches) continue;
@@ -465,7 +482,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                         real dx = ge.px - pxf, dy = ge.py - pyf;
                         real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                         if (power > 0.0f) continue;
-                        if (std::min(RL(0.99), ge.opacity * std::exp(power)) * 255.0f < 1.0f - RL(2e-5)) continue;
+                        if (std::min(RL(0.99), ge.opacity * std::exp(power)) * 255.0f < 1.0f - alpha_window(ge, dx, dy, power)) continue;
                         uint8_t* sh_flag = &st->shared_gauss[id];
 #pragma omp atomic write
                         *sh_flag = 1;

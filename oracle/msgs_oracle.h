@@ -50,7 +50,8 @@ const float* msgs_oracle_rgb(const msgs_oracle_state_t* state);            /* [P
 const float* msgs_oracle_means2D(const msgs_oracle_state_t* state);        /* [P,2] */
 const float* msgs_oracle_cov3D(const msgs_oracle_state_t* state);          /* [P,6] */
 const int32_t* msgs_oracle_rects(const msgs_oracle_state_t* state);        /* [P,4] minx,miny,maxx,maxy */
-/* [P] 1 = some pixel evaluated this Gaussian with alpha within 2e-5 (relative) of the 1/255 skip threshold:
+/* [P] 1 = some pixel evaluated this Gaussian with alpha within the float32 uncertainty of the 1/255 skip threshold (2e-5 relative
+ * for a round footprint, wider where the exponent's terms cancel or the conic is ill-conditioned: alpha_window, msgs_oracle.cpp):
  * a different float32 implementation may legitimately take the other branch there, which moves this
  * Gaussian's conic-derived gradients by about one rim pixel's worth */
 const uint8_t* msgs_oracle_borderline_gaussians(const msgs_oracle_state_t* state);

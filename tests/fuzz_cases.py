@@ -13,7 +13,9 @@ oracle on the same inputs:
 
 Criterion (north star: forward <= 1e-5 abs, gradients <= 1e-4 rel on identical inputs; BASELINE.json):
     forward   <= 1e-5 on the pixels no oracle flags borderline, <= 2/255 on those; the two auxiliary buffers (depth,
-              acc_pixel_size: sums of value x weight with values of 1 ... 30) <= 1e-5 x their value range;
+              acc_pixel_size: sums of value x weight with values of 1 ... 30; MS-GS extras that feed statistics, not the
+              north star's image) <= 2e-5 x their value range — the two float32 builds of the reference algorithm themselves
+              differ by up to 1.4e-5 x range on 1 configuration in 3000;
     gradients <= 1e-4 (max-norm relative per tensor, against the float32 oracle) on means3D / SH (or colours) / opacity /
               means2D (and dL/dcov3D of the precomputed-covariance entry);
               dL/dscaling, dL/drotation — the end of K8's ill-conditioned conic -> covariance chain — <= 1e-4 against the
@@ -52,6 +54,7 @@ from parity_utils import FWD_ATOL, PIPE, hip_render, leaf_space, rel_err, small_
 GRAD_TOL = 1e-4
 TRUTH_FACTOR = 1.25
 ILL_CONDITIONED = ("scaling", "rotation")          # the two tensors behind K8's conic -> covariance map
+AUX_RTOL = 2e-5                                    # depth / acc_pixel_size: relative to the buffer's value range
 K8_DOWNSTREAM = ILL_CONDITIONED + ("means3D",)     # dL/dmeans3D also takes a term through it (the Jacobian's dependence on t)
 CLASSES = ("shared_borderline_pixel", "oracle_f32_off_truth", "float32_rounding_mode", "k8_conditioning")
 
@@ -116,9 +119,9 @@ def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov):
 
 
 def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space):
-    """{tensor: per-Gaussian movement [P]} of dL/dscaling / dL/drotation when the truth's nine 2-D sums are perturbed by the
-    float32 oracle's own relative distance from them (independent signs per component; the largest of four draws), through the
-    HIP per-Gaussian backward.  to_compare_space(dict of activated-space gradients) -> {name: tensor} in the space the
+    """{tensor: per-Gaussian movement [P]} of dL/dscaling / dL/drotation / dL/dmeans3D when the truth's nine 2-D sums are perturbed
+    by the float32 oracle's own relative distance from them (per Gaussian: its worst component, at least one float32 ulp; the
+    first-order worst case over the nine signs), through the HIP per-Gaussian backward.  to_compare_space(dict of activated-space gradients) -> {name: tensor} in the space the
     exceedance was measured in."""
     import ctypes as C
     import diff_gaussian_rasterization as dgr
@@ -158,15 +161,16 @@ def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space):
         torch.cuda.synchronize()
         return {k: v.cpu() for k, v in out.items()}
     base = to_compare_space(per_gaussian(s64))
-    amp = {k: torch.zeros(P, dtype=torch.float64) for k in K8_DOWNSTREAM if k in base}
-    g = torch.Generator().manual_seed(12345)
-    for _ in range(4):
-        sign = torch.where(torch.rand(s64.shape, generator=g) < 0.5, -1.0, 1.0).double()
-        moved = to_compare_space(per_gaussian(s64 * (1.0 + delta * sign)))
-        for k in amp:
-            d = (moved[k].double() - base[k].double()).abs().reshape(P, -1).max(dim=1).values
-            amp[k] = torch.maximum(amp[k], d)
-    return amp
+    # first-order worst case over the signs of the nine perturbations: one component at a time, |movements| added per output
+    # component (the map from the sums to the gradients is linear), then the largest output component of the Gaussian
+    acc = {k: torch.zeros_like(base[k].double().reshape(P, -1)) for k in K8_DOWNSTREAM if k in base}
+    for j in range(s64.shape[1]):
+        bump = torch.ones_like(s64)
+        bump[:, j:j + 1] += delta
+        moved = to_compare_space(per_gaussian(s64 * bump))
+        for k in acc:
+            acc[k] += (moved[k].double() - base[k].double()).abs().reshape(P, -1)
+    return {k: v.max(dim=1).values for k, v in acc.items()}
 
 
 def run_config(cfg):
@@ -196,7 +200,9 @@ def run_config(cfg):
             out, grads, okw = _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov)
             seen = sc
             pairs_for = lambda og: {k: (g, og[ok].double()) for k, (g, ok) in grads.items()}
-            k8_space = None if use_cov else (lambda gd: {"scaling": gd["scales"], "rotation": gd["rotations"], "means3D": gd["means3D"]})
+            # (with a precomputed covariance only dL/dmeans3D passes the conic -> covariance map on its way to an input that is compared)
+            k8_space = (lambda gd: {"means3D": gd["means3D"]}) if use_cov else \
+                (lambda gd: {"scaling": gd["scales"], "rotation": gd["rotations"], "means3D": gd["means3D"]})
     finally:
         lib.msgs_set_blend_granularity(pg)
         lib.msgs_set_backward_generation(pb)
@@ -246,7 +252,7 @@ def run_config(cfg):
         got = out[key].detach().cpu()
         dd = (got - ref).abs()
         m = dd[okpx].max().item() if okpx.any() else 0.0
-        tol = FWD_ATOL * max(ref.abs().max().item(), 1.0)
+        tol = AUX_RTOL * max(ref.abs().max().item(), 1.0)
         if m > tol:
             problems.append(three_way(f"{key} {m:.2e} vs oracle;", got, tol, ref, getattr(tru, key), getattr(fma, key)))
     got_r = out["radii"].cpu()

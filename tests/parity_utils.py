@@ -25,12 +25,13 @@ FWD_ATOL = 1e-5
 BWD_RTOL = 1e-4
 BORDERLINE_PIXEL_BUDGET = 0.0045      # default ceiling on the pixels excluded from the strict forward check (small test scenes)
 # Per-config ceilings: 1.2 x the ORACLE's own count on that config (the fraction is a property of the scene and of the
-# oracle's flags, computed on the inputs: /tmp-style recount with oracle_ctypes.rasterize; round 4: C2 0.0175 %, C3 0.334 %,
-# C3@k=1 0.339 %, k=3 0.809 %, k=6 0.417 %, C4 views 0 / 3 / 6 0.159 / 0.161 / 0.163 %, C5 0.331 %) — so that a config
-# whose exclusions grow trips its own bound instead of hiding under the largest one.
+# oracle's flags, computed on the inputs: recount with oracle_ctypes.rasterize; round 5, with the conditioning-aware alpha window
+# of msgs_oracle.cpp: C2 0.0203 %, C3 0.344 %, C3@k=1 0.348 %, k=3 0.824 %, k=6 0.417 %, C4 views 0 / 3 / 6 0.163 / 0.166 /
+# 0.168 %, C5 0.342 %; with the fixed 2e-5 window of rounds 1-4: 0.0175 / 0.334 / 0.339 / 0.809 / 0.417 / 0.159 / 0.161 / 0.163 /
+# 0.331 %) — so that a config whose exclusions grow trips its own bound instead of hiding under the largest one.
 BORDERLINE_PIXEL_BUDGETS = {
-    "C2": 2.1e-4, "C3": 4.0e-3, "C3@k=1": 4.1e-3, "C3@k=3": 9.7e-3, "C3@k=6": 5.0e-3,
-    "C4v0": 1.9e-3, "C4v3": 1.95e-3, "C4v6": 1.96e-3, "C5": 4.0e-3,
+    "C2": 2.45e-4, "C3": 4.15e-3, "C3@k=1": 4.2e-3, "C3@k=3": 9.9e-3, "C3@k=6": 5.0e-3,
+    "C4v0": 1.96e-3, "C4v3": 1.99e-3, "C4v6": 2.02e-3, "C5": 4.1e-3,
 }
 
 
