@@ -328,7 +328,7 @@ int msgs_set_forward_variant(int32_t variant);
  * shrinks (the multi-scale model rendered without its filters, /root/reference/render.py:32: 427 M -> a few million at
  * 1080p).  msgs_set_occlusion returns the previous value.
  * msgs_occlusion_stats reads what the pass did for the forward that last wrote `geom`: out_host[8] = {ran (0 / 1), Gaussians
- * with more than 96 tile instances, cover candidates sampled from them (at most 16 384), cover blocks that received a cut-off,
+ * with more than 96 tile instances, cover candidates kept from them (the nearest by depth, at most 32 768), cover blocks that received a cut-off,
  * cover blocks of the view, tiles per side of a cover block, smallest and largest cut-off (float32 bits of a view depth;
  * 0xFFFFFFFF = a block stayed open)}.  (The instances removed = the instance count of the same view with the pass switched
  * off minus the one with it on.)  Synchronises `stream`; not re-entrant (a diagnostic). */

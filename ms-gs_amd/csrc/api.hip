@@ -220,7 +220,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     uint32_t* heavy_count = occlusion ? (uint32_t*)(scratch + SL.heavy_count) : nullptr;
     tm.begin(MSGS_K_PREPROCESS);
     HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, heavy_list, heavy_count));
-    if (occlusion)      // (timed with K1: three small launches, ~7 us when nothing closes)
+    if (occlusion)      // (timed with K1: four small launches, 16-21 us when nothing closes; the wrapper's adaptive policy skips them)
         HIP_TRY(launch_occlusion(vp, P, geom, heavy_list, heavy_count, (OccCand*)(scratch + SL.occ_cand), s));
     tm.end(MSGS_K_PREPROCESS);
     if ((rc = debug_sync(view, s))) return rc;

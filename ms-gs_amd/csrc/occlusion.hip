@@ -26,7 +26,7 @@
 //   occ_cover_kernel     one workgroup per block of tiles: bucketed sums of -log2(1 - alpha_min), prefix, cut-off key per tile
 //   occ_recount_kernel   Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in
 //                        place; a Gaussian left without instances leaves the depth sort: key 0xFFFFFFFF)
-// On a view where nothing closes (the BASELINE C3 headline: four candidates) they cost ~15 us; the Python wrapper then skips the
+// On a view where nothing closes (the BASELINE C3 headline: four candidates) they cost 16-21 us; the Python wrapper then skips the
 // pass for that kind of view and probes again every 32nd call (msgs_view_t.skip_occlusion, msgs_forward_info).
 #include "msgs_internal.h"
 

@@ -266,8 +266,8 @@ def set_deterministic(on=True):
 _last_instances = {}
 
 
-# Occlusion cut-off pass (include/msgs.h, msgs_set_occlusion): three small launches between the per-Gaussian stage and the depth
-# sort — ~15 us on a view where they find nothing to cut, milliseconds saved where opaque covers hide most of the scene (a
+# Occlusion cut-off pass (include/msgs.h, msgs_set_occlusion): four small launches between the per-Gaussian stage and the depth
+# sort — 16-21 us on a view where they find nothing to cut, milliseconds saved where opaque covers hide most of the scene (a
 # multi-scale model rendered without its filters, /root/reference/render.py:32).  The outputs never depend on it.  Policy per
 # (device, P, W, H, filters) key:
 #   "adaptive" (default)  the pass runs on the first call and then on every OCCLUSION_PROBE_PERIOD-th call; in between it runs only

@@ -266,8 +266,8 @@ def test_two_views_in_flight_on_a_scene_that_closes_blocks():
                 assert torch.equal(vs[i].grad, ref_m2[i]), (attempt, i)
             for n in LEAVES:
                 assert torch.equal(getattr(pc, n).grad, getattr(ref_pc, n).grad), (attempt, n)
-            state = getattr(kept[0]["render"].grad_fn, "state", None)
-            assert state is not None and state[3] < D_off, (state and state[3], D_off)
+            D_on = dgr._resolve(kept[0]["render"].grad_fn.state)[3]
+            assert D_on < D_off, (D_on, D_off)
     finally:
         dgr._C.lib.msgs_set_occlusion(prev)
         dgr.occlusion_policy = prev_policy
