@@ -1,7 +1,8 @@
 """Randomised three-way parity sweep, shared by tests/test_fuzz_parity_gpu.py (in front of the driver) and tools/fuzz_parity.py
 (long runs, the table of profiles/r5_parity.md).
 
-Every configuration — Gaussian count, ragged image size, SH degree, multi-scale filters, fade, background, blend granularity,
+Every configuration — Gaussian count, ragged image size, camera pose (the front camera or a random rigid pose: general view and
+projection matrices), focal length, scaling modifier, SH degree, multi-scale filters, fade, background, blend granularity,
 backward generation, forward variant, getter chaining, entry (render() through the reference call surface, or the op called
 with precomputed colours and / or covariances) — is rendered forward + backward by the HIP path and by three builds of the CPU
 oracle on the same inputs:
@@ -66,7 +67,10 @@ def draw_config(rng):
     return dict(P=P, W=W, H=H, deg=rng.randint(0, 3), ms=ms, fade=rng.choice([0.0, 0.5, 1.0]),
                 gran=rng.choice([0, 1, 2]), bwd_gen=rng.choice([0, 1, 2]), fwd_var=rng.choice([0, 0, 1, 3, 4, 5, 6]),
                 entry=rng.choice(["render", "render", "render", "precomp_col", "precomp_cov", "precomp_both"]),
-                chain=rng.random() < 0.7, seed=rng.randint(0, 10 ** 6))
+                chain=rng.random() < 0.7, seed=rng.randint(0, 10 ** 6),
+                # (since the sweeps of profiles/r5_fuzz_*_seed{123,777,4242,9001,31337}.json, which drew none of these:)
+                pose=rng.choice(["front", "rigid", "rigid"]), focal=rng.choice([1.0, 1.0, 0.6, 1.7]),
+                scale_mod=rng.choice([1.0, 1.0, 1.0, 0.7, 1.6]))
 
 
 def configs(n, seed):
@@ -74,7 +78,38 @@ def configs(n, seed):
     return [draw_config(rng) for _ in range(n)]
 
 
-def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov):
+def posed(sc, cam, pose, focal, seed):
+    """The scene and its camera under another pose / focal length.  "rigid": camera and Gaussians moved together by a random
+    rigid transform (the view-space content stays what frustum_scene built for the front camera, up to rounding — but the view
+    and projection matrices are general, the 3-D covariances rotate, the SH directions change); focal: the pinhole's focal
+    length x this factor (0.6: wide, more of the frustum's off-screen margin comes into view; 1.7: narrow, footprints grow and
+    more centres sit outside the 1.3 x tan(fov) clamp)."""
+    import copy
+    import numpy as np
+    from oracle import torch_oracle as to
+    W, H = cam.image_width, cam.image_height
+    f = 1000.0 * W / 1920.0 * focal
+    fovx, fovy = 2.0 * math.atan(W / (2.0 * f)), 2.0 * math.atan(H / (2.0 * f))
+    if pose == "front":
+        return sc, (cam if focal == 1.0 else scenes.make_camera(np.eye(3), np.zeros(3), fovx, fovy, W, H))
+    g = torch.Generator().manual_seed(seed + 7919)
+    q = torch.randn(1, 4, generator=g, dtype=torch.float64)
+    q = q / q.norm()
+    R = to.quat_to_rot(q)[0]                                         # camera axes in world (columns), = the scene's rotation
+    Cw = (torch.rand(3, generator=g, dtype=torch.float64) * 2.0 - 1.0) * 5.0
+    out = copy.copy(sc)
+    out.means3D = (sc.means3D.double() @ R.T + Cw).float().contiguous()
+    a, b = q[0], sc.rotations.double()                               # Hamilton product q (x) b: R(q b) = R(q) R(b)
+    qb = torch.stack([a[0] * b[:, 0] - a[1] * b[:, 1] - a[2] * b[:, 2] - a[3] * b[:, 3],
+                      a[0] * b[:, 1] + a[1] * b[:, 0] + a[2] * b[:, 3] - a[3] * b[:, 2],
+                      a[0] * b[:, 2] - a[1] * b[:, 3] + a[2] * b[:, 0] + a[3] * b[:, 1],
+                      a[0] * b[:, 3] + a[1] * b[:, 2] - a[2] * b[:, 1] + a[3] * b[:, 0]], dim=1)
+    out.rotations = (qb / qb.norm(dim=1, keepdim=True)).float().contiguous()
+    Rn = R.numpy()
+    return out, scenes.make_camera(Rn, -Rn.T @ Cw.numpy(), fovx, fovy, W, H)
+
+
+def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov, scale_mod=1.0):
     """the op called directly with precomputed colours and / or covariances (the reference's override_color /
     compute_cov3D_python call shapes, gaussian_renderer/__init__.py:68-91); returns (out dict, {name: (grad, key in the
     oracle's gradient dict)}, oracle kwargs)"""
@@ -84,7 +119,7 @@ def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov):
     camd = cam.to(dev)
     H, W = cam.image_height, cam.image_width
     rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
-                                       tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev), scale_modifier=1.0,
+                                       tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev), scale_modifier=float(scale_mod),
                                        viewmatrix=camd.world_view_transform, projmatrix=camd.full_proj_transform,
                                        sh_degree=sc.sh_degree, campos=camd.camera_center, prefiltered=False, debug=False, **st)
     t = lambda x: x.to(dev).contiguous().requires_grad_(True)
@@ -93,7 +128,7 @@ def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov):
               base_mask=sc.base_mask.to(dev))
     okw = {}
     if use_cov:
-        cov = to.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), 1.0).float()
+        cov = to.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), float(scale_mod)).float()
         kw["cov3D_precomp"] = t(cov)
         okw.update(use_cov_precomp=True, cov3D_precomp=cov)
     else:
@@ -118,7 +153,7 @@ def _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov):
     return out, {k: (inputs[k].grad, ok) for k, ok in names.items()}, okw
 
 
-def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space):
+def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space, scale_mod=1.0):
     """{tensor: per-Gaussian movement [P]} of dL/dscaling / dL/drotation / dL/dmeans3D when the truth's nine 2-D sums are perturbed
     by the float32 oracle's own relative distance from them (per Gaussian: its worst component, at least one float32 ulp; the
     first-order worst case over the nine signs), through the HIP per-Gaussian backward.  to_compare_space(dict of activated-space gradients) -> {name: tensor} in the space the
@@ -135,7 +170,7 @@ def _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, to_compare_space):
     camd = cam.to(dev)
     rs = dgr.GaussianRasterizationSettings(
         image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
-        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev), scale_modifier=1.0, viewmatrix=camd.world_view_transform,
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(dev), scale_modifier=float(scale_mod), viewmatrix=camd.world_view_transform,
         projmatrix=camd.full_proj_transform, sh_degree=seen.sh_degree, campos=camd.camera_center, prefiltered=False, debug=False, **st)
     t = lambda x: x.to(dev).contiguous()
     col = okw.get("colors_precomp")
@@ -180,6 +215,8 @@ def run_config(cfg):
     P, W, H, seed, ms = cfg["P"], cfg["W"], cfg["H"], cfg["seed"], cfg["ms"]
     sc, cam = small_scene(P, W, H, seed, sh_degree=cfg["deg"], multiscale=ms,
                           **({"scale_k": 0.004 * 1920.0 / max(W, 8) * 0.3} if ms else {}))
+    sc, cam = posed(sc, cam, cfg.get("pose", "front"), cfg.get("focal", 1.0), seed)
+    smod = float(cfg.get("scale_mod", 1.0))
     st = dict(filter_small=ms, filter_large=ms, fade_size=cfg["fade"])
     bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
     dL = scenes.grad_seed(W, H, seed % 97)
@@ -190,14 +227,14 @@ def run_config(cfg):
     dgr.chain_reference_getters = bool(cfg["chain"])
     try:
         if cfg["entry"] == "render":
-            out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+            out, pc, m2 = hip_render(sc, cam, st, bg, dL, scaling_modifier=smod)
             seen, okw = pc.seen, {}
             pairs_for = lambda og: {k: (g, ref) for k, (g, ref) in leaf_space(pc, m2, og).items()}
             # activated-space gradients of the per-Gaussian entry -> the leaf space the exceedances are measured in
             k8_space = lambda gd: {k: v[1] for k, v in leaf_space(pc, m2, {kk: vv for kk, vv in gd.items()}).items()}
         else:
             use_col, use_cov = cfg["entry"] in ("precomp_col", "precomp_both"), cfg["entry"] in ("precomp_cov", "precomp_both")
-            out, grads, okw = _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov)
+            out, grads, okw = _hip_precomp(sc, cam, st, bg, dL, use_col, use_cov, smod)
             seen = sc
             pairs_for = lambda og: {k: (g, og[ok].double()) for k, (g, ok) in grads.items()}
             # (with a precomputed covariance only dL/dmeans3D passes the conic -> covariance map on its way to an input that is compared)
@@ -208,6 +245,7 @@ def run_config(cfg):
         lib.msgs_set_backward_generation(pb)
         lib.msgs_set_forward_variant(pf)
         dgr.chain_reference_getters = pchain
+    okw = dict(okw, scale_modifier=smod)
     orc = oc.rasterize(seen, cam, st, bg, **okw)
     tru = oc.rasterize(seen, cam, st, bg, f64=True, **okw)
     fma = oc.rasterize(seen, cam, st, bg, fma=True, **okw)
@@ -302,7 +340,7 @@ def run_config(cfg):
         elif k in K8_DOWNSTREAM and k8_space is not None:
             try:
                 if k8_amp[0] is None:
-                    k8_amp[0] = _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, k8_space)
+                    k8_amp[0] = _k8_amplification(seen, cam, st, bg, okw, orc, tru, dL, k8_space, smod)
                 got, truth = p_o[k][0].detach().double().cpu(), p_t[k][1].double()
                 scale = max(truth.abs().max().item(), 1e-20)
                 err = (got.reshape(truth.shape) - truth).abs().reshape(P, -1).max(dim=1).values
