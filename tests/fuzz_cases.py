@@ -42,6 +42,12 @@ evidence the oracles produce (never from the kernel variant or the seed):
                               restates bit for bit); the exceedance is explained iff every clean Gaussian's HIP-vs-truth error
                               is within twice the movement that perturbation causes (+ the tolerance): HIP's sums need be no
                               worse than the float32 reference's — only their errors are not common to the three conic sums.
+    cancelled_sum             the max-norm relative error divides by the tensor's own largest entry; in a scene of one or two
+                              Gaussians that entry is ONE sum over the footprint of terms whose signs follow the image gradient,
+                              and it can cancel to a few per cent of its terms — every float32 build is then 1e-3 from the
+                              truth (seen only at P = 1: three configurations in 15 000).  Explained iff the tensor's max norm is
+                              below a tenth of what the same backward yields for |dL| (float64 oracle) AND the error is within
+                              1e-4 of THAT scale.
 Anything else is UNEXPLAINED and fails the test.
 """
 import math
@@ -57,7 +63,7 @@ TRUTH_FACTOR = 1.25
 ILL_CONDITIONED = ("scaling", "rotation")          # the two tensors behind K8's conic -> covariance map
 AUX_RTOL = 2e-5                                    # depth / acc_pixel_size: relative to the buffer's value range
 K8_DOWNSTREAM = ILL_CONDITIONED + ("means3D",)     # dL/dmeans3D also takes a term through it (the Jacobian's dependence on t)
-CLASSES = ("shared_borderline_pixel", "oracle_f32_off_truth", "float32_rounding_mode", "k8_conditioning")
+CLASSES = ("shared_borderline_pixel", "oracle_f32_off_truth", "float32_rounding_mode", "k8_conditioning", "cancelled_sum")
 
 
 def draw_config(rng):
@@ -318,6 +324,26 @@ def run_config(cfg):
             return True
         return k in ILL_CONDITIONED and e["hip_tru"] <= max(GRAD_TOL, TRUTH_FACTOR * e["orc_tru"] + 1e-6)
 
+    abs_scale = [None]
+
+    def last_resort(k, what):
+        """cancelled_sum, or unexplained: the error of tensor k measured against the scale the same backward has when the image
+        gradient does not cancel (the float64 oracle driven by |dL|)"""
+        try:
+            if abs_scale[0] is None:
+                abs_scale[0] = pairs_for(oc.backward(tru, dL.abs()))
+            clean = ~flagged1
+            got, truth = p_o[k][0].detach().double().cpu(), p_t[k][1].double()
+            err = (got.reshape(truth.shape) - truth).abs().reshape(P, -1)[clean]
+            scale = abs_scale[0][k][1].double().abs().reshape(P, -1)[clean].max().item()
+            own = truth.abs().reshape(P, -1)[clean].max().item()
+            r = err.max().item() / max(scale, 1e-300) if err.numel() else 0.0
+            if r <= GRAD_TOL and own < 0.1 * scale:
+                return ("cancelled_sum", what + f" | the tensor's max norm is {own / max(scale, 1e-300):.1e} of what |dL| gives; error / that scale {r:.2e}")
+        except Exception as ex:          # noqa: BLE001 - a failing diagnosis leaves the exceedance unexplained
+            return ("unexplained", what + f" | cancelled-sum diagnosis raised {ex!r}"[:300])
+        return ("unexplained", what)
+
     for k in p_o:
         e = distances(k, ~flagged1)
         if e is None:
@@ -351,11 +377,11 @@ def run_config(cfg):
                     problems.append(("k8_conditioning", what + f" | worst Gaussian: error {err[worst_i] / scale:.2e}, movement of the "
                                      f"float32-sized perturbation {k8_amp[0][k][worst_i] / scale:.2e} (of the tensor's max norm)"))
                 else:
-                    problems.append(("unexplained", what + f" | {int((~ok_rows & clean).sum())} Gaussians beyond twice their K8 movement"))
+                    problems.append(last_resort(k, what + f" | {int((~ok_rows & clean).sum())} Gaussians beyond twice their K8 movement"))
             except Exception as ex:      # noqa: BLE001 - a failing diagnosis leaves the exceedance unexplained
                 problems.append(("unexplained", what + f" | K8 diagnosis raised {ex!r}"[:200]))
         else:
-            problems.append(("unexplained", what))
+            problems.append(last_resort(k, what))
     res["grad"] = dist
     if problems:
         order = ("unexplained", "forward_borderline") + tuple(reversed(CLASSES))

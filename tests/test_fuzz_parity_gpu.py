@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 N, SEED = 320, 20251002
 # Explained-exceedance budgets, in configurations of the 320 (measured on MI355X: profiles/r5_parity.md)
-BUDGET = {"shared_borderline_pixel": 4, "oracle_f32_off_truth": 3, "float32_rounding_mode": 3, "k8_conditioning": 4}
+BUDGET = {"shared_borderline_pixel": 4, "oracle_f32_off_truth": 3, "float32_rounding_mode": 3, "k8_conditioning": 4,
+          "cancelled_sum": 1}
 
 
 def test_randomised_three_way_sweep_has_no_unexplained_exceedance():
