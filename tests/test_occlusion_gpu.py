@@ -273,6 +273,21 @@ def test_two_views_in_flight_on_a_scene_that_closes_blocks():
         dgr.occlusion_policy = prev_policy
 
 
+def test_8k_image_uses_larger_cover_blocks():
+    """7680x4320 = 480 x 270 tiles: more than 2048 blocks of 4 x 4 tiles, so the pass works on 8 x 8-tile blocks (60 x 34); forward
+    and backward with giants in front, bit-identical to the uncut path"""
+    W, H = 7680, 4320
+    sc = _giants_scene(3000, W, H, 21, 60, giant_scale=1.0, giant_opacity=0.9)
+    cam = scenes.front_camera(W, H).to("cuda")
+    bg = torch.tensor([0.1, 0.1, 0.3], device="cuda")
+    dL = scenes.grad_seed(W, H, 3).cuda()
+    on = _run(sc, cam, PLAIN, bg, dL, True)
+    off = _run(sc, cam, PLAIN, bg, dL, False)
+    _assert_identical(on, off, "8K")
+    print(f"[occlusion] 8K: D {off[2]} -> {on[2]}, {on[3]}")
+    assert on[3]["block"] == 8 and on[3]["closed_blocks"] > 0 and on[2] < off[2]
+
+
 def test_pyramid_levels_and_filters_on_are_unchanged():
     """the training path (filters on, fade 0) at three pyramid levels of the C3 scene, and the switch really switches"""
     import diff_gaussian_rasterization as dgr
@@ -292,7 +307,8 @@ def test_pyramid_levels_and_filters_on_are_unchanged():
 def test_adaptive_policy_probes_then_skips_then_probes_again():
     """diff_gaussian_rasterization.occlusion_policy = "adaptive" (the default): the pass runs on the first call of a (model size,
     image, filters) key; while a probe finds nothing to cut the next OCCLUSION_PROBE_PERIOD - 1 calls skip it
-    (msgs_view_t.skip_occlusion), and while it does cut, every call runs it.  Same image either way."""
+    (msgs_view_t.skip_occlusion), and while it does cut — or sees enough cover candidates that another view of the same model
+    might — every call runs it.  Same image either way."""
     import diff_gaussian_rasterization as dgr
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
@@ -303,7 +319,9 @@ def test_adaptive_policy_probes_then_skips_then_probes_again():
     quiet = scenes.frustum_scene(3000, W, H, seed=5, scale_k=0.004 * 1920.0 / W * 0.3)          # nothing to cut
     walls = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.9)                # opaque covers in front
     info = (C.c_int64 * 2)()
-    for sc, cuts in ((quiet, False), (walls, True)):
+    # many heavy Gaussians, all nearly transparent: candidates, but nothing closes — the pass must stay on for the other views
+    haze = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.012)
+    for sc, cuts in ((quiet, False), (walls, True), (haze, True)):
         dgr._occ_countdown.clear()
         dgr._last_instances.clear()
         pc = SyntheticGaussians(sc, "cuda", requires_grad=False)
