@@ -285,7 +285,7 @@ def test_8k_image_uses_larger_cover_blocks():
     off = _run(sc, cam, PLAIN, bg, dL, False)
     _assert_identical(on, off, "8K")
     print(f"[occlusion] 8K: D {off[2]} -> {on[2]}, {on[3]}")
-    assert on[3]["block"] == 8 and on[3]["closed_blocks"] > 0 and on[2] < off[2]
+    assert on[3]["block"] >= 8 and on[3]["closed_blocks"] > 0 and on[2] < off[2]       # (8 unless MSGS_OCC_BLOCK asks for more)
 
 
 def test_pyramid_levels_and_filters_on_are_unchanged():
@@ -312,7 +312,7 @@ def test_adaptive_policy_probes_then_skips_then_probes_again():
     import diff_gaussian_rasterization as dgr
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
-    assert dgr.occlusion_policy == "adaptive"
+    prev_policy, dgr.occlusion_policy = dgr.occlusion_policy, "adaptive"       # (the default unless MSGS_OCCLUSION_POLICY says otherwise)
     W, H = 480, 320
     cam = scenes.front_camera(W, H).to("cuda")
     bg = torch.zeros(3, device="cuda")
@@ -338,3 +338,4 @@ def test_adaptive_policy_probes_then_skips_then_probes_again():
         else:            # candidates may be zero on a quiet scene: look at the wrapper's own bookkeeping instead
             key = next(iter(dgr._occ_countdown))
             assert dgr._occ_countdown[key] == dgr.OCCLUSION_PROBE_PERIOD - 2, dgr._occ_countdown
+    dgr.occlusion_policy = prev_policy
