@@ -76,7 +76,11 @@ def draw_config(rng):
                 chain=rng.random() < 0.7, seed=rng.randint(0, 10 ** 6),
                 # (since the sweeps of profiles/r5_fuzz_*_seed{123,777,4242,9001,31337}.json, which drew none of these:)
                 pose=rng.choice(["front", "rigid", "rigid"]), focal=rng.choice([1.0, 1.0, 0.6, 1.7]),
-                scale_mod=rng.choice([1.0, 1.0, 1.0, 0.7, 1.6]))
+                scale_mod=rng.choice([1.0, 1.0, 1.0, 0.7, 1.6]),
+                # (and since r5_fuzz_50000_seed99.json:) the SH tensor holds all 16 coefficients (a model built for degree 3 whose
+                # active degree is `deg`) or only the (deg + 1)^2 of a model built with --sh_degree deg (other row layouts in K1 / K9,
+                # no getter chaining: the reference's features_rest is [P, (deg + 1)^2 - 1, 3] there, empty at degree 0)
+                sh_full=rng.random() < 0.6)
 
 
 def configs(n, seed):
@@ -221,6 +225,8 @@ def run_config(cfg):
     P, W, H, seed, ms = cfg["P"], cfg["W"], cfg["H"], cfg["seed"], cfg["ms"]
     sc, cam = small_scene(P, W, H, seed, sh_degree=cfg["deg"], multiscale=ms,
                           **({"scale_k": 0.004 * 1920.0 / max(W, 8) * 0.3} if ms else {}))
+    if not cfg.get("sh_full", True):
+        sc.shs = sc.shs[:, :(cfg["deg"] + 1) ** 2, :].contiguous()
     sc, cam = posed(sc, cam, cfg.get("pose", "front"), cfg.get("focal", 1.0), seed)
     smod = float(cfg.get("scale_mod", 1.0))
     st = dict(filter_small=ms, filter_large=ms, fade_size=cfg["fade"])
