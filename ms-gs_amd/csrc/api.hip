@@ -213,7 +213,11 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     // K1 also clears the depth sort's group-sum table (saves a fill launch) and the header of the occlusion cut-off
     // (enabled = 0, no candidates: what the emit reads when the pass does not run)
     ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.occ_hdr), sizeof(OccHeader) / 4 + (size_t)OCC_BUCKETS};
-    const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
+    // MSGS_DEPTH_SORT_BEGIN_BIT=8: a TIMING EXPERIMENT, never a mode — the depth sort skips its lowest byte (three passes; ties
+    // inside 256 ulps of depth fall back to index order, which is not the reference's order): the cost of one radix pass inside
+    // the whole step, i.e. the upper bound of what a three-pass (9-bit digit) depth sort could save (profiles/r5_notes.md)
+    static const int depth_begin_bit = [] { const char* e = getenv("MSGS_DEPTH_SORT_BEGIN_BIT"); return (e && atoi(e) == 8) ? 8 : 0; }();
+    const bool sort1_prezeroed = radix_sort_zero_region(P, depth_begin_bit, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
     // exact per-tile occlusion cut-off (occlusion.hip): on unless switched off
     const bool occlusion = get_occlusion() != 0 && view->skip_occlusion == 0;
     uint32_t* heavy_list = occlusion ? (uint32_t*)(scratch + SL.heavy_list) : nullptr;
@@ -229,7 +233,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     // the emit compares them with the tiles' cut-off keys
     tm.begin(MSGS_K_DEPTH_SORT);
     HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(geom + GL.skey),
-                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed,
+                             (uint32_t*)(geom + GL.order), P, depth_begin_bit, 32, scratch + SL.sort, s, sort1_prezeroed,
                              (uint32_t*)(geom + GL.nvalid)));
     tm.end(MSGS_K_DEPTH_SORT);
     if ((rc = debug_sync(view, s))) return rc;
