@@ -80,7 +80,11 @@ def draw_config(rng):
                 # (and since r5_fuzz_50000_seed99.json:) the SH tensor holds all 16 coefficients (a model built for degree 3 whose
                 # active degree is `deg`) or only the (deg + 1)^2 of a model built with --sh_degree deg (other row layouts in K1 / K9,
                 # no getter chaining: the reference's features_rest is [P, (deg + 1)^2 - 1, 3] there, empty at degree 0)
-                sh_full=rng.random() < 0.6)
+                sh_full=rng.random() < 0.6,
+                # (and since r5_fuzz_10000_seed777001.json:) a multi-scale model may be rendered WITHOUT its filters — render.py's
+                # default flags: the x4 .. x64 scaled coarse-level Gaussians are all drawn, covers close blocks, the occlusion
+                # cut-off (forced on for these) removes instances — against the oracle, which knows nothing of it
+                filters=rng.random() < 0.65)
 
 
 def configs(n, seed):
@@ -229,10 +233,14 @@ def run_config(cfg):
         sc.shs = sc.shs[:, :(cfg["deg"] + 1) ** 2, :].contiguous()
     sc, cam = posed(sc, cam, cfg.get("pose", "front"), cfg.get("focal", 1.0), seed)
     smod = float(cfg.get("scale_mod", 1.0))
-    st = dict(filter_small=ms, filter_large=ms, fade_size=cfg["fade"])
+    filt = bool(ms and cfg.get("filters", True))
+    st = dict(filter_small=filt, filter_large=filt, fade_size=cfg["fade"])
     bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
     dL = scenes.grad_seed(W, H, seed % 97)
     lib = dgr._C.lib
+    prev_policy = dgr.occlusion_policy
+    if ms and not filt:
+        dgr.occlusion_policy = "always"
     pg, pb, pf = lib.msgs_set_blend_granularity(cfg["gran"]), lib.msgs_set_backward_generation(cfg["bwd_gen"]), \
         lib.msgs_set_forward_variant(cfg["fwd_var"])
     pchain = dgr.chain_reference_getters
@@ -257,6 +265,7 @@ def run_config(cfg):
         lib.msgs_set_backward_generation(pb)
         lib.msgs_set_forward_variant(pf)
         dgr.chain_reference_getters = pchain
+        dgr.occlusion_policy = prev_policy
     okw = dict(okw, scale_modifier=smod)
     orc = oc.rasterize(seen, cam, st, bg, **okw)
     tru = oc.rasterize(seen, cam, st, bg, f64=True, **okw)
