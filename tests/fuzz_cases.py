@@ -70,7 +70,7 @@ def draw_config(rng):
     P = rng.choice([1, 2, 7, 63, 64, 65, 200, 777, 1500, 4001, 9000])
     W, H = rng.randint(1, 260), rng.randint(1, 200)
     ms = rng.random() < 0.5
-    return dict(P=P, W=W, H=H, deg=rng.randint(0, 3), ms=ms, fade=rng.choice([0.0, 0.5, 1.0]),
+    cfg = dict(P=P, W=W, H=H, deg=rng.randint(0, 3), ms=ms, fade=rng.choice([0.0, 0.5, 1.0]),
                 gran=rng.choice([0, 1, 2]), bwd_gen=rng.choice([0, 1, 2]), fwd_var=rng.choice([0, 0, 1, 3, 4, 5, 6]),
                 entry=rng.choice(["render", "render", "render", "precomp_col", "precomp_cov", "precomp_both"]),
                 chain=rng.random() < 0.7, seed=rng.randint(0, 10 ** 6),
@@ -85,6 +85,11 @@ def draw_config(rng):
                 # default flags: the x4 .. x64 scaled coarse-level Gaussians are all drawn, covers close blocks, the occlusion
                 # cut-off (forced on for these) removes instances — against the oracle, which knows nothing of it
                 filters=rng.random() < 0.65)
+    if ms and not cfg["filters"] and rng.random() < 0.6:
+        # covers need room: a Gaussian becomes a cover candidate from 97 tile instances on, and a 260 x 200 image has 221 tiles.
+        # Larger images (up to 30 x 20 tiles), fewer Gaussians (the oracle walks every instance of every giant for 256 pixels)
+        cfg.update(W=rng.randint(200, 480), H=rng.randint(160, 320), P=rng.choice([200, 777, 1500]))
+    return cfg
 
 
 def configs(n, seed):
@@ -260,6 +265,15 @@ def run_config(cfg):
             # (with a precomputed covariance only dL/dmeans3D passes the conic -> covariance map on its way to an input that is compared)
             k8_space = (lambda gd: {"means3D": gd["means3D"]}) if use_cov else \
                 (lambda gd: {"scaling": gd["scales"], "rotation": gd["rotations"], "means3D": gd["means3D"]})
+        closed = None
+        if ms and not filt:          # did the cut-off have anything to cut?  (msgs_occlusion_stats of this forward's geometry buffer)
+            import ctypes as C
+            fn = out["render"].grad_fn
+            geom = dgr._resolve(fn.state)[0]
+            o = (C.c_int64 * 8)()
+            dgr._C.check(lib.msgs_occlusion_stats(C.c_void_p(geom.data_ptr()), geom.numel(), fn.call.P, o,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "msgs_occlusion_stats")
+            closed = (int(o[0]), int(o[2]), int(o[3]), int(o[4]))          # ran, candidates, closed blocks, blocks
     finally:
         lib.msgs_set_blend_granularity(pg)
         lib.msgs_set_backward_generation(pb)
@@ -274,7 +288,8 @@ def run_config(cfg):
 
     k8_amp = [None]
     res = dict(cfg=cfg, status="pass", detail="", pixels=W * H, borderline_pixels=int(orc.borderline.sum()),
-               gaussians=P, tier1=int(orc.borderline_gaussians.sum()), tier2=int(orc.shared_borderline_gaussians.sum()))
+               gaussians=P, tier1=int(orc.borderline_gaussians.sum()), tier2=int(orc.shared_borderline_gaussians.sum()),
+               occlusion=closed)
     # ---- forward -------------------------------------------------------------------------------------------------------
     okpx = ~(orc.borderline.bool() | tru.borderline.bool())
     col = out["render"].detach().cpu()
@@ -426,6 +441,10 @@ def summarize(results):
     s = {"configurations": n, "pass": sum(r["status"] == "pass" for r in results)}
     for c in CLASSES + ("unexplained",):
         s[c] = sum(r["status"] == c for r in results)
+    occ = [r["occlusion"] for r in results if r.get("occlusion")]
+    s["multiscale_without_filters"] = {"configurations": len(occ), "with_cover_candidates": sum(o[1] > 0 for o in occ),
+                                       "with_closed_blocks": sum(o[2] > 0 for o in occ),
+                                       "with_every_block_closed": sum(o[2] == o[3] and o[3] > 0 for o in occ)}
     s["borderline_pixel_fraction"] = sum(r["borderline_pixels"] for r in results) / max(sum(r["pixels"] for r in results), 1)
     s["tier1_gaussian_fraction"] = sum(r["tier1"] for r in results) / max(sum(r["gaussians"] for r in results), 1)
     s["tier2_gaussian_fraction"] = sum(r["tier2"] for r in results) / max(sum(r["gaussians"] for r in results), 1)

@@ -31,6 +31,9 @@ def test_randomised_three_way_sweep_has_no_unexplained_exceedance():
     assert s["pass"] >= N - sum(BUDGET.values())
     # the exclusions of the strict checks stay rare over the sweep as a whole (single tiny scenes can exceed any fraction)
     assert s["borderline_pixel_fraction"] < 0.0045 and s["tier1_gaussian_fraction"] < 0.03, s
+    # the multi-scale models rendered without their filters did give the occlusion cut-off something to cut
+    mw = s["multiscale_without_filters"]
+    assert mw["configurations"] >= 40 and mw["with_closed_blocks"] >= 8 and mw["with_every_block_closed"] >= 4, mw
     # every kernel variant was drawn
     cfgs = [r["cfg"] for r in results]
     assert {c["fwd_var"] for c in cfgs} == {0, 1, 3, 4, 5, 6} and {c["bwd_gen"] for c in cfgs} == {0, 1, 2}
