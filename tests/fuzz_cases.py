@@ -2,7 +2,9 @@
 (long runs, the table of profiles/r5_parity.md).
 
 Every configuration — Gaussian count, ragged image size, camera pose (the front camera or a random rigid pose: general view and
-projection matrices), focal length, scaling modifier, SH degree, multi-scale filters, fade, background, blend granularity,
+projection matrices), focal length, scaling modifier, SH degree and layout (16 coefficients or the (deg + 1)^2 of a model built
+for that degree), multi-scale filters (a multi-scale model may also be rendered WITHOUT them: render.py's flags, the occlusion
+cut-off's case, pass forced on), fade, background, blend granularity,
 backward generation, forward variant, getter chaining, entry (render() through the reference call surface, or the op called
 with precomputed colours and / or covariances) — is rendered forward + backward by the HIP path and by three builds of the CPU
 oracle on the same inputs:
@@ -33,8 +35,8 @@ evidence the oracles produce (never from the kernel variant or the seed):
                               (contraction off / on) + 1e-6: inside the spread of the reference algorithm's own legal float32
                               evaluations;
     k8_conditioning           dL/dscaling / dL/drotation, and dL/dmeans3D (which takes one term through the same map: the
-                              projection Jacobian's dependence on the view-space position) only.  K8 maps the nine per-Gaussian 2-D sums of the blend backward to
-                              the 3-D gradients through the conic -> covariance inverse, which amplifies a relative difference
+                              projection Jacobian's dependence on the view-space position) only.  K8 maps the nine per-Gaussian
+                              2-D sums of the blend backward to the 3-D gradients through the conic -> covariance inverse, which amplifies a relative difference
                               in the sums by the squared aspect ratio of the footprint (tests/test_k8_isolation_gpu.py: 100-850x).
                               MEASURED per Gaussian here: the float64 truth's sums are perturbed, independently per component,
                               by the relative distance the FLOAT32 ORACLE'S OWN sums have from them (>= one float32 ulp), and
