@@ -342,6 +342,25 @@ def test_shared_flags_cover_everything_a_flipped_alpha_decision_changes():
     assert covered_strictly_more
 
 
+def test_alpha_window_follows_the_float32_uncertainty_of_the_exponent():
+    """The case the 10 000-configuration sweep found (profiles/r5_parity.md 2.1): a needle of aspect 23 evaluated 60 px from its
+    centre, power = -5.41 out of terms of magnitude 1179; alpha x 255 - 1 = -2.5e-5 in this build, -8.6e-5 with FMA contraction,
+    -3.4e-5 in float64 — and >= 0 in the HIP kernels, which blended it.  The fixed 2e-5 window of rounds 1-4 left pixel (80, 41)
+    unflagged; the conditioning-aware window flags it (and the Gaussian) in all three builds, while a round footprint keeps 2e-5:
+    the flagged fraction of the whole image stays below 1 %."""
+    from parity_utils import small_scene
+    W, H, P, seed = 155, 119, 9000, 124916
+    sc, cam = small_scene(P, W, H, seed, sh_degree=3, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.3)
+    st = dict(filter_small=True, filter_large=True, fade_size=0.5)
+    bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
+    cov = to.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), 1.0).float()
+    for kw in ({}, {"f64": True}, {"fma": True}):
+        r = oc.rasterize(sc, cam, st, bg, use_cov_precomp=True, cov3D_precomp=cov, **kw)
+        assert bool(r.borderline[41, 80]), kw
+        assert bool(r.borderline_gaussians[3433]), kw
+        assert r.borderline.float().mean().item() < 0.01, kw
+
+
 def test_c_oracle_clamped_projection_and_ring_camera():
     W, H = 56, 40
     sc = scenes.frustum_scene(300, W, H, seed=6, scale_k=_k(W, 1.5))
