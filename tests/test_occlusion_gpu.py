@@ -323,6 +323,7 @@ def test_adaptive_policy_probes_then_skips_then_probes_again():
     haze = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.012)
     for sc, cuts in ((quiet, False), (walls, True), (haze, True)):
         dgr._occ_countdown.clear()
+        dgr._occ_hot.clear()
         dgr._last_instances.clear()
         pc = SyntheticGaussians(sc, "cuda", requires_grad=False)
         ran, imgs = [], []
@@ -338,4 +339,20 @@ def test_adaptive_policy_probes_then_skips_then_probes_again():
         else:            # candidates may be zero on a quiet scene: look at the wrapper's own bookkeeping instead
             key = next(iter(dgr._occ_countdown))
             assert dgr._occ_countdown[key] == dgr.OCCLUSION_PROBE_PERIOD - 2, dgr._occ_countdown
+    # a sweep that alternates a view that closes with one that looks away from everything (same key: the wrapper does not know
+    # the camera): the pass must keep running for the view that closes
+    dgr._occ_countdown.clear()
+    dgr._occ_hot.clear()
+    dgr._last_instances.clear()
+    away = scenes.ring_camera(0, 8, W, H, radius=50.0).to("cuda")        # far from the frustum scene, looking back at the origin
+    pc = SyntheticGaussians(walls, "cuda", requires_grad=False)
+    closed_when_facing = []
+    with torch.no_grad():
+        for it in range(12):
+            facing = it % 2 == 0
+            render(cam if facing else away, pc, PIPE, bg, **PLAIN)
+            dgr._C.lib.msgs_forward_info(info)
+            if facing:
+                closed_when_facing.append(int(info[1]))
+    assert all(closed_when_facing), closed_when_facing
     dgr.occlusion_policy = prev_policy
