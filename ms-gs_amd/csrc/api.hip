@@ -617,37 +617,6 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     if (det && grads->scratch_is_clear) return MSGS_ERR_INVALID_ARG;
     if (!grads->scratch_is_clear)           // (else: cleared by the blend kernel of this view's forward, msgs.h)
         HIP_TRY(launch_zero(grad_rec, GRAD_REC_BYTES * (size_t)P, s));
-    // dense per-Gaussian gradients, 44 % zero rows at C3: zero-filled by the blend backward's side job, the per-Gaussian backward
-    // then stores the rendered rows only (msgs_internal.h, ZeroRegions).  Not when the views of a step accumulate into one
-    // bucket, not in the verification mode, not where the blend backward runs a variant without the side job.
-    // MSGS_DENSE_GRAD_ROWS=1: A/B, the per-Gaussian backward writes every row itself as in rounds 1-5
-    static const bool dense_rows = [] { const char* e = getenv("MSGS_DENSE_GRAD_ROWS"); return e && e[0] == '1'; }();
-    ZeroRegions zr{};
-    bool sparse = !det && !dense_rows && !grads->accumulate && blend_backward_zeroes_inline(vp.gx * vp.gy);
-    if (sparse) {
-        bool aligned = true;                 // the side job stores 16-byte words: a caller's 4-byte aligned tensor keeps the old path
-        const unsigned long long Pw = (unsigned long long)P;
-        const bool factored = g->raw_params && !grads->dL_dfeatures_dc;     // dL_dcolors = the factors, written densely
-        auto add = [&](float* p, unsigned long long words) {
-            if (p) {
-                aligned = aligned && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-                zr.p[zr.n] = reinterpret_cast<uint32_t*>(p); zr.words[zr.n] = words; ++zr.n;
-            }
-        };
-        add(grads->dL_dmeans3D, 3 * Pw);
-        add(grads->dL_dmeans2D, 3 * Pw);
-        if (!g->colors_precomp) {
-            add(grads->dL_dshs, 3ull * (unsigned long long)view->sh_coeffs * Pw);
-            add(grads->dL_dfeatures_dc, 3 * Pw);
-            add(grads->dL_dfeatures_rest, 45 * Pw);
-        }
-        if (!factored) add(grads->dL_dcolors, 3 * Pw);
-        add(grads->dL_dopacities, Pw);
-        add(grads->dL_dscales, 3 * Pw);
-        add(grads->dL_drotations, 4 * Pw);
-        add(grads->dL_dcov3D, 6 * Pw);
-        if (!aligned) { sparse = false; zr = ZeroRegions{}; }
-    }
     tm.begin(MSGS_K_BLEND_BWD);
     if (det)      // grad_rec is the first region of the deterministic scratch layout
         HIP_TRY(launch_blend_backward_det(vp, P, geom, (const uint32_t*)(binning + BL.ids), D,
@@ -656,12 +625,12 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     else
         HIP_TRY(launch_blend_backward(vp, geom, (const uint32_t*)(binning + BL.ids), (const uint2*)(binning + BL.ranges),
                                       (const float*)(image + IL.final_T), (const uint32_t*)(image + IL.n_contrib),
-                                      dL_dcolor, grad_rec, s, (const uint32_t*)(image + IL.tile_order), sparse ? &zr : nullptr));
+                                      dL_dcolor, grad_rec, s, (const uint32_t*)(image + IL.tile_order)));
     tm.end(MSGS_K_BLEND_BWD);
     if ((rc = debug_sync(view, s))) return rc;
 
     tm.begin(MSGS_K_PREPROCESS_BWD);
-    HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s, false, sparse));
+    HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s));
     tm.end(MSGS_K_PREPROCESS_BWD);
     return debug_sync(view, s);
 }

@@ -99,21 +99,6 @@ __device__ __forceinline__ void clear_slice(uint4* __restrict__ p, size_t n16) {
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// Side job of the one-wave-per-tile backward: workgroup b zero-fills slice b of every region (16-byte stores; the up to three
-// trailing words of a region by workgroup 0)
-__device__ __forceinline__ void zero_regions_slice(const ZeroRegions& z) {
-    for (int r = 0; r < z.n; ++r) {
-        uint4* p = reinterpret_cast<uint4*>(z.p[r]);
-        const size_t n16 = (size_t)(z.words[r] >> 2);
-        const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
-        const size_t lo = per * blockIdx.x;
-        const size_t hi = lo + per < n16 ? lo + per : n16;
-        for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t tail = (uint32_t)(z.words[r] & 3ull);
-        if (blockIdx.x == 0 && threadIdx.x < tail) z.p[r][(n16 << 2) + threadIdx.x] = 0u;
-    }
-}
-
 // Per-tile traversal length for the backward's launch order (ImageLayout::tile_last): the position behind the last entry any
 // pixel of the tile blended = the number of list entries the backward will walk for this tile — its work, to first order.
 // Also invalidates the previous frame's launch order (launch_tile_order re-validates it after this kernel).
@@ -1087,14 +1072,12 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                                                                  const uint32_t* __restrict__ n_contrib,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  void* __restrict__ grad_out,
-                                                                 const uint32_t* __restrict__ tile_order,
-                                                                 ZeroRegions zr = ZeroRegions{}) {
+                                                                 const uint32_t* __restrict__ tile_order) {
     __shared__ float4 s_r0[WB], s_r1[WB];
     __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
                                                            // address register serves every LDS read of an entry
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
-    if constexpr (!DET && !COUNT) zero_regions_slice(zr);          // fire-and-forget stores in front of the walk (msgs_internal.h)
     // launch order: heaviest tiles first inside every XCD's contiguous run (launch_tile_order) when the forward left a valid
     // order behind, the plain XCD swizzle otherwise
     int tile = swizzled_tile(blockIdx.x, num_tiles);
@@ -1479,21 +1462,13 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
     return hipGetLastError();
 }
 
-static bool backward_uses_fine(int tiles) {
-    return g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD));
-}
-constexpr int ZERO_INLINE_MIN_TILES = 2048;        // (as CLEAR_INLINE_MIN_TILES of the forward: enough workgroups for the stores)
-bool blend_backward_zeroes_inline(int tiles) {
-    return tiles >= ZERO_INLINE_MIN_TILES && !backward_uses_fine(tiles) && !bwd_v1(tiles);
-}
-
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order, const ZeroRegions* zr) {
+                                 grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order) {
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    if (backward_uses_fine(tiles)) {
+    if (g_granularity.load() == 2 || (g_bwd_gen.load() == 0 && use_fine(tiles, FINE_MAX_TILES_BWD))) {
         const FineShape f = fine_shape(tiles);
 #define MSGS_FINE_BWD(WAVES, SB) launch_fine_bwd<WAVES, SB>(tiles, s, vp, rec, ids, ranges, final_T, n_contrib, dL_dcolor, grad_rec)
         if (f.sb == 1) {
@@ -1509,8 +1484,7 @@ hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const u
     }
     else if (!bwd_v1(tiles))
         hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
-                           n_contrib, dL_dcolor, grad_rec, tile_order,
-                           zr && tiles >= ZERO_INLINE_MIN_TILES ? *zr : ZeroRegions{});
+                           n_contrib, dL_dcolor, grad_rec, tile_order);
     else
         hipLaunchKernelGGL(blend_backward_kernel, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, final_T,
                            n_contrib, dL_dcolor, grad_rec);

@@ -437,11 +437,9 @@ hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint3
 int set_occlusion(int on);                // occlusion.hip: process-wide switch (MSGS_NO_OCCLUSION=1 initially off); returns previous
 int get_occlusion();
 int occlusion_block_log2(int gx, int gy);  // log2(tiles per side of a cover block) for a gx x gy grid (MSGS_OCC_BLOCK: minimum, default 4)
-// sparse: the gradient tensors were zero-filled by the blend backward's side job (ZeroRegions): only the rows of rendered
-// Gaussians are written
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
-                                      hipStream_t s, bool textbook = false, bool sparse = false);
+                                      hipStream_t s, bool textbook = false);
 hipError_t launch_sh_grad_from_views(int P, int n_views, int deg, const float* means3D, const float* campos,
                                      int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
                                      float* d_dc, float* d_rest, hipStream_t s);
@@ -525,22 +523,9 @@ hipError_t voxel_pool_average(const float* features, int F, const uint32_t* orde
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
                                 uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s);
-// Side job of the one-wave-per-tile blend backward: zero-fill the backward's OUTPUT tensors.  44 % of the rows of the dense
-// per-Gaussian gradients belong to Gaussians the view did not render (C3); written by the per-Gaussian backward they are a fifth
-// of its HBM traffic, written here they cost nothing — the kernel is instruction-issue bound with the memory pipe mostly idle —
-// and the per-Gaussian backward then stores the rendered rows only.  words: 4-byte words per region.
-struct ZeroRegions {
-    uint32_t* p[10];
-    unsigned long long words[10];
-    int n;
-};
-// true iff launch_blend_backward(.., zr) will run the side job for this tile count under the current mode switches (the
-// one-wave-per-tile kernel with enough workgroups to spread the stores over the chip); otherwise it ignores `zr`
-bool blend_backward_zeroes_inline(int tiles);
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
-                                 grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order = nullptr,
-                                 const ZeroRegions* zr = nullptr);
+                                 grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order = nullptr);
 // heaviest-first launch order of the one-wave-per-tile backward from the forward's per-tile traversal lengths
 hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, uint32_t* tile_order, hipStream_t s);
 hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,

@@ -241,16 +241,15 @@ __device__ __forceinline__ void coop_load_rows_part(float* lds_rows, const float
 // rows 0..nrow of the wave are stored to g_rows (all 12 float4 of every row); a row whose bit in
 // `live` is clear, and every float at or beyond nfloat, is written as zero.
 // acc (msgs_grads_t::accumulate): live rows are ADDED to what g_rows holds, the other rows are not touched
-// acc: live rows are ADDED, the others not touched; skip_dead: live rows are STORED, the others not touched (pre-zeroed tensor)
 __device__ __forceinline__ void coop_store_rows(const float* lds_rows, float* g_rows, int nrow, uint64_t live,
-                                                int nfloat, int lane, bool acc, bool skip_dead = false) {
+                                                int nfloat, int lane, bool acc) {
     constexpr int n4 = ROW_F / 4, rpi = 64 / n4;            // 12 float4 per row, 5 rows per instruction
     const int sub = lane / n4, c = lane - sub * n4;
     for (int it = 0; it * rpi < nrow; ++it) {
         const int row = it * rpi + sub;
         if (sub < rpi && row < nrow) {
             const bool on = (live >> row) & 1ull;
-            if ((acc || skip_dead) && !on) continue;
+            if (acc && !on) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (on) {
                 const float* sp = lds_rows + row * ROW_LDS + 4 * c;
@@ -370,16 +369,10 @@ __device__ __forceinline__ void coop_load_split_rows(float* lds_rows, const floa
 // coefficients beyond the active degree).  acc: live rows are ADDED to the tensors, the others not touched.
 __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, float* d_dc, float* d_rest, int i,
                                                       bool in_range, int wave_first, int nrow, uint64_t live,
-                                                      int nfloat, int lane, int lrow, bool acc = false,
-                                                      bool skip_dead = false) {
+                                                      int nfloat, int lane, int lrow, bool acc = false) {
     if (in_range) {
         const bool on = (live >> lrow) & 1ull;
-        if (skip_dead) {
-            if (on) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = lds_rows[lrow * ROW_LDS + c];
-            }
-        } else if (!acc) {
+        if (!acc) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) d_dc[3 * (size_t)i + c] = on ? lds_rows[lrow * ROW_LDS + c] : 0.f;
         } else if (on) {
@@ -403,8 +396,7 @@ __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, flo
         if (f0 + 3 < nflat) {
             float4* d4 = reinterpret_cast<float4*>(dst + f0);
             if (!acc) {
-                // (skip_dead: four consecutive floats span at most two rows; what they cover of a dead row is zero as before)
-                if (!skip_dead || on[0] || on[3]) *d4 = make_float4(v[0], v[1], v[2], v[3]);
+                *d4 = make_float4(v[0], v[1], v[2], v[3]);
             } else if (on[0] || on[3]) {             // four consecutive floats span at most two rows
                 const float4 o = *d4;
                 *d4 = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
@@ -413,7 +405,7 @@ __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, flo
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (f0 + j < nflat) {
-                    if (!acc) { if (!skip_dead || on[j]) dst[f0 + j] = v[j]; }
+                    if (!acc) dst[f0 + j] = v[j];
                     else if (on[j]) dst[f0 + j] = dst[f0 + j] + v[j];
                 }
         }
@@ -647,7 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
                                                                   const int32_t* __restrict__ radii,
                                                                   const char* __restrict__ geom,
                                                                   const grad_acc_t* __restrict__ grad_rec,
-                                                                  msgs_grads_t grads, int sparse_rows) {
+                                                                  msgs_grads_t grads) {
     // 32 rows per wave: the SH rows of a wave's 64 Gaussians pass through LDS in two runs of 32 (below).  25 KB per workgroup
     // instead of 50: the kernel is latency-bound and its time follows the occupancy (measured at C3 with 1 / 2 / 3 workgroups
     // per CU: 252 / 147 / 121 us)
@@ -680,9 +672,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
     // accumulate (several views of one optimizer step into one gradient bucket): add to what the gradient tensors hold and
     // leave the rows of Gaussians this view did not render alone — no zero rows, no separate accumulation pass
     const bool accum = grads.accumulate != 0;
-    // the gradient tensors were zero-filled by the blend backward (ZeroRegions): rows of Gaussians this view did not render are
-    // left alone (wave-uniform, never together with accum)
-    const bool sparse = sparse_rows != 0;
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
     if (staged_sh) {                         // list of the rendered lanes, ascending: the rows to fetch
@@ -945,18 +934,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
             wave_lds_fence();
             if (raw)
                 coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range && mine, first,
-                                      nrow, live_h, nfloat, lane, lrow, accum, sparse);
+                                      nrow, live_h, nfloat, lane, lrow, accum);
             else
-                coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)first * ROW_F, nrow, live_h, nfloat, lane, accum, sparse);
+                coop_store_rows(s_rows[wv], grads.dL_dshs + (size_t)first * ROW_F, nrow, live_h, nfloat, lane, accum);
         }
     } else if (do_colour) {
         // (direct per-thread rows, K != 16: accumulate mode is not offered on this path — msgs_backward refuses it)
         float* dsh = grads.dL_dshs && in_range ? grads.dL_dshs + (size_t)3 * K * i : nullptr;
         if (rendered) colour_backward(g.shs + (size_t)3 * K * i, dsh);
-        else if (dsh && !sparse) for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
+        else if (dsh) for (int k = 0; k < 3 * K; ++k) dsh[k] = 0.f;
     }
     if (!in_range) return;
-    if (sparse && !rendered) return;                          // every output row of this Gaussian is zero already
 
     // the screen-space gradient is per view (viewspace_points.grad of THIS render, scene/gaussian_model.py:698-701): stored
     if (grads.dL_dmeans2D) { grads.dL_dmeans2D[3 * i] = g2x; grads.dL_dmeans2D[3 * i + 1] = g2y; grads.dL_dmeans2D[3 * i + 2] = 0.f; }
@@ -1097,11 +1085,11 @@ hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, in
 
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
-                                      hipStream_t s, bool textbook, bool sparse) {
+                                      hipStream_t s, bool textbook) {
     if (g.P == 0) return hipSuccess;
     if (textbook) {
         hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
-                           grad_rec, grads, 0);
+                           grad_rec, grads);
         return hipGetLastError();
     }
     if (g.raw_params != 0 && grads.dL_dfeatures_dc == nullptr) {          // factored SH gradient: the factors first
@@ -1121,7 +1109,7 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
-                       grad_rec, grads, sparse && !grads.accumulate ? 1 : 0);
+                       grad_rec, grads);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && grads.accumulated) e = hipEventRecord((hipEvent_t)grads.accumulated, s);
     return e;
