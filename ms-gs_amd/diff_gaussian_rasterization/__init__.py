@@ -271,21 +271,17 @@ _last_instances = {}
 # multi-scale model rendered without its filters, /root/reference/render.py:32).  The outputs never depend on it.  Policy per
 # (device, P, W, H, filters) key:
 #   "adaptive" (default)  the pass runs on the first call and then on every OCCLUSION_PROBE_PERIOD-th call; in between it runs only
-#                         while one of the key's last OCCLUSION_PROBE_PERIOD calls closed at least one block OR found at least
-#                         OCCLUSION_MIN_CANDIDATES Gaussians with
-#                         more than 96 tile instances (msgs_forward_info: both words travel with the count).  The key does not
-#                         know the camera: the candidate count is mostly a property of the model and its filters, "closed" is a
-#                         property of the view — a sweep over views of which only some close must not switch the pass off for
-#                         the others (skipping costs milliseconds where it would have cut, running costs ~20 us where it does not)
+#                         while one of the key's last OCCLUSION_PROBE_PERIOD calls closed at least one block (msgs_forward_info:
+#                         the answer travels with the count).  The key does not know the camera: in a sweep that alternates views
+#                         that close with views that do not, the latter must not switch the pass off for the former (skipping
+#                         costs milliseconds where it would have cut, running costs ~20 us where it does not).  The number of
+#                         cover candidates is NOT a criterion: the C5 headline view has 10 751 of them and closes nothing
 #   "always" / "never"    MSGS_OCCLUSION_POLICY, or assign diff_gaussian_rasterization.occlusion_policy
 occlusion_policy = os.environ.get("MSGS_OCCLUSION_POLICY", "adaptive")
 OCCLUSION_PROBE_PERIOD = 32
-OCCLUSION_MIN_CANDIDATES = 32     # (a block needs the product of dozens of (1 - alpha_min) to reach 1e-4; the C3 headline has 4)
 _occ_countdown = {}          # key -> calls left before the next probe (absent / 0: run the pass)
 _occ_hot = {}                # key -> calls for which the pass keeps running whatever they find: refreshed to OCCLUSION_PROBE_PERIOD by
-                             # every call that closes a block or sees enough candidates.  The key does not know the camera: in a
-                             # sweep that alternates views that close with views that see nothing, the latter must not switch the
-                             # pass off for the former
+                             # every call that closes a block
 
 
 def _occlusion_skip(key):
@@ -308,7 +304,7 @@ def _occlusion_note(key, skipped):
     if len(_occ_countdown) > 256:
         _occ_countdown.clear()
         _occ_hot.clear()
-    if info[1] or info[0] >= OCCLUSION_MIN_CANDIDATES:
+    if info[1]:
         hot = OCCLUSION_PROBE_PERIOD
     else:
         hot = max(_occ_hot.get(key, 0) - 1, 0)

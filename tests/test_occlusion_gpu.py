@@ -307,8 +307,8 @@ def test_pyramid_levels_and_filters_on_are_unchanged():
 def test_adaptive_policy_probes_then_skips_then_probes_again():
     """diff_gaussian_rasterization.occlusion_policy = "adaptive" (the default): the pass runs on the first call of a (model size,
     image, filters) key; while a probe finds nothing to cut the next OCCLUSION_PROBE_PERIOD - 1 calls skip it
-    (msgs_view_t.skip_occlusion), and while it does cut — or sees enough cover candidates that another view of the same model
-    might — every call runs it.  Same image either way."""
+    (msgs_view_t.skip_occlusion), and while one of the key's last OCCLUSION_PROBE_PERIOD calls did cut, every call runs it
+    — also for a view of the same key that cuts nothing itself.  Same image either way."""
     import diff_gaussian_rasterization as dgr
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
@@ -319,9 +319,10 @@ def test_adaptive_policy_probes_then_skips_then_probes_again():
     quiet = scenes.frustum_scene(3000, W, H, seed=5, scale_k=0.004 * 1920.0 / W * 0.3)          # nothing to cut
     walls = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.9)                # opaque covers in front
     info = (C.c_int64 * 2)()
-    # many heavy Gaussians, all nearly transparent: candidates, but nothing closes — the pass must stay on for the other views
+    # many heavy Gaussians, all nearly transparent: cover candidates, but nothing closes (the C5 headline view has 10 751
+    # candidates and closes nothing) — treated like the quiet scene
     haze = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.012)
-    for sc, cuts in ((quiet, False), (walls, True), (haze, True)):
+    for sc, cuts in ((quiet, False), (walls, True), (haze, False)):
         dgr._occ_countdown.clear()
         dgr._occ_hot.clear()
         dgr._last_instances.clear()
