@@ -24,20 +24,23 @@ def hip_forward(cfg, sc, cam, st, bg, dL, occlusion=True):
     pg, pb, pf = lib.msgs_set_blend_granularity(cfg["gran"]), lib.msgs_set_backward_generation(cfg["bwd_gen"]), \
         lib.msgs_set_forward_variant(cfg["fwd_var"])
     po = lib.msgs_set_occlusion(1 if occlusion else 0)
+    ppol, dgr.occlusion_policy = dgr.occlusion_policy, "always"
     pchain = dgr.chain_reference_getters
     dgr.chain_reference_getters = bool(cfg["chain"])
     try:
+        smod = float(cfg.get("scale_mod", 1.0))
         if cfg["entry"] == "render":
-            out, pc, _ = hip_render(sc, cam, st, bg, dL)
-            return out, pc.seen, {}
+            out, pc, _ = hip_render(sc, cam, st, bg, dL, scaling_modifier=smod)
+            return out, pc.seen, {"scale_modifier": smod}
         use_col, use_cov = cfg["entry"] in ("precomp_col", "precomp_both"), cfg["entry"] in ("precomp_cov", "precomp_both")
-        out, _, okw = fuzz_cases._hip_precomp(sc, cam, st, bg, dL, use_col, use_cov)
-        return out, sc, okw
+        out, _, okw = fuzz_cases._hip_precomp(sc, cam, st, bg, dL, use_col, use_cov, smod)
+        return out, sc, dict(okw, scale_modifier=smod)
     finally:
         lib.msgs_set_blend_granularity(pg)
         lib.msgs_set_backward_generation(pb)
         lib.msgs_set_forward_variant(pf)
         lib.msgs_set_occlusion(po)
+        dgr.occlusion_policy = ppol
         dgr.chain_reference_getters = pchain
 
 
@@ -47,7 +50,11 @@ def main():
     P, W, H, seed, ms = cfg["P"], cfg["W"], cfg["H"], cfg["seed"], cfg["ms"]
     sc, cam = small_scene(P, W, H, seed, sh_degree=cfg["deg"], multiscale=ms,
                           **({"scale_k": 0.004 * 1920.0 / max(W, 8) * 0.3} if ms else {}))
-    st = dict(filter_small=ms, filter_large=ms, fade_size=cfg["fade"])
+    if not cfg.get("sh_full", True):
+        sc.shs = sc.shs[:, :(cfg["deg"] + 1) ** 2, :].contiguous()
+    sc, cam = fuzz_cases.posed(sc, cam, cfg.get("pose", "front"), cfg.get("focal", 1.0), seed)
+    filt = bool(ms and cfg.get("filters", True))
+    st = dict(filter_small=filt, filter_large=filt, fade_size=cfg["fade"])
     bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
     dL = scenes.grad_seed(W, H, seed % 97)
     base_out, seen, okw = hip_forward(cfg, sc, cam, st, bg, dL)
