@@ -104,6 +104,20 @@ static inline real alpha_window(const Geom& ge, real dx, real dy, real power) {
     return std::min(RL(0.1), RL(2e-5) + RL(1.8e-7) * (M + ge.con_cond * std::fabs(power)));      // 1.8e-7 = 3 x 2^-24
 }
 
+// Half-width of the window around power = 0 inside which ANOTHER float32 implementation may take the other branch of the
+// reference's `if (power > 0) continue` guard.  For a positive-definite conic the exponent is never positive; the guard only
+// catches roundings, i.e. pixels a hair from a Gaussian's centre, where the Gaussian has its LARGEST alpha: blended by one
+// implementation and skipped by another it changes the pixel visibly.  Besides the rounding of the three products (2^-24 of
+// their magnitude sum M each) an implementation may fold log2(opacity) into the exponent — this build's HIP kernels do: one
+// FMA chain gives log2(alpha), and the sign test becomes `log2(alpha) > log2(opacity)` — which resolves the sign only to an ulp
+// or two of log2(opacity).  Found by the 60 000-configuration sweep (profiles/r5_parity.md 2.3): a giant (conic 3e-4) whose
+// centre sits 0.014 px from a pixel centre, power = -7.5e-9, blended by the three oracle builds, skipped by the HIP kernels.
+static inline real power_sign_window(const Geom& ge, real dx, real dy) {
+    const real M = RL(0.5) * (std::fabs(ge.con[0]) * dx * dx + std::fabs(ge.con[2]) * dy * dy) + std::fabs(ge.con[1] * dx * dy);
+    const real l2o = std::fabs(std::log2(std::max(ge.opacity, RL(1e-30))));
+    return RL(1.8e-7) * M + RL(3.3e-7) * std::max(RL(1.0), l2o);       // 3 x 2^-24 M  +  2^-21 ln 2 x max(1, |log2 opacity|)
+}
+
 struct msgs_oracle_state {
     int P = 0, W = 0, H = 0, gx = 0, gy = 0;
     std::vector<Geom> geom;
@@ -426,11 +440,22 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                     if (!done) { k_end = k + 1; ++contributor; if (!ge.ghost) ++evaluated_pairs; }
                     real dx = ge.px - pxf, dy = ge.py - pyf;
                     real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
-                    if (power > 0.0f) continue;
+                    // the sign of the exponent is undecided in float32 and the Gaussian would be blended (alpha ~ opacity there)
+                    const bool power_edge = std::fabs(power) <= power_sign_window(ge, dx, dy) &&
+                                            ge.opacity * 255.0f >= 1.0f - RL(2e-5);
+                    if (power > 0.0f) {
+                        if (power_edge && !done && !ge.ghost) {                  // skipped here, blended by another implementation
+                            flag = true;
+                            uint8_t* bg_flag = &st->borderline_gauss[st->list[k]];
+#pragma omp atomic write
+                            *bg_flag = 1;
+                        }
+                        continue;
+                    }
                     real alpha = std::min(RL(0.99), ge.opacity * std::exp(power));        // Q6
                     const real win = alpha_window(ge, dx, dy, power);
                     const bool reaches = alpha * 255.0f >= 1.0f - win;
-                    const bool own_edge = std::fabs(alpha * 255.0f - 1.0f) < win;
+                    const bool own_edge = std::fabs(alpha * 255.0f - 1.0f) < win || power_edge;
                     if (done) {
                         // shadow: only how far another implementation can get
                         if (!reaches) continue;

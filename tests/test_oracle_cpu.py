@@ -361,6 +361,30 @@ def test_alpha_window_follows_the_float32_uncertainty_of_the_exponent():
         assert r.borderline.float().mean().item() < 0.01, kw
 
 
+def test_exponent_sign_decisions_within_float32_uncertainty_are_flagged():
+    """The reference skips an entry whose float32 exponent comes out positive (`if (power > 0) continue`); for a positive-definite
+    conic that only happens by rounding, a hair from a Gaussian's centre — where its alpha is largest.  Found by the 60 000-
+    configuration sweep (profiles/r5_parity.md 2.3): a giant (conic 3e-4, radius 425 px) whose centre sits 0.014 px from pixel
+    (158, 226), power = -7.5e-9: blended by all three oracle builds, skipped by the HIP kernels, which fold log2(opacity) into
+    the exponent and so resolve its sign to an ulp of log2(opacity) only.  The oracle flags the pixel and the Gaussian in every
+    build now; the flagged fraction of the image stays small."""
+    import fuzz_cases
+    from parity_utils import small_scene
+    W, H, P, seed = 453, 234, 1500, 123533
+    sc, cam = small_scene(P, W, H, seed, sh_degree=0, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.3)
+    sc.shs = sc.shs[:, :1, :].contiguous()
+    sc, cam = fuzz_cases.posed(sc, cam, "rigid", 1.0, seed)
+    st = dict(filter_small=False, filter_large=False, fade_size=0.0)
+    bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
+    d = sc.means3D.double() - cam.camera_center.double()[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    col = torch.clamp_min(to.eval_sh_color(sc.sh_degree, sc.shs.double(), d) + 0.5, 0).float()
+    for kw in ({}, {"f64": True}, {"fma": True}):
+        r = oc.rasterize(sc, cam, st, bg, use_colors_precomp=True, colors_precomp=col, scale_modifier=0.7, **kw)
+        assert bool(r.borderline[226, 158]) and bool(r.borderline_gaussians[980]), kw
+        assert r.borderline.float().mean().item() < 0.004, kw
+
+
 def test_c_oracle_clamped_projection_and_ring_camera():
     W, H = 56, 40
     sc = scenes.frustum_scene(300, W, H, seed=6, scale_k=_k(W, 1.5))
