@@ -64,6 +64,15 @@ __device__ __forceinline__ PairEval eval_pair(float A, float B2, float C, float 
     return e;
 }
 __device__ __forceinline__ float4 doubled_w(const float4& r) { return make_float4(r.x, r.y, r.z, r.w + r.w); }
+// Bound of the sign test of the exponent (SPEC Q11: an entry whose exponent comes out positive is skipped — a rounding guard, the
+// conic being positive definite).  e.p is log2(alpha) = q + log2(opacity) from ONE FMA chain, and q > 0 is tested as p > bound.
+// With bound = log2(opacity) itself (rounds 1-5) the sign of q was resolved to one ulp of log2(opacity) only: a cross term of
+// +0.6 ulp rounds the chain up and two negative terms of 0.4 ulp each are lost — an entry with q = -1e-8 was skipped a hair from
+// the centre of a giant Gaussian (found by the 60 000-configuration sweep, profiles/r5_parity.md 2.3).  The bound sits two to
+// four ulps above log2(opacity): roundings of the chain never skip; a genuinely positive exponent (an indefinite conic from a
+// degenerate covariance) still does.  One value per staged record, in a slot the walks read anyway.
+__device__ __forceinline__ float sign_test_bound(float lo) { return __fmaf_rn(fabsf(lo), 2.4e-7f, lo); }
+__device__ __forceinline__ float4 with_bound(const float4& r2, float lo) { return make_float4(r2.x, r2.y, r2.z, sign_test_bound(lo)); }
 
 // quadrant hit mask of one record (bit q: quadrant q = qx + 2*qy of the tile at (tx0, ty0))
 __device__ __forceinline__ uint32_t quadrant_mask(const float4& r0, float C, float tau2, float tx0, float ty0) {
@@ -177,7 +186,7 @@ __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, co
         const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
         const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
         const float test_T = __fmaf_rn(-T, alpha, T);
-        const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r1.y);          // power <= 0
+        const uint64_t m_pow = __builtin_amdgcn_ballot_w64(ev.p <= r2.w);          // power <= 0 (r2.w: sign_test_bound)
         const uint64_t m_alpha = __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);   // alpha >= 1/255
         const uint64_t m_stop = __builtin_amdgcn_ballot_w64(test_T < T_MIN);
         const uint64_t validm = alive & m_pow & m_alpha;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         if (tid < n) {
             const uint32_t id = ids[range.x + base + tid];
             const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
-            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = with_bound(r2, r1.y);
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
         }
         __syncthreads();
@@ -333,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
     uint32_t* __restrict__ n_contrib, unsigned long long* __restrict__ lane_stats, uint4* __restrict__ clear_ptr,
     size_t clear_n16, uint32_t* __restrict__ tile_last, uint32_t* __restrict__ order_flag) {
     __shared__ float4 s_r0[SBATCH + 1], s_r1[SBATCH + 1], s_r2[SBATCH + 1];     // slot SBATCH: the sentinel record
+    __shared__ float s_tau[SBATCH];                                             // (s_r2.w carries the sign-test bound)
     __shared__ uint32_t s_mask[SBATCH];
     __shared__ float2 s_yr[SBATCH];                                              // y-extent of the alpha >= 1/255 level set
     __shared__ float2 s_xr[MODE == 2 ? SBATCH : 1];                              // x-extent (block lists by bounding box)
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         if (tid < n) {
             const uint32_t id = ids[range.x + base + tid];
             const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
-            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = r2;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = with_bound(r2, r1.y); s_tau[tid] = r2.w;
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
             // y-extent of {f >= tau2}: |dy| <= sqrt(A tau2 / det) (levelset_rows_setup); everything when it cannot be bounded
             float ylo = -3.0e38f, yhi = 3.0e38f, xlo = -3.0e38f, xhi = 3.0e38f;
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
             if (hitq) {
                 if (MODE == 3) {               // exact 4x4 block test
                     const float4 r0 = s_r0[e];
-                    const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                    const float C = s_r1[e].x, tau2 = s_tau[e];
                     if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
                     else {
                         b0 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 3.0f, qy0, qy0 + 3.0f);
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
                     b0 = xl && yl; b1 = xh && yl; b2 = xl && yh; b3 = xh && yh;
                 } else if (STRIP_EXACT) {
                     const float4 r0 = s_r0[e];
-                    const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                    const float C = s_r1[e].x, tau2 = s_tau[e];
                     if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
                     else {
                         b0 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0, qy0 + 1.0f);
@@ -486,6 +496,7 @@ __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewPara
     constexpr int T = 64 * WAVES, G = NSB / WAVES;
     constexpr int R = (BATCH + T - 1) / T;               // records a thread stages per batch
     __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
+    __shared__ float s_tau[BATCH];                                           // (s_r2.w carries the sign-test bound)
     __shared__ __attribute__((aligned(16))) uint32_t s_list[WAVES][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
     if (threadIdx.x == 0) {
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewPara
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int e = tid + k * T;
-            if (e < n) { s_r0[e] = doubled_w(p0[k]); s_r1[e] = p1[k]; s_r2[e] = p2[k]; }
+            if (e < n) { s_r0[e] = doubled_w(p0[k]); s_r1[e] = p1[k]; s_r2[e] = with_bound(p2[k], p1[k].y); s_tau[e] = p2[k].w; }
         }
         fetch(base + BATCH);
         __syncthreads();
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(64 * WAVES) void blend_forward_fine_kernel(ViewPara
             bool hit = false;
             if (e < n) {
                 const float4 r0 = s_r0[e];
-                const float C = s_r1[e].x, tau2 = s_r2[e].w;
+                const float C = s_r1[e].x, tau2 = s_tau[e];
                 hit = !(tau2 > -1.0e38f) ||
                       levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, bx0, bx0 + (float)(SB - 1), by0,
                                          by0 + (float)(SB - 1));
@@ -619,17 +630,18 @@ struct BwdPix {
 };
 template <bool CROSS_ROW>
 __device__ __forceinline__ void backward_walk(const uint16_t* lp, int cnt, int base, const float4* s_r0, const float4* s_r1,
-                                              const float* s_b, const uint32_t* s_id, float pxf, float pyf, BwdPix& st,
+                                              const float2* s_b, const uint32_t* s_id, float pxf, float pyf, BwdPix& st,
                                               bool alane, uint32_t aoff, grad_acc_t* __restrict__ grad_rec) {
     for (int j = cnt - 1; j >= 0; --j) {
         const int e = lp[j];
         const float4 r0 = s_r0[e], r1 = s_r1[e];
-        const float cb = s_b[e];
+        const float2 bl = s_b[e];                              // {blue, sign_test_bound}
+        const float cb = bl.x;
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
         const float a_raw = __builtin_amdgcn_exp2f(ev.p);
         const uint64_t validm = __builtin_amdgcn_ballot_w64((uint32_t)(base + e) < st.last) &
-                                __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
+                                __builtin_amdgcn_ballot_w64(ev.p <= bl.y) &
                                 __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);   // <=> min(0.99, a_raw) >= 1/255
         if (validm == 0) continue;
         const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
                                                              const float* __restrict__ dL_dcolor,
                                                              grad_acc_t* __restrict__ grad_rec) {
     __shared__ float4 s_r0[BATCH], s_r1[BATCH];
-    __shared__ float s_b[BATCH];
+    __shared__ float2 s_b[BATCH];                          // {blue, sign_test_bound}
     __shared__ uint32_t s_id[BATCH];
     __shared__ uint32_t s_mask[BATCH];
     __shared__ uint16_t s_list[4][BATCH];
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(ViewParams vp, cons
             const uint32_t id = ids[range.x + base + tid];
             const float4 r0 = rec[id].r0, r1 = rec[id].r1;
             const float4 r2 = rec[id].r2;
-            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_b[tid] = r2.x; s_id[tid] = id;
+            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_b[tid] = make_float2(r2.x, sign_test_bound(r1.y)); s_id[tid] = id;
             s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
         }
         __syncthreads();
@@ -747,7 +759,8 @@ __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewPar
     constexpr int T = 64 * WAVES, G = NSB / WAVES;
     constexpr int R = (BATCH + T - 1) / T;               // records a thread stages per batch
     __shared__ float4 s_r0[BATCH], s_r1[BATCH];
-    __shared__ float s_b[BATCH], s_tau[BATCH];
+    __shared__ float2 s_b[BATCH];                          // {blue, sign_test_bound}
+    __shared__ float s_tau[BATCH];
     __shared__ uint32_t s_id[BATCH];
     __shared__ uint16_t s_list[WAVES][BATCH];
     __shared__ uint32_t s_wmax[WAVES];
@@ -810,7 +823,7 @@ __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewPar
         for (int k = 0; k < R; ++k) {
             const int e = tid + k * T;
             if (e < n) {
-                s_r0[e] = doubled_w(p0[k]); s_r1[e] = p1[k]; s_b[e] = p2[k].x; s_id[e] = pid[k];
+                s_r0[e] = doubled_w(p0[k]); s_r1[e] = p1[k]; s_b[e] = make_float2(p2[k].x, sign_test_bound(p1[k].y)); s_id[e] = pid[k];
                 s_tau[e] = p2[k].w;
             }
         }
@@ -867,7 +880,7 @@ __device__ __forceinline__ bool fwd_quad_step(FwdQuad& s, const float4& r0, cons
                                               float dx, float dy, uint32_t pos) {
     const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
     const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
-    const bool valid = !s.done && ev.p <= r1.y && alpha >= ALPHA_MIN;      // power <= 0, alpha >= 1/255
+    const bool valid = !s.done && ev.p <= r2.w && alpha >= ALPHA_MIN;      // power <= 0 (sign_test_bound), alpha >= 1/255
     const float test_T = __fmaf_rn(-s.T, alpha, s.T);
     const bool stop = valid && test_T < T_MIN;
     s.done = s.done || stop;
@@ -940,7 +953,7 @@ __global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, c
     for (int base = 0; base < len && alive; base += WB) {
         const int n = min(WB, len - base);
         wave_fence();                                     // previous batch fully consumed
-        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_r2[lane] = n2;
+        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_r2[lane] = with_bound(n2, n1.y);
         // quadrant hit masks of the whole batch as four 64-bit ballots (bit e = record e): wave-uniform, in SGPRs
         const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
         const uint64_t h0 = __ballot(mymask & 1u), h1 = __ballot(mymask & 2u), h2 = __ballot(mymask & 4u),
@@ -1017,11 +1030,11 @@ struct BwdQuad {
 //  of a derived bool costs two VALU instructions, and the caller only needs "any lane?")
 template <class A>
 __device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSumsT<A>& v, const float4& r0, const float4& r1, float cb,
-                                                  float dx, float dy, uint32_t pos0) {
+                                                  float bound, float dx, float dy, uint32_t pos0) {
     const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
     const float a_raw = __builtin_amdgcn_exp2f(ev.p);
     // alpha = min(0.99, a_raw) >= 1/255  <=>  a_raw >= 1/255
-    const uint64_t validm = __builtin_amdgcn_ballot_w64(pos0 < s.last) & __builtin_amdgcn_ballot_w64(ev.p <= r1.y) &
+    const uint64_t validm = __builtin_amdgcn_ballot_w64(pos0 < s.last) & __builtin_amdgcn_ballot_w64(ev.p <= bound) &
                             __builtin_amdgcn_ballot_w64(a_raw >= ALPHA_MIN);
     const bool valid = __builtin_amdgcn_inverse_ballot_w64(validm);
     // ONE select masks the lane: with a_m = 0 everything downstream is the identity (alpha 0, 1/(1-0) = 1 exactly,
@@ -1074,7 +1087,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                                                                  void* __restrict__ grad_out,
                                                                  const uint32_t* __restrict__ tile_order) {
     __shared__ float4 s_r0[WB], s_r1[WB];
-    __shared__ float4 s_bi[WB];                            // {blue, id bits, -, -}: 16-byte stride like s_r0 / s_r1, so one
+    __shared__ float4 s_bi[WB];                            // {blue, sign_test_bound, id bits, -}: 16-byte stride like s_r0 / s_r1, so one
                                                            // address register serves every LDS read of an entry
     const int num_tiles = vp.gx * vp.gy;
     const int lane = threadIdx.x;
@@ -1132,7 +1145,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
         const int base = b * WB;
         const int n = min(WB, (int)tile_last - base);
         wave_fence();
-        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, __uint_as_float(nid), 0.f, 0.f);
+        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_bi[lane] = make_float4(n2.x, sign_test_bound(n1.y), __uint_as_float(nid), 0.f);
         // quadrant hit masks of the batch as four 64-bit ballots; a record beyond the last blended entry of a
         // quadrant cannot matter to that quadrant
         const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
@@ -1151,24 +1164,25 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             todo &= ~bit;
             const uint32_t pos0 = (uint32_t)(base + e);   // 0-based position in the tile list
             const float4 r0 = s_r0[e], r1 = s_r1[e];
-            const float cb = s_bi[e].x;
+            const float2 bl = *reinterpret_cast<const float2*>(&s_bi[e]);      // {blue, sign_test_bound}: one 8-byte read
+            const float cb = bl.x;
             const float dx = r0.x - bxf, dy = r0.y - byf;
             BwdSumsT<typename std::conditional<DET, double, float>::type> v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint64_t any = 0;
             if constexpr (COUNT) {
                 uint64_t m;
                 cnt_visits += 1u;
-                if (h0 & bit) { m = bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
-                if (h1 & bit) { m = bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
-                if (h2 & bit) { m = bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
-                if (h3 & bit) { m = bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h0 & bit) { m = bwd_quad_step(q0, v, r0, r1, cb, bl.y, dx, dy, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h1 & bit) { m = bwd_quad_step(q1, v, r0, r1, cb, bl.y, dx - 8.0f, dy, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h2 & bit) { m = bwd_quad_step(q2, v, r0, r1, cb, bl.y, dx, dy - 8.0f, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
+                if (h3 & bit) { m = bwd_quad_step(q3, v, r0, r1, cb, bl.y, dx - 8.0f, dy - 8.0f, pos0); any |= m; cnt_steps += 1u; cnt_lanes += (uint32_t)__popcll(m); }
                 if (any) cnt_hits += 1u;
                 continue;
             }
-            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, dx, dy, pos0);
-            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, dx - 8.0f, dy, pos0);
-            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, dx, dy - 8.0f, pos0);
-            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, dx - 8.0f, dy - 8.0f, pos0);
+            if (h0 & bit) any |= bwd_quad_step(q0, v, r0, r1, cb, bl.y, dx, dy, pos0);
+            if (h1 & bit) any |= bwd_quad_step(q1, v, r0, r1, cb, bl.y, dx - 8.0f, dy, pos0);
+            if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, bl.y, dx, dy - 8.0f, pos0);
+            if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, bl.y, dx - 8.0f, dy - 8.0f, pos0);
             if (any == 0) continue;                        // no lane contributed: nothing to reduce
             if constexpr (DET) {
                 // deterministic (verification) mode: double sums over the 256 pixels, reduced in double in a fixed tree,
@@ -1193,7 +1207,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
                 const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
                 // (record id through v_readlane of a register copy and a scalar-base atomic — no 64-bit VALU multiply-add —
                 //  were measured: no difference, 357..382 us for all four combinations)
-                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].y));
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(s_bi[e].z));
                 grad_acc_t* gdst = (grad_acc_t*)grad_out + (size_t)gid * GRAD_REC_FLOATS;
                 if (alane) unsafeAtomicAdd(gdst + aoff, (grad_acc_t)outv);
             }

@@ -71,3 +71,28 @@ def test_diagnosed_configurations_stay_explained(cfg, expected):
     import fuzz_cases
     r = fuzz_cases.run_config(cfg)
     assert r["status"] in expected, (r["status"], r["detail"])
+
+
+def test_a_giant_centred_a_hair_from_a_pixel_centre_is_blended_there():
+    """The mechanism behind the exponent-sign finding (profiles/r5_parity.md 2.3), on the configuration that showed it: Gaussian 980
+    (radius 425 px) is centred 0.014 px from pixel (158, 226), its exponent there is -7.5e-9.  Until round 5 the kernels tested the
+    sign on the fused exponent against log2(opacity) itself and skipped the entry when the chain rounded up by one ulp; with the
+    bound two ulps above log2(opacity) (blend.hip, sign_test_bound) the pixel — flagged by the oracle either way — carries the
+    oracle's colour again, and so does the whole image."""
+    import fuzz_cases
+    import scenes
+    from oracle import oracle_ctypes as oc
+    from parity_utils import small_scene
+    W, H, P, seed = 453, 234, 1500, 123533
+    sc, cam = small_scene(P, W, H, seed, sh_degree=0, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.3)
+    sc.shs = sc.shs[:, :1, :].contiguous()
+    sc, cam = fuzz_cases.posed(sc, cam, "rigid", 1.0, seed)
+    st = dict(filter_small=False, filter_large=False, fade_size=0.0)
+    import torch
+    bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
+    dL = scenes.grad_seed(W, H, seed % 97)
+    out, _, okw = fuzz_cases._hip_precomp(sc, cam, st, bg, dL, True, False, 0.7)
+    orc = oc.rasterize(sc, cam, st, bg, scale_modifier=0.7, **okw)
+    d = (out["render"].detach().cpu() - orc.color).abs()
+    assert d[:, 226, 158].max().item() < 1e-5, d[:, 226, 158]
+    assert d.max().item() < 1e-5, d.max().item()
