@@ -83,8 +83,11 @@ struct OccHeader {
                               //  drops 420 M instances; run the view with msgs_set_occlusion(0) to learn the uncut count)
 };
 static_assert(sizeof(OccHeader) == 64, "OccHeader layout");
-// candidate record: { px, py, kA, kB | kC, log2 o, key bits, gaussian id }
-struct __attribute__((aligned(32))) OccCand { float4 c0, c1; };
+// candidate record: { px, py, kA, kB | kC, log2 o, key bits, gaussian id | tile rect (minx | miny << 16, maxx | maxy << 16), -, - }
+// (the rect travels with the candidate: tile instances exist only inside it, and the alpha >= 1/255 level set of an opaque
+//  Gaussian — up to 3.33 sigma along the major axis — reaches past the 3-sigma rect: a block outside the rect is never covered)
+struct __attribute__((aligned(16))) OccCand { float4 c0, c1; uint32_t rect_lo, rect_hi, pad0, pad1; };
+static_assert(sizeof(OccCand) == 48, "OccCand layout");
 
 struct GeomLayout {
     size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, skey, occ_hdr, occ_cut, total;

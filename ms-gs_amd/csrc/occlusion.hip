@@ -187,14 +187,27 @@ __global__ __launch_bounds__(256) void occ_gather_kernel(int P, const char* __re
         OccCand c;
         c.c0 = b.q0;                                                                  // px, py, kA, kB(half)
         c.c1 = make_float4(b.q1.x, rec[ge.x].r1.y, __uint_as_float(ge.y), __uint_as_float(ge.x));   // kC, log2 o, depth key, id
+        c.rect_lo = __float_as_uint(b.q1.z);                                          // minx | miny << 16   (tiles)
+        c.rect_hi = __float_as_uint(b.q1.w);                                          // maxx | maxy << 16   (exclusive)
+        c.pad0 = c.pad1 = 0u;
         cand[by_depth ? s_base + e : (s_prefix[ls] + j) / stride] = c;
     }
 }
 
-// fixed-point weight -log2(1 - alpha_min) of candidate c over the pixel-centre rectangle [x0, x1] x [y0, y1], 0 when the
-// level set does not contain the rectangle
-__device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, float x1, float y0, float y1) {
+// fixed-point weight -log2(1 - alpha_min) of candidate c over the pixel-centre rectangle [x0, x1] x [y0, y1] of the block of
+// tiles [tx0, tx1) x [ty0, ty1); 0 when the level set does not contain the rectangle — or when the block is not inside the
+// candidate's tile RECT: count, emit and recount clip every Gaussian to its rect (radius = ceil(3 sqrt(lambda_max)), Q4/Q5),
+// while the alpha >= 1/255 level set of an opaque Gaussian reaches up to 3.33 sigma along the major axis.  A tile outside the
+// rect holds no instance of the Gaussian, so none of its pixels loses transmittance to it (a giant centred off-screen whose
+// rect ends inside a block would otherwise add a phantom weight to tiles it is never blended in).
+__device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, float x1, float y0, float y1, int tx0, int tx1,
+                                                 int ty0, int ty1) {
 #pragma clang fp contract(off)
+    {
+        const int minx = (int)(c.rect_lo & 0xFFFFu), miny = (int)(c.rect_lo >> 16);
+        const int maxx = (int)(c.rect_hi & 0xFFFFu), maxy = (int)(c.rect_hi >> 16);
+        if (tx0 < minx || tx1 > maxx || ty0 < miny || ty1 > maxy) return 0u;
+    }
     const float px = c.c0.x, py = c.c0.y, A = c.c0.z, Bh = c.c0.w, Cc = c.c1.x, l2o = c.c1.y;
     const float dxa = px - x0, dxb = px - x1, dya = py - y0, dyb = py - y1;
     // f(d) = A dx^2 + 2 Bh dx dy + C dy^2 = log2 G(d) <= 0, concave: its minimum over the rectangle is at a corner
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams
         const float x0 = (float)(tx0 * TILE), y0 = (float)(ty0 * TILE);
         const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);   // pixels inside the image
         auto add = [&](const OccCand& cc) {
-            const uint32_t w = cover_weight(cc, x0, x1, y0, y1);
+            const uint32_t w = cover_weight(cc, x0, x1, y0, y1, tx0, tx1, ty0, ty1);
             if (w) atomicAdd(&s_b[occ_bucket(__float_as_uint(cc.c1.z))], w);
         };
         uint32_t c = threadIdx.x;

@@ -194,6 +194,57 @@ def test_covers_at_the_skip_threshold_and_partial_covers():
         _assert_identical(on, off, ("threshold covers", k))
 
 
+def test_giants_centred_off_screen_whose_rect_ends_inside_a_block():
+    """Round-5 advisor finding: a cover counts for a block only where tile instances of it EXIST, i.e. inside its 3-sigma tile
+    rect (Q4 / Q5); the alpha >= 1/255 level set of an opaque Gaussian reaches 3.33 sigma.  3000 opaque giants centred 880 px
+    left of a 1080p image, sigma 300 px: their rects end in tile column 1..2, their level sets contain all of block column 0
+    (tiles 0..3).  Before the fix the blocks of column 0 closed on those phantom covers and the Gaussians behind them in tile
+    columns 2..3 — which hold no instance of any giant — lost their instances: wrong image and gradients.  On / off bit-identical,
+    and the Gaussians behind are really drawn."""
+    W, H = 1920, 1080
+    cam = scenes.front_camera(W, H).to("cuda")
+    bg = torch.tensor([0.05, 0.1, 0.2], device="cuda")
+    dL = scenes.grad_seed(W, H, 11).cuda()
+    f = 1000.0
+    sc = scenes.frustum_scene(6000, W, H, seed=61, scale_k=0.004 * 0.5)
+    g = torch.Generator().manual_seed(62)
+    n = 3000
+    idx = torch.arange(n)
+    z = 1.0 + 0.2 * torch.rand(n, generator=g)
+    sigma = 300.0 + 10.0 * torch.rand(n, generator=g)                       # px
+    px = 18.0 + 14.0 * torch.rand(n, generator=g) - 3.0 * sigma             # rect ends at px 18..32 -> tile column 1 or 2
+    py = 540.0 + 80.0 * (2.0 * torch.rand(n, generator=g) - 1.0)
+    sc.means3D[idx, 0] = (px - W / 2) * z / f
+    sc.means3D[idx, 1] = (py - H / 2) * z / f
+    sc.means3D[idx, 2] = z
+    # flat discs facing the camera (no extent along z): off-axis the Jacobian's z column would otherwise widen the footprint
+    sc.scales[idx] = torch.stack([sigma * z / f, sigma * z / f, torch.full((n,), 1e-4)], dim=1)
+    sc.rotations[idx] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    sc.opacities[idx, 0] = 0.99
+    # Gaussians BEHIND the giants in tile columns 2..3 of block column 0 (px 36..62), around the giants' rows
+    m = 200
+    jdx = torch.arange(n, n + m)
+    zb = 4.0 + torch.rand(m, generator=g)
+    pxb = 36.0 + 26.0 * torch.rand(m, generator=g)
+    pyb = 540.0 + 120.0 * (2.0 * torch.rand(m, generator=g) - 1.0)
+    sc.means3D[jdx, 0] = (pxb - W / 2) * zb / f
+    sc.means3D[jdx, 1] = (pyb - H / 2) * zb / f
+    sc.means3D[jdx, 2] = zb
+    sc.scales[jdx] = (2.0 * zb / f)[:, None].expand(m, 3).clone()
+    sc.opacities[jdx, 0] = 0.9
+    on = _run(sc, cam, PLAIN, bg, dL, True)
+    off = _run(sc, cam, PLAIN, bg, dL, False)
+    print(f"[occlusion] off-screen giants: D {off[2]} -> {on[2]}, {on[3]}")
+    _assert_identical(on, off, "off-screen giants")
+    assert on[3]["ran"] == 1 and on[3]["candidates"] >= n // 2, on[3]
+    # the scene is what it claims to be: the giants' rects end inside block column 0 and the Gaussians behind are rendered
+    assert (off[0]["radii"][n:n + m] > 0).sum().item() > m // 2
+    grad_behind = getattr(off[1], "_opacity").grad[n:n + m].abs().sum().item()
+    print(f"[occlusion] off-screen giants: rendered behind {(off[0]['radii'][n:n + m] > 0).sum().item()} of {m}, "
+          f"sum |dL/dopacity| behind {grad_behind:.3e}, giants' radii {off[0]['radii'][:n].min().item()}..{off[0]['radii'][:n].max().item()}")
+    assert grad_behind > 0.0
+
+
 def test_a_view_that_really_closes_blocks_matches_the_oracle():
     """the bit-identity tests compare the library with itself; here a giants scene whose blocks do close is compared with the CPU
     oracle directly (forward <= 1e-5 off the flagged pixels, gradients <= 1e-4 on the unflagged Gaussians) with the pass forced on"""
