@@ -278,8 +278,7 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=11, warmup=3):
         cam0_ = scenes.front_camera(W0, H0).to(dev)
         key0 = (dev.index, int(pc.get_xyz.shape[0]), W0, H0, 0, 0)
 
-        def count_and_time(policy, switch):
-            prev_p, dgr.occlusion_policy = dgr.occlusion_policy, policy
+        def count_and_time(switch):
             prev_s = dgr._C.lib.msgs_set_occlusion(switch)
             try:
                 dgr._last_instances.pop(key0, None)
@@ -288,9 +287,8 @@ def pyramid_timing(scenes, pc, settings, bg, dev, steps=11, warmup=3):
                 return int(dgr._last_instances.get(key0, -1)), round(t_, 4)
             finally:
                 dgr._C.lib.msgs_set_occlusion(prev_s)
-                dgr.occlusion_policy = prev_p
-        d_on, t_on = count_and_time("always", 1)
-        d_off, t_off = count_and_time("never", 0)
+        d_on, t_on = count_and_time(1)
+        d_off, t_off = count_and_time(0)
         occ = {"instances": d_on, "ms": t_on, "instances_uncut": d_off, "ms_uncut": t_off,
                "what": "level 0, render.py's default flags: with the exact per-tile occlusion cut-off (default) and with it switched off "
                        "(msgs_set_occlusion(0)); bit-identical images (tests/test_occlusion_gpu.py)"}
@@ -468,7 +466,16 @@ def config_leg(name, scenes, dev, steps=20, warmup=3):
         out = render(cam, pc, PIPE, bg, **st)
         out["render"].backward(dL)
         return out
-    med, ts = period_median(step, steps, warmup, torch.cuda.synchronize)
+    # depth-slab binning: the wrapper's adaptive policy engages it from the library's D / D_trav feedback — three
+    # warm-up frames are what it needs; the same steps single-pass for comparison
+    single = None
+    if name == "C5":
+        prev_pol, dgr.slab_policy = dgr.slab_policy, "never"
+        try:
+            single = period_median(step, steps, warmup, torch.cuda.synchronize)[0]
+        finally:
+            dgr.slab_policy = prev_pol
+    med, ts = period_median(step, steps, max(warmup, 4), torch.cuda.synchronize)
     timers = [dgr._C.KernelTimer() for _ in range(3)]
     for t_ in timers:
         dgr._C.set_timer(t_)
@@ -484,6 +491,22 @@ def config_leg(name, scenes, dev, steps=20, warmup=3):
     out = step()
     torch.cuda.synchronize()
     D, D_trav, V = binning_counts(dgr, out["render"].grad_fn, P, dev)
+    slab = None
+    try:
+        import ctypes as C_
+        ctx_ = out["render"].grad_fn
+        geom_ = dgr._resolve(ctx_.state)[0]
+        o_ = (C_.c_int64 * 6)()
+        dgr._C.check(dgr._C.lib.msgs_slab_stats(C_.c_void_p(geom_.data_ptr()), geom_.numel(), P, o_,
+                                                C_.c_void_p(torch.cuda.current_stream().cuda_stream)), "msgs_slab_stats")
+        if int(o_[0]):
+            slab = {"fraction": round(float(ctx_.call.view.slab_fraction), 4), "ranks_in_slab_a": int(o_[1]),
+                    "instances_slab_a": int(o_[2]), "tiles_left_open": int(o_[3]), "instances_slab_b": int(o_[4]),
+                    "instances_binned": int(o_[2]) + int(o_[4]), "instances_single_pass": D,
+                    "ms_per_step_single_pass": round(single, 4) if single is not None else None,
+                    "how": "wrapper's adaptive policy (slab_policy = 'adaptive'): engaged from the library's D / D_trav feedback"}
+    except Exception as e:                  # informational
+        slab = {"error": repr(e)}
     alg = algorithmic_bytes(P, W, H, D, D_trav, V)
     total = float(sum(alg.values()))
     peak = int(torch.cuda.max_memory_allocated(dev))
@@ -497,6 +520,10 @@ def config_leg(name, scenes, dev, steps=20, warmup=3):
            "whole_step": {"algorithmic_bytes": int(total), "GBps": round(total / (med * 1e-3) / 1e9, 1),
                           "frac": round(total / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
            "peak_device_bytes": peak}
+    if slab is not None:
+        res["depth_slabs"] = slab
+    elif single is not None:
+        res["depth_slabs"] = {"engaged": False, "ms_per_step_single_pass": round(single, 4)}
     del pc, out, dL
     torch.cuda.empty_cache()
     return res

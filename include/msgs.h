@@ -26,12 +26,13 @@
  *
  * Threading: re-entrant (forward is called from the Python main thread, backward from PyTorch's
  * autograd thread).  Not stateless:
- *   - five PROCESS-WIDE mode flags: msgs_set_deterministic, msgs_set_backward_generation, msgs_set_blend_granularity,
- *     msgs_set_forward_variant, msgs_set_occlusion (the last four only choose between code paths that give the same results);
- *   - environment switches latched on first use (process-wide, for A/B measurements; every one only selects between
- *     code paths with the same results): MSGS_BLOCKING_SYNC, MSGS_NO_SPECULATIVE_STAGE2, MSGS_BWD_LPT,
- *     MSGS_SORT_TILE_PASSES, MSGS_SORT_NO_COMPACT, MSGS_SORT_ONESWEEP, MSGS_SORT_SCAN_TABLE, MSGS_SORT_DIRECT_SCATTER,
- *     MSGS_FINE_SB, MSGS_FINE_SPLIT, MSGS_NO_OCCLUSION, MSGS_OCC_BLOCK (full list with meanings: INTEGRATION.md §3);
+ *   - four PROCESS-WIDE mode flags: msgs_set_deterministic, msgs_set_backward_generation, msgs_set_blend_granularity,
+ *     msgs_set_occlusion (the last three only choose between code paths that give the same results);
+ *   - six environment variables latched on first use (process-wide): the initial values of the four flags
+ *     (MSGS_DETERMINISTIC, MSGS_BWD_GEN, MSGS_BLEND_GRANULARITY, MSGS_NO_OCCLUSION) and MSGS_BLOCKING_SYNC,
+ *     MSGS_NO_SPECULATIVE_STAGE2 — how the host learns the instance count; none changes a result.
+ *     The A/B switches of rounds 1-5 (sort / scan / emit / forward-list variants, MSGS_DEPTH_SORT_BEGIN_BIT) are gone from the
+ *     product together with the code paths they selected;
  *   - one 64-byte pinned status block per calling host thread for the calls that WAIT for the instance count
  *     (msgs_forward, msgs_forward_stage1), and one per msgs_status_t handle for msgs_forward_launch /
  *     msgs_forward_finish — any number of forwards may be in flight from one host thread on any streams, one per handle.
@@ -48,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 9
+#define MSGS_ABI_VERSION 10
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -74,12 +75,31 @@ typedef struct msgs_view {
     int32_t filter_large;     /* bool */
     int32_t prefiltered;      /* bool (accepted; the reference always passes False)                  */
     int32_t debug;            /* bool: synchronise + return the first HIP error after every stage   */
-    int32_t skip_occlusion;   /* bool (not a reference field): "an ordinary view" — this call renders without the occlusion
-                               * cut-off pass (four small launches) even when msgs_set_occlusion is on, and without the queue
-                               * for Gaussians with many instances (one launch): same outputs, only the instance count may
-                               * differ; a caller that renders similar views in a loop sets it while msgs_forward_info says
-                               * the pass found nothing to cut, and re-probes now and then                                  */
-    int32_t reserved0;        /* 0 */
+    int32_t no_heavy_queue;   /* bool (not a reference field), a performance hint only: "an ordinary view" — Gaussians with more than
+                               * 96 tile instances are emitted by their wave inside the emit kernel instead of being queued for a
+                               * second launch that gives each a workgroup (binning.hip).  The queue pays off when opaque covers
+                               * closed blocks and the nearest depth ranks are all giants (0.28 -> 0.05 ms on the multi-scale model
+                               * rendered without its filters); on an ordinary view it is one wasted launch (~3 us).  A caller that
+                               * renders similar views in a loop sets it while msgs_forward_info says no block closed lately.
+                               * Same outputs either way                                                                      */
+    int32_t feedback_tag;     /* (not a reference field) non-zero: the forward ends with one small kernel that publishes what
+                               * this view cost — instances D, traversed tile-list entries D_trav (sum over tiles of the last list
+                               * position any pixel blended), and the slab numbers below — together with this tag in the pinned
+                               * status block; msgs_forward_info returns the most recent publication, so a caller that renders
+                               * similar views in a loop learns, one frame late and without any synchronisation, whether depth
+                               * slabs pay off for that kind of view.  0: nothing is published (no extra launch)               */
+    float slab_fraction;      /* (not a reference field) > 0: DEPTH-SLAB BINNING (round 6).  Stage 2 first bins and blends only the
+                               * nearest depth ranks — up to this fraction of the D tile instances (slab A) —; the forward blend
+                               * marks the tiles in which a pixel is still blending at the end of its slab-A list; the rest of
+                               * the view (slab B) is then counted, emitted and sorted into THOSE tiles only (their complete
+                               * lists, slab-A entries included) and they are blended again over the complete list.  A tile
+                               * whose every pixel terminated inside slab A never evaluates an entry behind it (Q7), so every
+                               * output, n_contrib, final_T and every gradient is bit-identical to the single-pass path; what
+                               * shrinks is the work of emit / tile sort / ranges on instances nobody walks (BASELINE C5: 54.9 M
+                               * instances, 4.35 M walked).  Needs binning >= msgs_binning_bytes_slab(D, W, H, fraction); ignored
+                               * (single pass) with fewer than 2048 tiles, in deterministic mode, with fine blend granularity
+                               * forced, or when the buffers are too small.  0: single pass                                  */
+    int32_t reserved1;        /* 0 */
     const float* bg;          /* [3]   device                                                        */
     const float* viewmatrix;  /* [16]  device; world_view_transform = W2C^T row-major (cameras.py:54) */
     const float* projmatrix;  /* [16]  device; full_proj_transform (cameras.py:55-56)                */
@@ -162,7 +182,9 @@ typedef struct msgs_grads {
 enum {
     MSGS_K_PREPROCESS = 0, MSGS_K_DEPTH_SORT = 1, MSGS_K_SCAN = 2, MSGS_K_EMIT = 3,
     MSGS_K_TILE_SORT = 4, MSGS_K_RANGES = 5, MSGS_K_BLEND_FWD = 6, MSGS_K_BLEND_BWD = 7,
-    MSGS_K_PREPROCESS_BWD = 8, MSGS_K_COUNT = 9
+    MSGS_K_PREPROCESS_BWD = 8,
+    MSGS_K_SLAB_B = 9,        /* slab mode only: the whole second pass (count, scan, emit, tile sort, ranges, blend of the open tiles) */
+    MSGS_K_COUNT = 10
 };
 typedef struct msgs_timing {
     void* ev[2 * MSGS_K_COUNT];   /* hipEvent_t handles created by the caller (msgs_timing_create) */
@@ -178,6 +200,10 @@ size_t msgs_geom_bytes(int32_t P);
 size_t msgs_stage1_scratch_bytes(int32_t P);
 /* per-instance state written by stage 2 (sorted Gaussian ids + tile ranges), read by backward */
 size_t msgs_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
+/* the same for a call with msgs_view_t.slab_fraction = fraction > 0: room for slab A's instances in front of the open tiles'
+ * complete lists (<= (1 + fraction) D + one instance per tile) */
+size_t msgs_binning_bytes_slab(int64_t num_instances, int32_t width, int32_t height, float slab_fraction);
+size_t msgs_stage2_scratch_bytes_slab(int64_t num_instances, int32_t width, int32_t height);
 /* scratch of stage 2 (tile sort double buffers, histograms); dead after stage 2 returns */
 size_t msgs_stage2_scratch_bytes(int64_t num_instances, int32_t width, int32_t height);
 /* per-pixel state written by stage 2 (final transmittance, last contributor), read by backward */
@@ -270,7 +296,7 @@ int msgs_binning_stats(const msgs_view_t* view, int32_t P, const int32_t* radii,
                        void* scratch, size_t scratch_bytes,
                        int64_t* out_host, void* stream);
 
-/* Diagnostic: lane efficiency of the blend kernels.  Replays the blend forward in use (msgs_set_forward_variant) and — when
+/* Diagnostic: lane efficiency of the blend kernels.  Replays the quadrant-list blend forward and — when
  * image_state is given — the one-wave-per-tile backward on the state a forward left behind (nothing is written to geom / binning /
  * image or to any output) with scalar counters:
  *   out_host[0] = forward (wave, entry) evaluations — each evaluates 64 lanes; [1] = lanes still blending summed over them;
@@ -309,16 +335,6 @@ int msgs_set_backward_generation(int32_t gen);
  * MSGS_BLEND_GRANULARITY.  Returns the previous value. */
 int msgs_set_blend_granularity(int32_t mode);
 
-/* Which blend-forward kernel msgs_forward_stage2 launches at or above the fine-grained threshold: 0 = the default,
- * 1 = quadrant lists (one wave64 per 8x8 pixel quadrant, one entry list per wave), 2 = one wave per tile, 3 = strip lists
- * (same mapping as 1, but each 16-lane row of a wave — an 8x2 pixel strip — walks its own entry list, the four rows in lock
- * step; strips chosen by the y-extent of the alpha >= 1/255 level set), 4 = strip lists with the exact 8x2 rectangle test,
- * 5 = 4x4 BLOCK lists (a 16-lane row owns a 4x4 pixel block of the quadrant; blocks chosen by the bounding box of the level
- * set), 6 = block lists with the exact 4x4 rectangle test.  All variants evaluate every pixel with the same instructions in
- * the same order: outputs are bit-identical; for the parity tests and A/B measurements (none of 3-6 beats 1: DESIGN.md 4.1).
- * Initial value from MSGS_FWD_GEN.  Returns the previous value. */
-int msgs_set_forward_variant(int32_t variant);
-
 /* Exact per-tile occlusion cut-off (round 5; process-wide switch, on by default, initial value off with MSGS_NO_OCCLUSION=1).
  * Between the per-Gaussian stage and the depth sort the forward finds, per block of tiles, the view depth behind which every
  * pixel of the block has provably met the reference's termination rule T (1 - alpha) < 1e-4 — from the Gaussians whose
@@ -326,8 +342,11 @@ int msgs_set_forward_variant(int32_t variant);
  * back with a factor 2 of slack — and neither counts, emits nor sorts the tile instances behind it.  The lists the pixels
  * walk are unchanged entry for entry: every output and gradient is bit-identical to the uncut path; only the instance count D
  * shrinks (the multi-scale model rendered without its filters, /root/reference/render.py:32: 427 M -> a few million at
- * 1080p).  msgs_set_occlusion returns the previous value.
- * msgs_occlusion_stats reads what the pass did for the forward that last wrote `geom`: out_host[8] = {ran (0 / 1), Gaussians
+ * 1080p).  One launch (a persistent grid, four phases behind grid barriers); a view without cover candidates leaves it after
+ * the first barrier (~5 us), so the pass runs on EVERY forward while the switch is on.  msgs_set_occlusion returns the
+ * previous value.
+ * msgs_occlusion_stats reads what the pass did for the forward that last wrote `geom`: out_host[8] = {ran (0 / 1; 2 = a barrier
+ * wait of the pass expired: the cut is valid but weaker — never observed), Gaussians
  * with more than 96 tile instances, cover candidates kept from them (the nearest by depth, at most 32 768), cover blocks that received a cut-off,
  * cover blocks of the view, tiles per side of a cover block, smallest and largest cut-off (float32 bits of a view depth;
  * 0xFFFFFFFF = a block stayed open)}.  (The instances removed = the instance count of the same view with the pass switched
@@ -335,9 +354,17 @@ int msgs_set_forward_variant(int32_t variant);
 int msgs_set_occlusion(int32_t on);
 /* What the last forward that RETURNED ITS INSTANCE COUNT on the calling host thread (msgs_forward, msgs_forward_stage1,
  * msgs_forward_finish) learned besides the count — the words travel with it, no extra device access: out_host[0] = cover
- * candidates of its occlusion pass (0 when the pass did not run), out_host[1] = 1 when the pass closed at least one block. */
+ * candidates of its occlusion pass (0 when the pass did not run), out_host[1] = 1 when the pass closed at least one block.
+ * out_host[2..7] = the most recent FEEDBACK publication that has landed in the status block of that forward (the thread's, or
+ * the msgs_status_t handle's) — normally that of an EARLIER forward, its stage 2 having finished since:
+ *   [2] its msgs_view_t.feedback_tag (0: none yet), [3] its instance count D, [4] its D_trav, [5] tiles left open by slab A
+ *   (-1: it ran single-pass), [6] instances of slab A, [7] instances slab B emitted.  out_host holds 8 values. */
 int msgs_forward_info(int64_t* out_host);
 int msgs_occlusion_stats(const void* geom, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream);
+/* Diagnostic: what depth-slab binning did for the forward that last wrote `geom`: out_host[6] = {ran in slab mode (0 / 1), depth
+ * ranks in slab A, instances of slab A, tiles slab A left open, instances slab B emitted, overflow flag (always 0)}.
+ * Synchronises `stream`. */
+int msgs_slab_stats(const void* geom, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream);
 
 /* msgs_forward: both stages in ONE call.  The caller passes `binning` and `scratch2` sized for a GUESS of the instance count
  * (the previous frame's D plus a margin).  Stage 1 is launched, stage 2 is launched right behind it on those buffers — sized for

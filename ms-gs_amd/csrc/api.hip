@@ -98,6 +98,14 @@ size_t msgs_stage2_scratch_bytes(int64_t D, int32_t W, int32_t H) {
     const Stage2Scratch L(D);
     return L.total + align256(4 * (size_t)(D > 0 ? D : 1));   // + sorted key buffer
 }
+static int64_t tiles_of(int32_t W, int32_t H) { return (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+size_t msgs_binning_bytes_slab(int64_t D, int32_t W, int32_t H, float fraction) {
+    if (!(fraction > 0.f)) return msgs_binning_bytes(D, W, H);
+    return msgs_binning_bytes(SlabGeom::ids_needed(D > 0 ? D : 1, (double)fraction, tiles_of(W, H)), W, H);
+}
+size_t msgs_stage2_scratch_bytes_slab(int64_t D, int32_t W, int32_t H) {
+    return msgs_stage2_scratch_bytes((D > 0 ? D : 1) + SLAB_SLACK + 256, W, H);
+}
 size_t msgs_image_bytes(int32_t W, int32_t H) { return ImageLayout(W, H).total; }
 size_t msgs_backward_scratch_bytes(int32_t P) {
     return align256(GRAD_REC_BYTES * (size_t)(P > 0 ? P : 1));
@@ -109,7 +117,6 @@ int msgs_set_deterministic(int32_t on) { return g_deterministic.exchange(on ? 1 
 int msgs_get_deterministic(void) { return g_deterministic.load(); }
 int msgs_set_backward_generation(int32_t gen) { return set_backward_generation(gen); }
 int msgs_set_blend_granularity(int32_t mode) { return set_blend_granularity(mode); }
-int msgs_set_forward_variant(int32_t variant) { return set_forward_variant(variant); }
 int msgs_set_occlusion(int32_t on) { return set_occlusion(on); }
 
 }  // extern "C"
@@ -134,13 +141,12 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                         void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes, void* image_v,
                         size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
                         size_t grad_records_bytes, int backward_follows, const msgs_timing_t* timing, void* stream,
-                        const uint32_t* D_dev);
+                        const uint32_t* D_dev, uint64_t* fb_dev, uint64_t fb_ticket);
 
 // The instance count D comes back through three pinned, device-mapped host words {D, flags, ticket} that a kernel writes
 // itself and the host polls: no copy command, no interrupt-driven wait (a blocking hipStreamSynchronize wakes up tens of
-// microseconds after the data landed, and until stage 2 is launched the GPU idles).  In the default sort/scan configuration
-// the scan's middle kernel — where the grand total is final — writes them, so the host learns D while the last stage-1
-// kernel still runs.  MSGS_BLOCKING_SYNC=1, or a failed pinned allocation, falls back to a 16-byte copy +
+// microseconds after the data landed, and until stage 2 is launched the GPU idles).  Block 0 of the scan's second kernel —
+// which sums every block total — writes them first thing, so the host learns D while the last stage-1 kernel still runs.  MSGS_BLOCKING_SYNC=1, or a failed pinned allocation, falls back to a 16-byte copy +
 // hipStreamSynchronize.  msgs_forward / msgs_forward_stage1 use one block per calling host thread (they wait before they
 // return); msgs_forward_launch takes the block of the caller's msgs_status_t, so that any number of forwards can be in
 // flight from one thread, one per handle.
@@ -158,7 +164,7 @@ struct StatusBlock {
             if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
                 host = (uint64_t*)h;
                 dev = (uint64_t*)d;
-                host[2] = 0;
+                for (int k = 0; k < 8; ++k) host[k] = 0;
             } else {
                 (void)hipHostFree(h);
             }
@@ -184,6 +190,8 @@ struct PendingCount {
 
 // {cover candidates, any block closed} of the last forward whose count this host thread collected (msgs_forward_info)
 thread_local uint64_t t_last_info = 0;
+// words 4..7 of the status block as they stood when that count was collected: the feedback publication of an earlier forward
+thread_local uint64_t t_last_feedback[4] = {0, 0, 0, 0};
 
 static bool blocking_sync() {
     static const bool blocking = [] { const char* e = getenv("MSGS_BLOCKING_SYNC"); return e && e[0] == '1'; }();
@@ -212,20 +220,17 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
 
     // K1 also clears the depth sort's group-sum table (saves a fill launch) and the header of the occlusion cut-off
     // (enabled = 0, no candidates: what the emit reads when the pass does not run)
-    ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.occ_hdr), sizeof(OccHeader) / 4 + (size_t)OCC_BUCKETS};
-    // MSGS_DEPTH_SORT_BEGIN_BIT=8: a TIMING EXPERIMENT, never a mode — the depth sort skips its lowest byte (three passes; ties
-    // inside 256 ulps of depth fall back to index order, which is not the reference's order): the cost of one radix pass inside
-    // the whole step, i.e. the upper bound of what a three-pass (9-bit digit) depth sort could save (profiles/r5_notes.md)
-    static const int depth_begin_bit = [] { const char* e = getenv("MSGS_DEPTH_SORT_BEGIN_BIT"); return (e && atoi(e) == 8) ? 8 : 0; }();
-    const bool sort1_prezeroed = radix_sort_zero_region(P, depth_begin_bit, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
+    ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.slab_hdr), (GL.occ_hdr - GL.slab_hdr) / 4 + sizeof(OccHeader) / 4 + (size_t)OCC_BUCKETS};
+    const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
     // exact per-tile occlusion cut-off (occlusion.hip): on unless switched off
-    const bool occlusion = get_occlusion() != 0 && view->skip_occlusion == 0;
+    const bool occlusion = get_occlusion() != 0;
     uint32_t* heavy_list = occlusion ? (uint32_t*)(scratch + SL.heavy_list) : nullptr;
     uint32_t* heavy_count = occlusion ? (uint32_t*)(scratch + SL.heavy_count) : nullptr;
+    uint32_t* heavy_blk = occlusion ? (uint32_t*)(scratch + SL.heavy_blk) : nullptr;
     tm.begin(MSGS_K_PREPROCESS);
-    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, heavy_list, heavy_count));
-    if (occlusion)      // (timed with K1: four small launches, 16-21 us when nothing closes; the wrapper's adaptive policy skips them)
-        HIP_TRY(launch_occlusion(vp, P, geom, heavy_list, heavy_count, (OccCand*)(scratch + SL.occ_cand), s));
+    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, heavy_list, heavy_count, heavy_blk));
+    if (occlusion)      // (timed with K1: two launches that leave at once when the view has no cover candidates)
+        HIP_TRY(launch_occlusion(vp, P, geom, heavy_list, heavy_count, heavy_blk, (OccCand*)(scratch + SL.occ_cand), s));
     tm.end(MSGS_K_PREPROCESS);
     if ((rc = debug_sync(view, s))) return rc;
 
@@ -233,7 +238,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     // the emit compares them with the tiles' cut-off keys
     tm.begin(MSGS_K_DEPTH_SORT);
     HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(geom + GL.skey),
-                             (uint32_t*)(geom + GL.order), P, depth_begin_bit, 32, scratch + SL.sort, s, sort1_prezeroed,
+                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed,
                              (uint32_t*)(geom + GL.nvalid)));
     tm.end(MSGS_K_DEPTH_SORT);
     if ((rc = debug_sync(view, s))) return rc;
@@ -241,30 +246,19 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     if (!blocking_sync()) sb.ensure();
     const bool polled = !blocking_sync() && sb.host != nullptr;
     const uint64_t ticket = ++sb.ticket;
-    const bool classic = use_classic_sort();
     uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
     uint64_t* status_dev = total_dev + 2;
     uint32_t* clamped_dev = (uint32_t*)(total_dev + 5);       // min(D, capacity) for a speculative stage 2
-    if (spec && !classic) {                                   // (the look-back scan variant does not write it):
-        spec->capacity = 0;                                   // tell the caller that stage 2 was NOT launched
-        spec = nullptr;
-    }
 
     tm.begin(MSGS_K_SCAN);
     HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
-                               classic ? status_dev : nullptr, classic && polled ? sb.dev : nullptr, ticket,
+                               status_dev, polled ? sb.dev : nullptr, ticket,
                                (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
                                spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr),
                                // the speculative stage 2's queue of heavy Gaussians starts empty (binning.hip)
                                spec ? (uint32_t*)((char*)spec->scratch2 + Stage2Scratch(spec->capacity).heavy_q) : nullptr));
     tm.end(MSGS_K_SCAN);
-    if (!classic) {        // look-back sort / scan variants: watchdog flags join the status in a final tiny kernel
-        const SortScratch SSL(P);
-        HIP_TRY(launch_collect_status(total_dev, (const uint32_t*)(scratch + SL.sort + SSL.hist) + 4 * 256 + 4,
-                                      (const uint32_t*)(scratch + SL.scan_partials + 8 * (size_t)scan_blocks(P)) + 1,
-                                      status_dev, polled ? sb.dev : nullptr, ticket, s));
-    }
     pend.active = true;
     pend.polled = polled;
     pend.stream = s;
@@ -275,14 +269,15 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
         spec->launched_rc = forward_stage2_impl(view, g, geom_v, geom_bytes, spec->capacity, spec->binning, spec->binning_bytes,
                                                 spec->scratch2, spec->scratch2_bytes, spec->image, spec->image_bytes,
                                                 spec->out_color, spec->out_acc_ps, spec->out_depth, spec->grad_records,
-                                                spec->grad_records_bytes, spec->backward_follows, timing, stream, clamped_dev);
+                                                spec->grad_records_bytes, spec->backward_follows, timing, stream, clamped_dev,
+                                                polled ? sb.dev : nullptr, ticket);
     return MSGS_OK;
 }
 
 // Waits until the count of `pend` has landed (polls the pinned words; falls back to a device copy + synchronise).
 int forward_stage1_wait(PendingCount& pend, int64_t* num_instances_host) {
     *num_instances_host = 0;
-    if (!pend.active) { t_last_info = 0; return MSGS_OK; }      // P == 0
+    if (!pend.active) { t_last_info = 0; for (int k = 0; k < 4; ++k) t_last_feedback[k] = 0; return MSGS_OK; }      // P == 0
     pend.active = false;
     hipStream_t s = pend.stream;
     uint64_t host_status[3] = {0, 0, 0};
@@ -302,7 +297,15 @@ int forward_stage1_wait(PendingCount& pend, int64_t* num_instances_host) {
             }
         }
         if (hv[2] == ticket) { host_status[0] = hv[0]; host_status[1] = hv[1]; host_status[2] = hv[3]; }
+        // feedback words (written by forward_feedback_kernel of an EARLIER forward on this block, the last word last): a
+        // consistent snapshot or nothing
+        for (int k = 0; k < 4; ++k) t_last_feedback[k] = 0;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            const uint64_t w7 = hv[7], w4 = hv[4], w5 = hv[5], w6 = hv[6];
+            if (hv[7] == w7) { t_last_feedback[0] = w4; t_last_feedback[1] = w5; t_last_feedback[2] = w6; t_last_feedback[3] = w7; break; }
+        }
     } else {
+        for (int k = 0; k < 4; ++k) t_last_feedback[k] = 0;
         HIP_TRY(hipMemcpyAsync(host_status, pend.status_dev, sizeof(host_status), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -354,6 +357,21 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                timing, stream, nullptr);
 }
 
+// Depth-slab binning for this call?  (msgs_view_t.slab_fraction; include/msgs.h)  Independent of the buffers, which
+// SlabGeom checks.
+static bool slab_wanted(const msgs_view_t* view, const msgs_gaussians_t* g) {
+    const float f = view->slab_fraction;
+    if (!(f > 0.f) || !(f <= 0.5f) || g->P <= 0 || g_deterministic.load() != 0) return false;
+    const int64_t tiles = (int64_t)((view->image_width + TILE - 1) / TILE) * ((view->image_height + TILE - 1) / TILE);
+    return tiles >= SLAB_MIN_TILES && tiles < 65535 * 16 && forward_uses_quadrant_kernel((int)tiles);
+}
+// instance capacities of the caller's stage-2 buffers: ids of `binning`, and what the scratch serves
+static void stage2_capacities(const msgs_view_t* view, size_t binning_bytes, size_t scratch2_bytes, int64_t& cb, int64_t& cs) {
+    const int W0 = view->image_width, H0 = view->image_height;
+    cb = max_instances_for(binning_bytes, [&](int64_t d) { return msgs_binning_bytes(d, W0, H0); });
+    cs = max_instances_for(scratch2_bytes, [&](int64_t d) { return msgs_stage2_scratch_bytes(d, W0, H0); });
+}
+
 // speculative stage 2 on the caller's buffers: possible when they hold at least 4096 instances, the view is not in debug
 // mode and the sort geometry can take its count from a device word (MSGS_NO_SPECULATIVE_STAGE2=1: never)
 static bool prepare_spec(const msgs_view_t* view, const msgs_gaussians_t* g, void* binning, size_t binning_bytes, void* scratch2,
@@ -365,10 +383,14 @@ static bool prepare_spec(const msgs_view_t* view, const msgs_gaussians_t* g, voi
         view->image_width <= 0 || view->image_height <= 0)
         return false;
     const int W0 = view->image_width, H0 = view->image_height;
-    const int64_t cb = max_instances_for(binning_bytes, [&](int64_t d) { return msgs_binning_bytes(d, W0, H0); });
-    const int64_t cs = max_instances_for(scratch2_bytes, [&](int64_t d) { return msgs_stage2_scratch_bytes(d, W0, H0); });
-    const int64_t cap = cb < cs ? cb : cs;
+    int64_t cb, cs;
+    stage2_capacities(view, binning_bytes, scratch2_bytes, cb, cs);
+    int64_t cap = cb < cs ? cb : cs;
     const int tiles0 = ((W0 + TILE - 1) / TILE) * ((H0 + TILE - 1) / TILE);
+    if (slab_wanted(view, g)) {          // in slab mode the buffers serve fewer instances: slab A's ids sit in front of slab B's
+        const SlabGeom SG(cb, cs, (double)view->slab_fraction, tiles0, (int64_t)1 << 40);
+        if (SG.ok && SG.cap_d >= 4096) cap = SG.cap_d;      // (else: single pass on the whole capacity)
+    }
     if (cap < 4096 || !radix_sort_supports_device_count(cap, 0, tile_bits(tiles0))) return false;
     spec.capacity = cap;
     spec.binning = binning; spec.binning_bytes = binning_bytes;
@@ -425,7 +447,7 @@ int msgs_forward_launch(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                    use_spec ? &spec : nullptr, status->sb, status->pend);
     if (rc) return rc;
     status->launched = true;
-    status->stage2_launched = use_spec && spec.capacity > 0;
+    status->stage2_launched = use_spec;
     status->capacity = spec.capacity;
     status->launched_rc = status->stage2_launched ? spec.launched_rc : MSGS_OK;
     return MSGS_OK;
@@ -459,7 +481,6 @@ int msgs_forward(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* ra
     int rc = forward_stage1_impl(view, g, radii, pixel_sizes, geom, geom_bytes, scratch1, scratch1_bytes, num_instances_host,
                                  timing, stream, use_spec ? &spec : nullptr);
     if (rc) return rc;
-    if (use_spec && spec.capacity == 0) use_spec = false;      // stage 1 declined the speculative launch: sequential route
     const int64_t D = *num_instances_host;
     const int W = view->image_width, H = view->image_height;
     if (use_spec && spec.launched_rc != MSGS_OK) return spec.launched_rc;
@@ -496,21 +517,30 @@ int msgs_forward_stage2(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                         void* image_v, size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth,
                         void* grad_records, size_t grad_records_bytes, int32_t backward_follows, const msgs_timing_t* timing,
                         void* stream) {
+    uint64_t* fb_dev = nullptr;
+    uint64_t fb_ticket = 0;
+    if (view && view->feedback_tag != 0 && !blocking_sync()) {        // feedback goes to the calling thread's status block
+        StatusBlock& sb = thread_status_block();
+        sb.ensure();
+        fb_dev = sb.dev;
+        fb_ticket = sb.ticket;
+    }
     return forward_stage2_impl(view, g, geom_v, geom_bytes, D, binning_v, binning_bytes, scratch_v, scratch_bytes, image_v,
                                image_bytes, out_color, out_acc_ps, out_depth, grad_records, grad_records_bytes, backward_follows,
-                               timing, stream, nullptr);
+                               timing, stream, nullptr, fb_dev, fb_ticket);
 }
 
 }  // extern "C"
 
 namespace {
 // D_dev != nullptr: speculative launch — D is the CAPACITY (layouts, grids, sort geometry), the kernels read the instance count
-// min(D_true, capacity) from *D_dev
+// min(D_true, capacity) from *D_dev.
+// fb_dev / fb_ticket: pinned status block (device address) for the feedback publication, msgs_view_t.feedback_tag.
 int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, const void* geom_v, size_t geom_bytes, int64_t D,
                         void* binning_v, size_t binning_bytes, void* scratch_v, size_t scratch_bytes, void* image_v,
                         size_t image_bytes, float* out_color, float* out_acc_ps, float* out_depth, void* grad_records,
                         size_t grad_records_bytes, int backward_follows, const msgs_timing_t* timing, void* stream,
-                        const uint32_t* D_dev) {
+                        const uint32_t* D_dev, uint64_t* fb_dev, uint64_t fb_ticket) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
     if (D < 0 || D > 0xFFFFFFFFll) return MSGS_ERR_TOO_MANY;
@@ -521,59 +551,140 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
     if (D > 0 && (!scratch_v || scratch_bytes < msgs_stage2_scratch_bytes(D, W, H))) return MSGS_ERR_CAPACITY;
     if (grad_records && grad_records_bytes < msgs_backward_scratch_bytes(P)) return MSGS_ERR_CAPACITY;
     hipStream_t s = (hipStream_t)stream;
-    const char* geom = (const char*)geom_v;
+    char* geom = const_cast<char*>((const char*)geom_v);        // (slab mode writes its header and second scan into geom)
     char* binning = (char*)binning_v;
     char* scratch = (char*)scratch_v;
     char* image = (char*)image_v;
     const ViewParams vp = make_view_params(view);
     const int num_tiles = vp.gx * vp.gy;
-    const BinningLayout BL(D, num_tiles);
-    const Stage2Scratch SL(D);
     const ImageLayout IL(W, H);
     const Timer tm{timing, s};
+    const int tbits = tile_bits(num_tiles);
+    // (ranges first, then ids: BinningLayout's positions do not depend on the instance count)
+    const BinningLayout BL(D, num_tiles);
     uint32_t* ids = (uint32_t*)(binning + BL.ids);
     uint2* ranges = (uint2*)(binning + BL.ranges);
-    uint32_t* keys_sorted = D > 0 ? (uint32_t*)(scratch + SL.total) : nullptr;
+    float* final_T = (float*)(image + IL.final_T);
+    uint32_t* n_contrib = (uint32_t*)(image + IL.n_contrib);
+    uint32_t* tile_last = (uint32_t*)(image + IL.tile_last);
+    const bool feedback = view->feedback_tag != 0 && fb_dev != nullptr && P > 0 && forward_uses_quadrant_kernel(num_tiles);
+    unsigned long long* dtrav = feedback ? (unsigned long long*)(binning + BL.dtrav) : nullptr;
+    const size_t clear_bytes = grad_records ? GRAD_REC_BYTES * (size_t)P : 0;
 
-    bool ranges_prezeroed = false, keys16 = false;
-    if (D > 0) {
+    // ---- depth slabs?  The buffers must serve this D in slab mode (SlabGeom); the speculative caller sized `D` accordingly
+    bool slab = D > 0 && slab_wanted(view, g) && radix_sort_supports_device_count(D, 0, tbits);
+    int64_t n_a_max = 0, cap_b = 0;
+    if (slab) {
+        int64_t cb, cs;
+        stage2_capacities(view, binning_bytes, scratch_bytes, cb, cs);
+        const SlabGeom SG(cb, cs, (double)view->slab_fraction, num_tiles, D);
+        slab = SG.ok && SG.cap_d == D && SortScratch(SG.n_a_max).total <= SortScratch(SG.cap_b).total;
+        n_a_max = SG.n_a_max;
+        cap_b = SG.cap_b;
+    }
+
+    if (!slab) {
+        const Stage2Scratch SL(D);
+        uint32_t* keys_sorted = D > 0 ? (uint32_t*)(scratch + SL.total) : nullptr;
+        bool ranges_prezeroed = false, keys16 = false;
+        if (D > 0) {
+            uint32_t* keys_a = (uint32_t*)(scratch + SL.keys_a);
+            uint32_t* ids_a = (uint32_t*)(scratch + SL.ids_a);
+            // emit also clears the tile sort's group-sum table and the tile-range array (two fill launches less)
+            ZeroJob zj2{nullptr, 0, (uint32_t*)ranges, BL.ranges_and_dtrav_words()};
+            const bool sort2_prezeroed = radix_sort_zero_region(D, 0, tbits, scratch + SL.sort, &zj2.p0, &zj2.n0);
+            ranges_prezeroed = true;
+            // tile ids (and the sentinel id = number of tiles) below 65536: the emit writes, the tile sort moves and the range
+            // search reads 16-bit keys — 6 instead of 8 bytes per pair and pass
+            keys16 = num_tiles < 65535 && radix_sort_keys16_ok(D, 0, tbits);
+            // the queue of heavy Gaussians (binning.hip: one more launch) — not on a view the caller marked as ordinary
+            // (msgs_view_t.no_heavy_queue: no covers closed anything lately, hence no crowd of giants in the first ranks either;
+            // the few Gaussians with many instances are then emitted by their wave inside emit_kernel, as before round 5)
+            uint32_t* heavy_q = view->no_heavy_queue ? nullptr : (uint32_t*)(scratch + SL.heavy_q);
+            if (heavy_q && !D_dev) HIP_TRY(launch_zero(heavy_q, 4, s));     // (a speculative launch had it cleared by stage 1's scan)
+            tm.begin(MSGS_K_EMIT);
+            HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2, D_dev, keys16, heavy_q));
+            tm.end(MSGS_K_EMIT);
+            if ((rc = debug_sync(view, s))) return rc;
+            tm.begin(MSGS_K_TILE_SORT);
+            HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, D, 0, tbits, scratch + SL.sort, s, sort2_prezeroed, nullptr,
+                                     D_dev, keys16));
+            tm.end(MSGS_K_TILE_SORT);
+            if ((rc = debug_sync(view, s))) return rc;
+        }
+        tm.begin(MSGS_K_RANGES);
+        HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s, ranges_prezeroed, D_dev, keys16));
+        tm.end(MSGS_K_RANGES);
+        if ((rc = debug_sync(view, s))) return rc;
+
+        tm.begin(MSGS_K_BLEND_FWD);
+        if (D == 0 && dtrav) HIP_TRY(launch_zero(dtrav, 8 * (size_t)DTRAV_SLOTS, s));      // (no emit ran: nobody cleared them)
+        const FwdSlabArgs fa{0, nullptr, nullptr, nullptr, dtrav};
+        HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth, final_T, n_contrib, tile_last,
+                                     grad_records, clear_bytes, s, dtrav ? &fa : nullptr));
+    } else {
+        // ---------------- slab A: the nearest ranks, up to slab_fraction * D instances ----------------
+        const GeomLayout GL(P);
+        SlabHeader* hdr = reinterpret_cast<SlabHeader*>(geom + GL.slab_hdr);
+        uint32_t* open_bits = (uint32_t*)(image + IL.open_bits);
+        uint32_t* open_list = (uint32_t*)(image + IL.open_list);
+        const Stage2Scratch SL(cap_b);                       // the scratch is laid out for slab B's capacity; A uses its head
         uint32_t* keys_a = (uint32_t*)(scratch + SL.keys_a);
         uint32_t* ids_a = (uint32_t*)(scratch + SL.ids_a);
-        // emit also clears the tile sort's group-sum table and the tile-range array (two fill launches less)
-        ZeroJob zj2{nullptr, 0, (uint32_t*)ranges, 2 * (size_t)num_tiles};
-        const bool sort2_prezeroed = radix_sort_zero_region(D, 0, tile_bits(num_tiles), scratch + SL.sort, &zj2.p0, &zj2.n0);
-        ranges_prezeroed = true;
-        // tile ids (and the sentinel id = number of tiles) below 65536: the emit writes, the tile sort moves and the range
-        // search reads 16-bit keys — 6 instead of 8 bytes per pair and pass
-        keys16 = num_tiles < 65535 && radix_sort_keys16_ok(D, 0, tile_bits(num_tiles));
-        // the queue of heavy Gaussians (binning.hip: one more launch) — not on a view the caller marked as ordinary
-        // (msgs_view_t.skip_occlusion: no covers worth a pass, hence no crowd of giants in the first ranks either; the few
-        // Gaussians with many instances are then emitted by their wave inside emit_kernel, as before round 5)
-        uint32_t* heavy_q = view->skip_occlusion ? nullptr : (uint32_t*)(scratch + SL.heavy_q);
-        if (heavy_q && !D_dev) HIP_TRY(launch_zero(heavy_q, 4, s));     // (a speculative launch had it cleared by stage 1's scan)
+        uint32_t* keys_sorted = (uint32_t*)(scratch + SL.total);
+        uint32_t* heavy_q = view->no_heavy_queue ? nullptr : (uint32_t*)(scratch + SL.heavy_q);
+        const bool keys16 = num_tiles < 65535 && radix_sort_keys16_ok(n_a_max, 0, tbits) && radix_sort_keys16_ok(cap_b, 0, tbits);
         tm.begin(MSGS_K_EMIT);
-        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, D, s, zj2, D_dev, keys16, heavy_q));
+        HIP_TRY(launch_slab_split(P, geom, D, D_dev, view->slab_fraction, open_bits, num_tiles, s));
+        if (heavy_q) HIP_TRY(launch_zero(heavy_q, 4, s));
+        ZeroJob zjA{nullptr, 0, (uint32_t*)ranges, BL.ranges_and_dtrav_words()};
+        const bool sortA_prezeroed = radix_sort_zero_region(n_a_max, 0, tbits, scratch + SL.sort, &zjA.p0, &zjA.n0);
+        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, n_a_max, s, zjA, &hdr->DA, keys16, heavy_q, 1, nullptr, D));
         tm.end(MSGS_K_EMIT);
         if ((rc = debug_sync(view, s))) return rc;
         tm.begin(MSGS_K_TILE_SORT);
-        HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, D, 0, tile_bits(num_tiles), scratch + SL.sort, s,
-                                 sort2_prezeroed, nullptr, D_dev, keys16));
+        HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids, n_a_max, 0, tbits, scratch + SL.sort, s, sortA_prezeroed, nullptr,
+                                 &hdr->DA, keys16));
         tm.end(MSGS_K_TILE_SORT);
         if ((rc = debug_sync(view, s))) return rc;
-    }
-    tm.begin(MSGS_K_RANGES);
-    HIP_TRY(launch_ranges(keys_sorted, D, ranges, num_tiles, s, ranges_prezeroed, D_dev, keys16));
-    tm.end(MSGS_K_RANGES);
-    if ((rc = debug_sync(view, s))) return rc;
+        tm.begin(MSGS_K_RANGES);
+        HIP_TRY(launch_ranges(keys_sorted, n_a_max, ranges, num_tiles, s, true, &hdr->DA, keys16, 0u));
+        tm.end(MSGS_K_RANGES);
+        if ((rc = debug_sync(view, s))) return rc;
+        tm.begin(MSGS_K_BLEND_FWD);
+        const FwdSlabArgs fa{1, open_bits, open_list, &hdr->n_open, dtrav};
+        HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth, final_T, n_contrib, tile_last,
+                                     grad_records, clear_bytes, s, &fa));
+        tm.end(MSGS_K_BLEND_FWD);
+        if ((rc = debug_sync(view, s))) return rc;
 
-    tm.begin(MSGS_K_BLEND_FWD);
-    HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth,
-                                 (float*)(image + IL.final_T), (uint32_t*)(image + IL.n_contrib),
-                                 (uint32_t*)(image + IL.tile_last),
-                                 grad_records, grad_records ? GRAD_REC_BYTES * (size_t)P : 0, s));
+        // ---------------- slab B: the complete lists of the tiles slab A left open ----------------
+        tm.begin(MSGS_K_SLAB_B);
+        uint32_t* offs_b = (uint32_t*)(geom + GL.offs_b);
+        HIP_TRY(launch_slab_recount(vp, P, geom, open_bits, D, D_dev, s));
+        HIP_TRY(exclusive_scan_u32(offs_b, nullptr, offs_b, P, (uint64_t*)(geom + GL.scan_b), &hdr->total_b, s, nullptr, nullptr, 0,
+                                   (const uint32_t*)(geom + GL.nvalid), &hdr->DB, (uint64_t)cap_b, nullptr, heavy_q, &hdr->pad0));
+        ZeroJob zjB{nullptr, 0, nullptr, 0};
+        const bool sortB_prezeroed = radix_sort_zero_region(cap_b, 0, tbits, scratch + SL.sort, &zjB.p0, &zjB.n0);
+        HIP_TRY(launch_emit(vp, P, geom, keys_a, ids_a, cap_b, s, zjB, &hdr->DB, keys16, heavy_q, 2, open_bits));
+        if ((rc = debug_sync(view, s))) return rc;
+        HIP_TRY(radix_sort_pairs(keys_a, ids_a, keys_sorted, ids + n_a_max, cap_b, 0, tbits, scratch + SL.sort, s, sortB_prezeroed,
+                                 nullptr, &hdr->DB, keys16));
+        if ((rc = debug_sync(view, s))) return rc;
+        HIP_TRY(launch_ranges(keys_sorted, cap_b, ranges, num_tiles, s, true, &hdr->DB, keys16, (uint32_t)n_a_max));
+        const FwdSlabArgs fb{2, open_bits, open_list, &hdr->n_open, dtrav};
+        HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth, final_T, n_contrib, tile_last,
+                                     nullptr, 0, s, &fb));
+        tm.end(MSGS_K_SLAB_B);
+    }
     if (backward_follows)  // give the backward's one-wave-per-tile kernel a heaviest-first launch order
-        HIP_TRY(launch_tile_order(vp, (const uint32_t*)(image + IL.tile_last), (uint32_t*)(image + IL.tile_order), s));
-    tm.end(MSGS_K_BLEND_FWD);
+        HIP_TRY(launch_tile_order(vp, tile_last, (uint32_t*)(image + IL.tile_order), s));
+    if (feedback) {
+        const GeomLayout GL(P);
+        HIP_TRY(launch_forward_feedback(dtrav, reinterpret_cast<const SlabHeader*>(geom + GL.slab_hdr), slab ? 1 : 0, D,
+                                        D_dev, (uint32_t)view->feedback_tag, fb_ticket, fb_dev, s));
+    }
+    if (!slab) tm.end(MSGS_K_BLEND_FWD);
     return debug_sync(view, s);
 }
 }  // namespace
@@ -697,6 +808,32 @@ int msgs_forward_info(int64_t* out_host) {
     if (!out_host) return MSGS_ERR_INVALID_ARG;
     out_host[0] = (int64_t)(t_last_info & 0xFFFFFFFFull);
     out_host[1] = (int64_t)(t_last_info >> 32) != 0 ? 1 : 0;
+    // feedback publication (forward_feedback_kernel): {D_trav | overflow << 63, tag | n_open << 32, DA | DB << 32, D | ticket << 40}
+    const uint64_t w4 = t_last_feedback[0], w5 = t_last_feedback[1], w6 = t_last_feedback[2], w7 = t_last_feedback[3];
+    const uint32_t n_open = (uint32_t)(w5 >> 32);
+    out_host[2] = (int64_t)(w5 & 0xFFFFFFFFull);                       // tag (0: nothing published yet)
+    out_host[3] = (int64_t)(w7 & 0xFFFFFFFFFFull);                     // D
+    out_host[4] = (int64_t)(w4 & ~(1ull << 63));                       // D_trav
+    out_host[5] = n_open == 0xFFFFFFFFu ? -1 : (int64_t)n_open;        // tiles left open by slab A (-1: single pass)
+    out_host[6] = (int64_t)(w6 & 0xFFFFFFFFull);                       // DA
+    out_host[7] = (w4 >> 63) ? -1 : (int64_t)(w6 >> 32);               // DB (-1: slab B outgrew its buffers — never observed)
+    return MSGS_OK;
+}
+
+int msgs_slab_stats(const void* geom_v, size_t geom_bytes, int32_t P, int64_t* out_host, void* stream) {
+    if (!geom_v || !out_host || P <= 0) return MSGS_ERR_INVALID_ARG;
+    if (geom_bytes < msgs_geom_bytes(P)) return MSGS_ERR_CAPACITY;
+    const GeomLayout GL(P);
+    SlabHeader h;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&h, (const char*)geom_v + GL.slab_hdr, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    out_host[0] = h.active;
+    out_host[1] = h.rA;
+    out_host[2] = h.DA;
+    out_host[3] = h.n_open;
+    out_host[4] = (int64_t)h.total_b;
+    out_host[5] = h.pad0;          // 1: slab B outgrew its buffers (never observed)
     return MSGS_OK;
 }
 
@@ -710,12 +847,16 @@ int msgs_occlusion_stats(const void* geom_v, size_t geom_bytes, int32_t P, int64
     HIP_TRY(hipMemcpyAsync(&h, (const char*)geom_v + GL.occ_hdr, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int k = 0; k < 8; ++k) out_host[k] = 0;
-    out_host[0] = h.enabled;
+    out_host[0] = h.enabled ? (h.watchdog ? 2 : 1) : 0;     // 2: a barrier wait of the pass expired (never observed)
     if (!h.enabled) return MSGS_OK;
     const int n_blocks = (int)(h.nbx * h.nby);
     if (n_blocks < 0 || n_blocks > OCC_MAX_BLOCKS) return MSGS_ERR_INTERNAL;
-    HIP_TRY(hipMemcpyAsync(table, (const char*)geom_v + GL.occ_cut, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (h.any_closed) {       // (a view in which nothing closed leaves the table unwritten: nobody reads it)
+        HIP_TRY(hipMemcpyAsync(table, (const char*)geom_v + GL.occ_cut, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        for (int k = 0; k < n_blocks; ++k) table[k] = 0xFFFFu;
+    }
     // cut-offs are depth buckets (0xFFFF = open): reported as the depth key at the far end of the bucket
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     int closed = 0;

@@ -26,12 +26,34 @@ namespace {
 // stage, so a staged pair is 3 bytes, not 8: the tile id as KeyT (16 bits whenever the grid has fewer than 65535 tiles) and
 // the owner's thread number (8 bits; the 256 Gaussian ids of the block sit in LDS once).
 
+// Depth-slab binning (msgs_view_t.slab_fraction): the same kernel emits slab A — the ranks below SlabArgs::V_dev, whose slots
+// end at *D_dev = offs[rA] — and, with SLAB_B, slab B: EVERY rank, but only into the tiles whose bit is set in open_bits (the tiles
+// slab A left open), at the slots of the second scan (offs_b).  The tile set of a Gaussian is computed by the same code from the
+// same inputs in all three uses, so a tile's slab-A list is exactly the head of its complete list.
+struct SlabArgs {
+    const uint32_t* V_dev;        // number of ranks to emit (nullptr: GeomLayout::nvalid)
+    const uint32_t* offs;         // exclusive scan of the per-rank instance counts (nullptr: GeomLayout::offs)
+    const uint32_t* open_bits;    // SLAB_B: bit t = tile t receives instances
+};
+__device__ __forceinline__ bool tile_open(const uint32_t* __restrict__ bits, uint32_t t) { return (bits[t >> 5] >> (t & 31u)) & 1u; }
+// set bits of `bits` in [a, b] (inclusive)
+__device__ __forceinline__ uint32_t open_in_range(const uint32_t* __restrict__ bits, uint32_t a, uint32_t b) {
+    uint32_t c = 0;
+    for (uint32_t w = a >> 5; w <= (b >> 5); ++w) {
+        uint32_t m = bits[w];
+        if (w == (a >> 5)) m &= 0xFFFFFFFFu << (a & 31u);
+        if (w == (b >> 5)) m &= 0xFFFFFFFFu >> (31u - (b & 31u));
+        c += (uint32_t)__popc(m);
+    }
+    return c;
+}
+
 // OutT: the element type of the key array in HBM — uint16_t when the tile sort runs on 16-bit keys (radix_sort_keys16_ok)
-template <int EMIT_STAGE, typename KeyT, typename OutT = uint32_t>
+template <int EMIT_STAGE, typename KeyT, typename OutT = uint32_t, bool SLAB_B = false>
 __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                    OutT* __restrict__ keys, uint32_t* __restrict__ ids,
                                                    int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev,
-                                                   uint32_t* __restrict__ heavy_q) {
+                                                   uint32_t* __restrict__ heavy_q, SlabArgs sl) {
     // ranks 0 .. V-1 of the depth order are the Gaussians that stayed in the compacting depth sort (GeomLayout::nvalid)
     {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
         const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
@@ -44,7 +66,8 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     __shared__ int64_t s_range[2];
     const GeomLayout L(P);
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
-    const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
+    const uint32_t* offs = sl.offs ? sl.offs : reinterpret_cast<const uint32_t*>(geom + L.offs);
+    const uint32_t* __restrict__ obits = sl.open_bits;
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
     // occlusion cut-off (occlusion.hip): a tile whose cut-off depth key lies in front of this Gaussian's key receives no
     // instance of it — the same predicate the recount applied to the counts the scan summed
@@ -54,9 +77,13 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     const int occ_lb = (int)occ->block_log2, occ_nbx = (int)occ->nbx;
 
     if (D_dev) D = (int64_t)*D_dev;      // speculative stage 2: min(instance count, capacity), from the scan
-    const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
+    const int V = (int)(sl.V_dev ? *sl.V_dev : *reinterpret_cast<const uint32_t*>(geom + L.nvalid));
     const int r0 = blockIdx.x * blockDim.x;
     if (r0 >= V) return;
+    if (SLAB_B) {       // normally a handful of tiles are open: most workgroups have nothing to emit and learn it from two words
+        const int64_t lo = offs[r0], hi = r0 + (int)blockDim.x < V ? (int64_t)offs[r0 + blockDim.x] : D;
+        if (hi <= lo) return;
+    }
     uint32_t cut_min = 0xFFFFFFFFu;
     if (occ_on) {
         occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), occ_nbx, (int)occ->nby);
@@ -125,6 +152,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
             if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi)) continue;
             if (!cut_check) {
                 for (int tx = tlo; tx <= thi && off < end; ++tx) {
+                    if (SLAB_B && !tile_open(obits, (uint32_t)(ty * vp.gx + tx))) continue;
                     put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
                     ++off;
                 }
@@ -135,6 +163,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
                     const int bend = min(thi, (((tx >> occ_lb) + 1) << occ_lb) - 1);
                     if (T.cut[brow + (tx >> occ_lb)] >= kmine) {
                         for (; tx <= bend && off < end; ++tx) {
+                            if (SLAB_B && !tile_open(obits, (uint32_t)(ty * vp.gx + tx))) continue;
                             put(off, (uint32_t)(ty * vp.gx + tx), gi, threadIdx.x);
                             ++off;
                         }
@@ -184,14 +213,16 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
                     const int n_r = lane_bcast(n_row, r);
                     const int tlo_r = lane_bcast(tlo, r);
                     const uint32_t kbase = (uint32_t)((row0 + r) * vp.gx + tlo_r);
-                    if (!h_check) {
+                    if (!h_check && !SLAB_B) {
                         for (int j = lane; j < n_r; j += 64)
                             if (at + j < h_end) put(at + j, kbase + (uint32_t)j, h_gi, h_owner);
                         at += n_r;
                     } else {                                           // only the tiles still open at this depth, compacted
                         for (int j0 = 0; j0 < n_r; j0 += 64) {
                             const int j = j0 + lane;
-                            const bool keep = j < n_r && T.cut[((row0 + r) >> occ_lb) * occ_nbx + ((tlo_r + j) >> occ_lb)] >= h_key;
+                            const bool keep = j < n_r &&
+                                              (!h_check || T.cut[((row0 + r) >> occ_lb) * occ_nbx + ((tlo_r + j) >> occ_lb)] >= h_key) &&
+                                              (!SLAB_B || tile_open(obits, kbase + (uint32_t)j));
                             const uint64_t km = __ballot(keep);
                             const int64_t pos = at + __popcll(km & ((1ull << lane) - 1ull));
                             if (keep && pos < h_end) put(pos, kbase + (uint32_t)j, h_gi, h_owner);
@@ -215,18 +246,19 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
 // 64 rows at a time) and the exclusive scan of the rows' instance counts, so every wave knows where every row starts without
 // talking to the others; wave w then writes the rows r with r % 4 == w, lanes on consecutive tiles.  Behind an occlusion cut-off
 // a row's count is its OPEN tiles (cover block by cover block, from the table in LDS) and the stores are compacted by ballot.
-template <typename OutT>
+template <typename OutT, bool SLAB_B = false>
 __global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, const char* __restrict__ geom,
                                                          OutT* __restrict__ keys, uint32_t* __restrict__ ids, int64_t D,
                                                          const uint32_t* __restrict__ D_dev,
-                                                         const uint32_t* __restrict__ heavy_q) {
+                                                         const uint32_t* __restrict__ heavy_q, SlabArgs sl) {
     __shared__ OccTable T;
     // (never more than D / EMIT_HEAVY_MIN + 1 entries: the queued Gaussians start below D and lie more than EMIT_HEAVY_MIN apart)
     const uint32_t n = min(heavy_q[0], (uint32_t)(D / EMIT_HEAVY_MIN + 64));
     if (blockIdx.x >= n) return;
     const GeomLayout L(P);
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
-    const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
+    const uint32_t* offs = sl.offs ? sl.offs : reinterpret_cast<const uint32_t*>(geom + L.offs);
+    const uint32_t* __restrict__ obits = sl.open_bits;
     const uint32_t* skey = reinterpret_cast<const uint32_t*>(geom + L.skey);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
     const OccHeader* occ = reinterpret_cast<const OccHeader*>(geom + L.occ_hdr);
@@ -234,7 +266,7 @@ __global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, c
     const int lb = (int)occ->block_log2, nbx = (int)occ->nbx;
     if (occ_on) occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), nbx, (int)occ->nby);
     if (D_dev) D = (int64_t)*D_dev;
-    const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
+    const int V = (int)(sl.V_dev ? *sl.V_dev : *reinterpret_cast<const uint32_t*>(geom + L.nvalid));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t sentinel = (uint32_t)(vp.gx * vp.gy);
@@ -259,12 +291,15 @@ __global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, c
             if (hit && check) hit = T.rowmax[ty >> lb] >= kb;
             if (hit && test) hit = levelset_row_interval(ls, b.q0.x, b.q0.y, ty, minx, maxx, LEVELSET_MARGIN_EMIT, tlo, thi);
             int n_row = 0;
-            if (hit && !check) n_row = thi - tlo + 1;
+            if (hit && !check) n_row = SLAB_B ? (int)open_in_range(obits, (uint32_t)(ty * vp.gx + tlo), (uint32_t)(ty * vp.gx + thi))
+                                              : thi - tlo + 1;
             else if (hit) {
                 const int brow = (ty >> lb) * nbx;
                 for (int tx = tlo; tx <= thi;) {
                     const int bend = min(thi, (((tx >> lb) + 1) << lb) - 1);
-                    if (T.cut[brow + (tx >> lb)] >= kb) n_row += bend - tx + 1;
+                    if (T.cut[brow + (tx >> lb)] >= kb)
+                        n_row += SLAB_B ? (int)open_in_range(obits, (uint32_t)(ty * vp.gx + tx), (uint32_t)(ty * vp.gx + bend))
+                                        : bend - tx + 1;
                     tx = bend + 1;
                 }
             }
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, c
                 const int64_t start = at + lane_bcast(excl, rr);
                 const int tlo_r = lane_bcast(tlo, rr), thi_r = lane_bcast(thi, rr);
                 const uint32_t kbase = (uint32_t)((row0 + rr) * vp.gx);
-                if (!check) {
+                if (!check && !SLAB_B) {
                     for (int j = lane; tlo_r + j <= thi_r; j += 64) {
                         const int64_t pos = start + j;
                         if (pos < end) { keys[pos] = (OutT)(kbase + (uint32_t)(tlo_r + j)); ids[pos] = gi; }
@@ -293,7 +328,8 @@ __global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, c
                     int64_t p = start;
                     for (int j0 = 0; tlo_r + j0 <= thi_r; j0 += 64) {
                         const int tx = tlo_r + j0 + lane;
-                        const bool keep = tx <= thi_r && T.cut[brow + (tx >> lb)] >= kb;
+                        const bool keep = tx <= thi_r && (!check || T.cut[brow + (tx >> lb)] >= kb) &&
+                                          (!SLAB_B || tile_open(obits, kbase + (uint32_t)tx));
                         const uint64_t km = __ballot(keep);
                         const int64_t pos = p + __popcll(km & lt);
                         if (keep && pos < end) { keys[pos] = (OutT)(kbase + (uint32_t)tx); ids[pos] = gi; }
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(256) void emit_heavy_kernel(ViewParams vp, int P, c
 template <typename KeyT>
 __global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ keys, int64_t D,
                                                      uint2* __restrict__ ranges, int num_tiles,
-                                                     const uint32_t* __restrict__ D_dev) {
+                                                     const uint32_t* __restrict__ D_dev, uint32_t base) {
     if (D_dev) D = (int64_t)*D_dev;
     const int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
     const int lane = threadIdx.x & 63;
@@ -343,49 +379,197 @@ __global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ ke
         if (t >= nt) continue;
         const uint32_t before = j == 0 ? prev : k[j - 1];
         const uint32_t after = (j == 3 || i + 1 >= D) ? (j == 3 ? next : 0xFFFFFFFFu) : k[j + 1];
-        if (i == 0 || before != t) ranges[t].x = (uint32_t)i;
-        if (i == D - 1 || after != t) ranges[t].y = (uint32_t)(i + 1);
+        if (i == 0 || before != t) ranges[t].x = base + (uint32_t)i;           // base: where this key array's ids start in `ids`
+        if (i == D - 1 || after != t) ranges[t].y = base + (uint32_t)(i + 1);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depth-slab binning: split of the depth order and the second count
+// ---------------------------------------------------------------------------------------------
+// One workgroup.  Slab A = the ranks [0, rA) with rA the smallest rank whose offset reaches thr = max(1, fraction * D):
+// DA = offs[rA] <= fraction * D + one Gaussian's instances (<= number of tiles).  A 256-ary search over offs[0 .. V) (offs[V] := D).
+// Also clears what the forward blend of slab A fills: the open-tile bitmap and the list's counter.
+__global__ __launch_bounds__(256) void slab_split_kernel(int P, char* __restrict__ geom, int64_t D_host,
+                                                         const uint32_t* __restrict__ D_dev, float fraction,
+                                                         uint32_t* __restrict__ open_bits, int n_bit_words) {
+    __shared__ uint32_t s_lo, s_hi;
+    const GeomLayout L(P);
+    const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
+    SlabHeader* hdr = reinterpret_cast<SlabHeader*>(geom + L.slab_hdr);
+    const uint32_t V = *reinterpret_cast<const uint32_t*>(geom + L.nvalid);
+    const uint64_t D = D_dev ? (uint64_t)*D_dev : (uint64_t)D_host;
+    for (int k = threadIdx.x; k < n_bit_words; k += 256) open_bits[k] = 0u;
+    uint64_t thr = (uint64_t)((double)fraction * (double)D);
+    thr = thr < 1 ? 1 : (thr > D ? D : thr);
+    // invariant: value(lo) < thr <= value(hi), value(r) = r < V ? offs[r] : D, value(-1) = -inf; start lo = -1 (stored + 1), hi = V
+    if (threadIdx.x == 0) { s_lo = 0u; s_hi = V + 1u; }       // both stored + 1
+    __syncthreads();
+    for (int round = 0; round < 5; ++round) {
+        const uint32_t lo = s_lo, hi = s_hi;                  // candidates strictly between: lo < c < hi (in + 1 coordinates)
+        __syncthreads();
+        if (hi - lo <= 1u) break;
+        const uint64_t span = (uint64_t)(hi - lo - 1u);       // number of interior candidates
+        // thread t probes candidate c_t = lo + 1 + floor(t * span / 256) (distinct while span >= 256, repeated below)
+        const uint32_t c = lo + 1u + (uint32_t)(((uint64_t)threadIdx.x * span) >> 8);
+        const uint32_t r = c - 1u;                            // rank
+        const uint64_t v = r < V ? (uint64_t)offs[r] : D;
+        // offs is non-decreasing: the largest probed candidate with value < thr raises lo, the smallest with value >= thr lowers hi
+        if (v < thr) atomicMax(&s_lo, c); else atomicMin(&s_hi, c);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // (D == 0: thr = 0 is clamped to 1 > value(V) = 0 -> lo rises to V + 1, hi stays: rA = V, DA = 0)
+        const uint32_t rA = min(s_hi - 1u, V);
+        hdr->rA = rA;
+        hdr->DA = rA < V ? offs[rA] : (uint32_t)D;
+        hdr->DB = 0u;
+        hdr->active = 1u;
+        hdr->n_open = 0u;
+        hdr->total_b = 0ull;
+    }
+}
+
+// Slab B's count: per depth rank, the instances that fall into OPEN tiles — the same per-row extents and margin as the count in
+// preprocess_kernel (hence >= what the emit will write there), the same occlusion predicate as recount / emit.  One thread per
+// rank; the bitmap is read through the cache (4 KB at 4K).
+__global__ __launch_bounds__(256) void slab_recount_kernel(ViewParams vp, int P, const char* __restrict__ geom,
+                                                           const uint32_t* __restrict__ open_bits, int64_t D_host,
+                                                           const uint32_t* __restrict__ D_dev, uint32_t* __restrict__ cnt_b) {
+    __shared__ OccTable T;
+    const GeomLayout L(P);
+    const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
+    const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
+    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
+    const SlabHeader* hdr = reinterpret_cast<const SlabHeader*>(geom + L.slab_hdr);
+    const OccHeader* occ = reinterpret_cast<const OccHeader*>(geom + L.occ_hdr);
+    const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
+    const int r0 = blockIdx.x * blockDim.x;
+    if (r0 >= V) return;
+    const int r = r0 + threadIdx.x;
+    const uint32_t n_open = hdr->n_open;                                       // final: blend A has completed
+    if (n_open == 0u) {                                                        // nothing left open: slab B is empty
+        if (r < V) cnt_b[r] = 0u;
+        return;
+    }
+    const bool occ_on = occ->enabled != 0u && occ->any_closed != 0u;
+    const int occ_lb = (int)occ->block_log2, occ_nbx = (int)occ->nbx;
+    uint32_t cut_min = 0xFFFFFFFFu;
+    if (occ_on) {
+        occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), occ_nbx, (int)occ->nby);
+        cut_min = T.cut_min;
+    }
+    if (r >= V) return;
+    const int64_t D = D_dev ? (int64_t)*D_dev : D_host;
+    const uint32_t full = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - (int64_t)offs[r]);
+    uint32_t c = 0;
+    if (full) {
+        const uint32_t gi = order[r];
+        const float4 q1 = binrec[gi].q1, q0 = binrec[gi].q0;         // (one 32-byte line)
+        const uint32_t kmine = cut_min != 0xFFFFFFFFu ? occ_bucket(reinterpret_cast<const uint32_t*>(geom + L.skey)[r]) : 0u;
+        const bool cut_check = kmine > cut_min;
+        const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
+        const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
+        const float tau2 = q1.y;
+        const bool test = tau2 > -1.0e38f;
+        LevelSetRows ls{};
+        bool ls_ready = false;
+        for (int ty = miny; ty < maxy; ++ty) {
+            if (cut_check && T.rowmax[ty >> occ_lb] < kmine) continue;
+            const uint32_t row = (uint32_t)(ty * vp.gx);
+            // (normally a handful of tiles are open: no open tile in this row of the rect -> no extent to compute)
+            if (open_in_range(open_bits, row + (uint32_t)minx, row + (uint32_t)(maxx - 1)) == 0u) continue;
+            if (test && !ls_ready) { ls = levelset_rows_setup(q0.z, q0.w, q1.x, tau2); ls_ready = true; }
+            int tlo = minx, thi = maxx - 1;
+            if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi)) continue;
+            if (tlo > thi) continue;
+            if (!cut_check) {
+                c += open_in_range(open_bits, row + (uint32_t)tlo, row + (uint32_t)thi);
+            } else {
+                const int brow = (ty >> occ_lb) * occ_nbx;
+                for (int tx = tlo; tx <= thi;) {
+                    const int bend = min(thi, (((tx >> occ_lb) + 1) << occ_lb) - 1);
+                    if (T.cut[brow + (tx >> occ_lb)] >= kmine) c += open_in_range(open_bits, row + (uint32_t)tx, row + (uint32_t)bend);
+                    tx = bend + 1;
+                }
+            }
+        }
+        c = min(c, full);        // (a subset of the first count's tiles; the clamp only guards the scan against a rounding surprise)
+    }
+    cnt_b[r] = c;
 }
 
 }  // namespace
 
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids, int64_t D,
-                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev, bool keys16, uint32_t* heavy_q) {
+                       hipStream_t s, ZeroJob zj, const uint32_t* D_dev, bool keys16, uint32_t* heavy_q, int slab,
+                       const uint32_t* open_bits, int64_t density_D) {
     if (P == 0 || D == 0) return hipSuccess;     // (callers fold a ZeroJob in only when D > 0)
     const bool narrow = vp.gx * vp.gy < 65535;        // tile ids and the sentinel (= number of tiles) fit 16 bits
     const dim3 grid((P + 255) / 256), block(256);
     if (keys16 && !narrow) return hipErrorInvalidValue;
-    static const bool no_queue = [] { const char* e = getenv("MSGS_EMIT_NO_QUEUE"); return e && e[0] == '1'; }();
-    if (no_queue) heavy_q = nullptr;
+    if (slab == 2 && !open_bits) return hipErrorInvalidValue;
+    const GeomLayout L(P);
+    const SlabHeader* hdr = reinterpret_cast<const SlabHeader*>(geom + L.slab_hdr);
+    SlabArgs sl{nullptr, nullptr, nullptr};
+    if (slab == 1) sl.V_dev = &hdr->rA;
+    if (slab == 2) { sl.offs = reinterpret_cast<const uint32_t*>(geom + L.offs_b); sl.open_bits = open_bits; }
+    // a block of 256 Gaussians emits more than the small stage on average (slab A: the ranks it covers are as dense as the whole
+    // view's; slab B: normally a handful of tiles — the small stage keeps more of its workgroups, most of which only learn that
+    // they have nothing to emit, resident per CU: 64 -> ~15 us on an empty slab B at C5)
+    const bool wide = slab == 2 ? false : (density_D > 0 ? density_D : D) > 8 * (int64_t)P;
+#define MSGS_EMIT(STAGE, KEYT, OUTT, KPTR)                                                                                          \
+    do {                                                                                                                            \
+        if (slab == 2) hipLaunchKernelGGL((emit_kernel<STAGE, KEYT, OUTT, true>), grid, block, 0, s, vp, P, geom, KPTR, ids, D, zj,  \
+                                          D_dev, heavy_q, sl);                                                                      \
+        else hipLaunchKernelGGL((emit_kernel<STAGE, KEYT, OUTT, false>), grid, block, 0, s, vp, P, geom, KPTR, ids, D, zj, D_dev,    \
+                                heavy_q, sl);                                                                                       \
+    } while (0)
+    uint16_t* k16 = reinterpret_cast<uint16_t*>(keys);
     if (keys16) {
-        uint16_t* k16 = reinterpret_cast<uint16_t*>(keys);
-        if (D > 8 * (int64_t)P)
-            hipLaunchKernelGGL((emit_kernel<12288, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev, heavy_q);
-        else
-            hipLaunchKernelGGL((emit_kernel<3072, uint16_t, uint16_t>), grid, block, 0, s, vp, P, geom, k16, ids, D, zj, D_dev, heavy_q);
-    } else if (D > 8 * (int64_t)P) {
-        if (narrow) hipLaunchKernelGGL((emit_kernel<12288, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
-        else hipLaunchKernelGGL((emit_kernel<6144, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
+        if (wide) MSGS_EMIT(12288, uint16_t, uint16_t, k16); else MSGS_EMIT(3072, uint16_t, uint16_t, k16);
+    } else if (wide) {
+        if (narrow) MSGS_EMIT(12288, uint16_t, uint32_t, keys); else MSGS_EMIT(6144, uint32_t, uint32_t, keys);
     } else {
-        if (narrow) hipLaunchKernelGGL((emit_kernel<3072, uint16_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
-        else hipLaunchKernelGGL((emit_kernel<3072, uint32_t>), grid, block, 0, s, vp, P, geom, keys, ids, D, zj, D_dev, heavy_q);
+        if (narrow) MSGS_EMIT(3072, uint16_t, uint32_t, keys); else MSGS_EMIT(3072, uint32_t, uint32_t, keys);
     }
+#undef MSGS_EMIT
     if (heavy_q) {
         // at most D / EMIT_HEAVY_MIN Gaussians can be queued; workgroups beyond the queue's length leave at once
         const unsigned hb = (unsigned)std::min<int64_t>(2048, D / EMIT_HEAVY_MIN + 1);
-        if (keys16)
-            hipLaunchKernelGGL(emit_heavy_kernel<uint16_t>, dim3(hb), block, 0, s, vp, P, geom, reinterpret_cast<uint16_t*>(keys), ids, D,
-                               D_dev, (const uint32_t*)heavy_q);
+        if (keys16 && slab == 2)
+            hipLaunchKernelGGL((emit_heavy_kernel<uint16_t, true>), dim3(hb), block, 0, s, vp, P, geom, k16, ids, D, D_dev,
+                               (const uint32_t*)heavy_q, sl);
+        else if (keys16)
+            hipLaunchKernelGGL((emit_heavy_kernel<uint16_t, false>), dim3(hb), block, 0, s, vp, P, geom, k16, ids, D, D_dev,
+                               (const uint32_t*)heavy_q, sl);
+        else if (slab == 2)
+            hipLaunchKernelGGL((emit_heavy_kernel<uint32_t, true>), dim3(hb), block, 0, s, vp, P, geom, keys, ids, D, D_dev,
+                               (const uint32_t*)heavy_q, sl);
         else
-            hipLaunchKernelGGL(emit_heavy_kernel<uint32_t>, dim3(hb), block, 0, s, vp, P, geom, keys, ids, D, D_dev,
-                               (const uint32_t*)heavy_q);
+            hipLaunchKernelGGL((emit_heavy_kernel<uint32_t, false>), dim3(hb), block, 0, s, vp, P, geom, keys, ids, D, D_dev,
+                               (const uint32_t*)heavy_q, sl);
     }
     return hipGetLastError();
 }
 
+hipError_t launch_slab_split(int P, char* geom, int64_t D, const uint32_t* D_dev, float fraction, uint32_t* open_bits,
+                             int num_tiles, hipStream_t s) {
+    hipLaunchKernelGGL(slab_split_kernel, dim3(1), dim3(256), 0, s, P, geom, D, D_dev, fraction, open_bits, (num_tiles + 31) / 32 + 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_recount(const ViewParams& vp, int P, char* geom, const uint32_t* open_bits, int64_t D,
+                               const uint32_t* D_dev, hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    const GeomLayout L(P);
+    hipLaunchKernelGGL(slab_recount_kernel, dim3((P + 255) / 256), dim3(256), 0, s, vp, P, (const char*)geom, open_bits, D, D_dev,
+                       reinterpret_cast<uint32_t*>(geom + L.offs_b));
+    return hipGetLastError();
+}
+
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
-                         bool pre_zeroed, const uint32_t* D_dev, bool keys16) {
+                         bool pre_zeroed, const uint32_t* D_dev, bool keys16, uint32_t base) {
     if (!pre_zeroed) {
         hipError_t e = launch_zero(ranges, sizeof(uint2) * (size_t)num_tiles, s);
         if (e != hipSuccess) return e;
@@ -394,9 +578,9 @@ hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num
     const dim3 grid((unsigned)((D + 1023) / 1024)), block(256);
     if (keys16)
         hipLaunchKernelGGL(ranges_kernel<uint16_t>, grid, block, 0, s, reinterpret_cast<const uint16_t*>(keys), D, ranges, num_tiles,
-                           D_dev);
+                           D_dev, base);
     else
-        hipLaunchKernelGGL(ranges_kernel<uint32_t>, grid, block, 0, s, keys, D, ranges, num_tiles, D_dev);
+        hipLaunchKernelGGL(ranges_kernel<uint32_t>, grid, block, 0, s, keys, D, ranges, num_tiles, D_dev, base);
     return hipGetLastError();
 }
 

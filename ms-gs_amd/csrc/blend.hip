@@ -116,7 +116,7 @@ __device__ __forceinline__ void clear_slice(uint4* __restrict__ p, size_t n16) {
 // forward's waves walked (`walked`, wave-uniform).
 __device__ __forceinline__ void note_tile_last(uint32_t* s_wlast, int nwaves, uint32_t last, uint32_t walked, int tile, int w,
                                                int lane, uint32_t* __restrict__ tile_last,
-                                               uint32_t* __restrict__ order_flag) {
+                                               uint32_t* __restrict__ order_flag, unsigned long long* __restrict__ dtrav = nullptr) {
     if (tile_last == nullptr) return;
     const uint32_t wl = wave_max_u32(last);
     if (lane == 0) { s_wlast[w] = wl; s_wlast[nwaves + w] = walked; }
@@ -125,6 +125,8 @@ __device__ __forceinline__ void note_tile_last(uint32_t* s_wlast, int nwaves, ui
         uint32_t m = 0, q = 0;
         for (int k = 0; k < nwaves; ++k) { m = max(m, s_wlast[k]); q += s_wlast[nwaves + k]; }
         tile_last[tile] = (52u * m + 36u * q) >> 4;
+        // entries of this tile's list that are traversed (sum over the tiles = D_trav), into one of DTRAV_SLOTS accumulators
+        if (dtrav) atomicAdd(&dtrav[tile & (DTRAV_SLOTS - 1)], (unsigned long long)m);
         if (blockIdx.x == 0 && order_flag) *order_flag = 0u;
     }
 }
@@ -134,6 +136,15 @@ __device__ __forceinline__ void note_tile_last(uint32_t* s_wlast, int nwaves, ui
 // the same order (bit-identical images, test_blend_granularities_agree).
 struct FwdPix {
     float T, C0, C1, C2, aps, adp;
+};
+// depth-slab binning (msgs_view_t.slab_fraction) and feedback: what blend_forward_kernel does besides blending
+struct FwdSlab {
+    uint32_t* open_bits;          // slab A: publish the tiles that are still open here (bitmap) ...
+    uint32_t* open_list;          // ... and here (list, any order)
+    uint32_t* n_open;             // ... counted here
+    const uint32_t* tile_list;    // slab B: blend only these tiles
+    const uint32_t* n_tiles;      // ... this many
+    unsigned long long* dtrav;    // D_trav accumulators (feedback; nullable)
 };
 // lp[0..cnt): BYTE offsets of the batch's 16-byte records this wave has to evaluate, in list order.  `alive` = lanes still
 // blending, as a SCALAR mask: every predicate is the ballot of one direct comparison combined with scalar logic (a ballot
@@ -154,8 +165,6 @@ struct LaneStats { uint32_t steps, alive, blended; };
 // measured the same time and was not kept; eight entries per trip: 184 us, no gain.)
 constexpr int LIST_PAD = 4;
 constexpr uint32_t SENTINEL_OFF = (uint32_t)BATCH << 4;
-constexpr int SBATCH = 128;                                   // records per batch of the strip kernel (below)
-constexpr uint32_t SENTINEL_OFF_S = (uint32_t)SBATCH << 4;
 
 __device__ __forceinline__ void write_sentinel_record(float4* s_r0, float4* s_r1, float4* s_r2) {
     s_r0[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,7 +176,7 @@ __device__ __forceinline__ void pad_list(uint32_t* lp, int cnt, int lane) {
     if (lane < LIST_PAD - 1) lp[cnt + lane] = SENTINEL_OFF;
 }
 
-template <bool COUNT = false, uint32_t SENT = SENTINEL_OFF>
+template <bool COUNT = false>
 __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, const float4* s_r0, const float4* s_r1,
                                                  const float4* s_r2, float pxf, float pyf, FwdPix& st, uint64_t& alive_io,
                                                  uint32_t& walked, LaneStats* stats = nullptr) {
@@ -192,9 +201,8 @@ __device__ __forceinline__ uint32_t forward_walk(const uint32_t* lp, int cnt, co
         const uint64_t validm = alive & m_pow & m_alpha;
         const uint64_t stopm = validm & m_stop;
         if (COUNT) {
-            // (per-row lists of the strip kernel: a trip counts when any row holds a real entry; a row on padding evaluates the
-            //  sentinel record and can never blend)
-            if (__builtin_amdgcn_ballot_w64(off != SENT) != 0) {
+            // (a trip on padding evaluates the sentinel record and can never blend: not counted)
+            if (off != SENTINEL_OFF) {
                 stats->steps += 1u; stats->alive += (uint32_t)__popcll(alive); stats->blended += (uint32_t)__popcll(validm & ~stopm);
             }
         }
@@ -237,8 +245,9 @@ __device__ __forceinline__ void forward_store(const FwdPix& st, uint32_t last, b
 // ---------------------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------------------
+// (the kernel: blend_forward_kernel below — one call per workgroup, or, for slab B, one call per listed tile)
 template <bool COUNT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+__device__ __forceinline__ void blend_forward_tile(int tile, const ViewParams& vp, const GaussRec* __restrict__ rec,
                                                             const uint32_t* __restrict__ ids,
                                                             const uint2* __restrict__ ranges,
                                                             float* __restrict__ out_color,
@@ -247,18 +256,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
                                                             unsigned long long* __restrict__ lane_stats,
-                                                            uint4* __restrict__ clear_ptr, size_t clear_n16,
                                                             uint32_t* __restrict__ tile_last,
-                                                            uint32_t* __restrict__ order_flag) {
-    __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
-    __shared__ uint32_t s_mask[BATCH];
-    __shared__ uint32_t s_wlast[8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + LIST_PAD];
-    clear_slice(clear_ptr, clear_n16);
-    if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
-
-    const int num_tiles = vp.gx * vp.gy;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
+                                                            uint32_t* __restrict__ order_flag, const FwdSlab& sb,
+                                                            float4* s_r0, float4* s_r1, float4* s_r2, uint32_t* s_mask,
+                                                            uint32_t* s_wlast, uint32_t (*s_list)[BATCH + LIST_PAD]) {
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int px = tx * TILE + (w & 1) * 8 + (lane & 7);
@@ -311,160 +312,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         }
     } else {
         forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-        note_tile_last(s_wlast, 4, inside ? last : 0u, walked, tile, w, lane, tile_last, order_flag);
+        // slab A: a pixel that is still blending at the end of this list may blend entries of slab B — the tile stays OPEN and
+        // is blended again over its complete list (which then also counts its traversed entries).  Where every pixel has
+        // terminated (Q7) nothing behind the list is ever evaluated: the tile is done, bit for bit.
+        const bool open = sb.open_bits != nullptr && __syncthreads_or(alive != 0);
+        note_tile_last(s_wlast, 4, inside ? last : 0u, walked, tile, w, lane, tile_last, order_flag, open ? nullptr : sb.dtrav);
+        if (open && threadIdx.x == 0) {
+            atomicOr(&sb.open_bits[tile >> 5], 1u << (tile & 31));
+            sb.open_list[atomicAdd(sb.n_open, 1u)] = (uint32_t)tile;
+        }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K6, strip lists (gen 3): the same workgroup / wave / lane <-> pixel mapping as blend_forward_kernel, but every DPP ROW of a
-// wave — sixteen lanes = an 8x2 pixel strip of the wave's quadrant — walks its OWN entry list, the four rows in lock step:
-// in one trip row r evaluates entry j of list r.  An entry reaches an 8x2 strip far less often than an 8x8 quadrant, so the
-// longest of the four lists is shorter than the quadrant's list (simulated on the C3 scene: 0.84x the trips, lane efficiency
-// 0.53 -> 0.63), at the same instructions per trip: the walk is forward_walk unchanged, reading the list and the records
-// through per-lane LDS addresses (a ds_read_b128 serves a 16-lane row per pass either way).  Rows on a shorter list evaluate
-// the sentinel record.  Same arithmetic per pixel in the same order: outputs bit-identical to blend_forward_kernel.
-// Strip membership: the exact quadrant test of the loading thread AND
-//   STRIP_EXACT = false: the y-extent of the level set (gy +- sqrt(A tau / det), one sqrt per record) overlaps the strip's two
-//                        pixel rows — conservative (ignores the quadrant's x-range), ~12 instructions per 64 records and wave;
-//   STRIP_EXACT = true:  the exact 8x2 rectangle test (levelset_hits_rect) — four tests per (record, wave).
-// 128 records per batch: the sixteen lists of a workgroup (4 waves x 4 rows x 132 words) and the records fit 15 KB, so that
-// eight workgroups stay resident per CU (the walk is issue-bound and wants 8 waves per SIMD).
-// ---------------------------------------------------------------------------------------------
-// MODE (round 4: the same kernel with 4x4 BLOCK lists — a DPP row owns a 4x4 pixel block of the wave's quadrant instead of an 8x2
-// strip; lane l of row r <-> pixel ((r & 1) * 4 + (l & 3), (r >> 1) * 4 + (l >> 2)) of the quadrant; more compact than a strip, so
-// an entry reaches it less often):
-//   0 strips by y-extent, 1 strips exact;  2 blocks by the level set's BOUNDING BOX (x- and y-extent, two sqrt per record, computed
-//   once by the loading thread: a block is listed when both extents overlap it — conservative), 3 blocks by the exact 4x4 test.
-template <bool COUNT, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void blend_forward_strip_kernel(
-    ViewParams vp, const GaussRec* __restrict__ rec, const uint32_t* __restrict__ ids, const uint2* __restrict__ ranges,
-    float* __restrict__ out_color, float* __restrict__ out_ps, float* __restrict__ out_depth, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, unsigned long long* __restrict__ lane_stats, uint4* __restrict__ clear_ptr,
-    size_t clear_n16, uint32_t* __restrict__ tile_last, uint32_t* __restrict__ order_flag) {
-    __shared__ float4 s_r0[SBATCH + 1], s_r1[SBATCH + 1], s_r2[SBATCH + 1];     // slot SBATCH: the sentinel record
-    __shared__ float s_tau[SBATCH];                                             // (s_r2.w carries the sign-test bound)
-    __shared__ uint32_t s_mask[SBATCH];
-    __shared__ float2 s_yr[SBATCH];                                              // y-extent of the alpha >= 1/255 level set
-    __shared__ float2 s_xr[MODE == 2 ? SBATCH : 1];                              // x-extent (block lists by bounding box)
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][4][SBATCH + LIST_PAD];
-    constexpr bool STRIP_EXACT = MODE == 1;
-    constexpr bool BLOCKS = MODE >= 2;
+template <bool COUNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void blend_forward_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
+                                                            const uint32_t* __restrict__ ids,
+                                                            const uint2* __restrict__ ranges,
+                                                            float* __restrict__ out_color,
+                                                            float* __restrict__ out_ps,
+                                                            float* __restrict__ out_depth,
+                                                            float* __restrict__ final_T,
+                                                            uint32_t* __restrict__ n_contrib,
+                                                            unsigned long long* __restrict__ lane_stats,
+                                                            uint4* __restrict__ clear_ptr, size_t clear_n16,
+                                                            uint32_t* __restrict__ tile_last,
+                                                            uint32_t* __restrict__ order_flag, FwdSlab sb) {
+    __shared__ float4 s_r0[BATCH + 1], s_r1[BATCH + 1], s_r2[BATCH + 1];     // slot BATCH: the sentinel record
+    __shared__ uint32_t s_mask[BATCH];
     __shared__ uint32_t s_wlast[8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + LIST_PAD];
     clear_slice(clear_ptr, clear_n16);
+    if (threadIdx.x == 0) write_sentinel_record(s_r0, s_r1, s_r2);          // ordered by the first barrier of the batch loop
+    if (sb.tile_list == nullptr) {
+        blend_forward_tile<COUNT>(swizzled_tile(blockIdx.x, vp.gx * vp.gy), vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T,
+                                  n_contrib, lane_stats, tile_last, order_flag, sb, s_r0, s_r1, s_r2, s_mask, s_wlast, s_list);
+        return;
+    }
+    // slab B: the tiles slab A left open, in the order they were listed; a small grid walks the list (normally a handful of
+    // tiles: a grid of one workgroup per tile of the image would spend 25 us at 4K on workgroups that only learn that)
+    const uint32_t n = *sb.n_tiles;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        blend_forward_tile<COUNT>((int)sb.tile_list[k], vp, rec, ids, ranges, out_color, out_ps, out_depth, final_T, n_contrib,
+                                  lane_stats, tile_last, order_flag, sb, s_r0, s_r1, s_r2, s_mask, s_wlast, s_list);
+        __syncthreads();            // the staged batch and the per-wave slots are reused by the next tile
+    }
+}
+
+// Feedback publication (msgs_view_t.feedback_tag): one wave sums the D_trav accumulators and writes
+// {D_trav, tag | n_open, DA | DB, D | ticket} into words 4..7 of the forward's pinned status block (the last word last).
+__global__ __launch_bounds__(64) void forward_feedback_kernel(const unsigned long long* __restrict__ dtrav,
+                                                              const SlabHeader* __restrict__ hdr, int slab_mode,
+                                                              int64_t D_host, const uint32_t* __restrict__ D_dev, uint32_t tag,
+                                                              uint64_t ticket, volatile uint64_t* __restrict__ host) {
+    static_assert(DTRAV_SLOTS == 64, "one accumulator per lane");
+    unsigned long long acc = dtrav[threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1)
+        acc += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)acc, off);
     if (threadIdx.x == 0) {
-        s_r0[SBATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_r1[SBATCH] = make_float4(0.f, -1.0e30f, 0.f, 0.f);
-        s_r2[SBATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int num_tiles = vp.gx * vp.gy;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
-    const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, row = lane >> 4;
-    const int px = tx * TILE + (w & 1) * 8 + (BLOCKS ? (row & 1) * 4 + (lane & 3) : (lane & 7));
-    const int py = ty * TILE + (w >> 1) * 8 + (BLOCKS ? (row >> 1) * 4 + ((lane >> 2) & 3) : (lane >> 3));
-    const bool inside = px < vp.W && py < vp.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
-    const uint2 range = ranges[tile];
-    const int len = (int)(range.y - range.x);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const float qx0 = tx0 + (float)((w & 1) * 8), qy0 = ty0 + (float)((w >> 1) * 8);   // this wave's quadrant
-
-    FwdPix st = {1.0f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    LaneStats ls = {0u, 0u, 0u};
-    uint32_t last = 0, walked = 0;
-    uint64_t alive = __builtin_amdgcn_ballot_w64(inside);
-    uint32_t* const my_list = s_list[w][row];
-
-    for (int base = 0; base < len; base += SBATCH) {
-        if (__syncthreads_and(alive == 0)) break;    // barrier also protects the LDS batch
-        const int n = min(SBATCH, len - base);
-        if (tid < n) {
-            const uint32_t id = ids[range.x + base + tid];
-            const float4 r0 = rec[id].r0, r1 = rec[id].r1, r2 = rec[id].r2;
-            s_r0[tid] = doubled_w(r0); s_r1[tid] = r1; s_r2[tid] = with_bound(r2, r1.y); s_tau[tid] = r2.w;
-            s_mask[tid] = quadrant_mask(r0, r1.x, r2.w, tx0, ty0);
-            // y-extent of {f >= tau2}: |dy| <= sqrt(A tau2 / det) (levelset_rows_setup); everything when it cannot be bounded
-            float ylo = -3.0e38f, yhi = 3.0e38f, xlo = -3.0e38f, xhi = 3.0e38f;
-            if (r2.w > -1.0e38f) {
-                const float det = r0.z * r1.x - r0.w * r0.w;
-                const float e = sqrtf(fmaxf(0.0f, (r0.z * r2.w) / det)) + 0.05f;
-                if (det > 0.0f && e == e) { ylo = r0.y - e; yhi = r0.y + e; }
-                if (MODE == 2) {       // |dx| <= sqrt(C tau2 / det)
-                    const float ex = sqrtf(fmaxf(0.0f, (r1.x * r2.w) / det)) + 0.05f;
-                    if (det > 0.0f && ex == ex) { xlo = r0.x - ex; xhi = r0.x + ex; }
-                }
-            }
-            s_yr[tid] = make_float2(ylo, yhi);
-            if (MODE == 2) s_xr[tid] = make_float2(xlo, xhi);
-        }
-        __syncthreads();
-        // four row lists per wave: ballot + popcount prefix per strip
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (int c = 0; c < SBATCH / 64; ++c) {
-            const int e = c * 64 + lane;
-            const bool hitq = e < n && ((s_mask[e] >> w) & 1u);
-            bool b0 = false, b1 = false, b2 = false, b3 = false;
-            if (hitq) {
-                if (MODE == 3) {               // exact 4x4 block test
-                    const float4 r0 = s_r0[e];
-                    const float C = s_r1[e].x, tau2 = s_tau[e];
-                    if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
-                    else {
-                        b0 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 3.0f, qy0, qy0 + 3.0f);
-                        b1 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0 + 4.0f, qx0 + 7.0f, qy0, qy0 + 3.0f);
-                        b2 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 3.0f, qy0 + 4.0f, qy0 + 7.0f);
-                        b3 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0 + 4.0f, qx0 + 7.0f, qy0 + 4.0f, qy0 + 7.0f);
-                    }
-                } else if (MODE == 2) {        // bounding box of the level set against the four blocks
-                    const float2 yr = s_yr[e], xr = s_xr[e];
-                    const bool xl = xr.x <= qx0 + 3.0f && xr.y >= qx0, xh = xr.x <= qx0 + 7.0f && xr.y >= qx0 + 4.0f;
-                    const bool yl = yr.x <= qy0 + 3.0f && yr.y >= qy0, yh = yr.x <= qy0 + 7.0f && yr.y >= qy0 + 4.0f;
-                    b0 = xl && yl; b1 = xh && yl; b2 = xl && yh; b3 = xh && yh;
-                } else if (STRIP_EXACT) {
-                    const float4 r0 = s_r0[e];
-                    const float C = s_r1[e].x, tau2 = s_tau[e];
-                    if (!(tau2 > -1.0e38f)) { b0 = b1 = b2 = b3 = true; }
-                    else {
-                        b0 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0, qy0 + 1.0f);
-                        b1 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0 + 2.0f, qy0 + 3.0f);
-                        b2 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0 + 4.0f, qy0 + 5.0f);
-                        b3 = levelset_hits_rect(r0.x, r0.y, r0.z, 0.5f * r0.w, C, tau2, qx0, qx0 + 7.0f, qy0 + 6.0f, qy0 + 7.0f);
-                    }
-                } else {
-                    const float2 yr = s_yr[e];
-                    b0 = yr.x <= qy0 + 1.0f && yr.y >= qy0;
-                    b1 = yr.x <= qy0 + 3.0f && yr.y >= qy0 + 2.0f;
-                    b2 = yr.x <= qy0 + 5.0f && yr.y >= qy0 + 4.0f;
-                    b3 = yr.x <= qy0 + 7.0f && yr.y >= qy0 + 6.0f;
-                }
-            }
-            const uint32_t off = (uint32_t)(e << 4);
-            const uint64_t B0 = __ballot(b0), B1 = __ballot(b1), B2 = __ballot(b2), B3 = __ballot(b3);
-            if (b0) s_list[w][0][c0 + __popcll(B0 & lt_mask)] = off;
-            if (b1) s_list[w][1][c1 + __popcll(B1 & lt_mask)] = off;
-            if (b2) s_list[w][2][c2 + __popcll(B2 & lt_mask)] = off;
-            if (b3) s_list[w][3][c3 + __popcll(B3 & lt_mask)] = off;
-            c0 += __popcll(B0); c1 += __popcll(B1); c2 += __popcll(B2); c3 += __popcll(B3);
-        }
-        // lock step: the trip count is the longest list (rounded up to the four entries of a trip); shorter lists are padded
-        // with the sentinel record by their own sixteen lanes
-        const int cnt = (max(max(c0, c1), max(c2, c3)) + LIST_PAD - 1) & ~(LIST_PAD - 1);
-        const int mine = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
-        for (int j = mine + (lane & 15); j < cnt; j += 16) my_list[j] = SENTINEL_OFF_S;
-        const uint32_t last_off = forward_walk<COUNT, SENTINEL_OFF_S>(my_list, cnt, s_r0, s_r1, s_r2, pxf, pyf, st, alive, walked, &ls);
-        if (last_off != 0xFFFFFFFFu) last = (uint32_t)base + (last_off >> 4) + 1u;
-    }
-    if (COUNT) {
-        if (lane == 0) {
-            atomicAdd(&lane_stats[0], (unsigned long long)ls.steps);
-            atomicAdd(&lane_stats[1], (unsigned long long)ls.alive);
-            atomicAdd(&lane_stats[2], (unsigned long long)ls.blended);
-        }
-    } else {
-        forward_store(st, last, inside, px, py, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-        note_tile_last(s_wlast, 4, inside ? last : 0u, walked, tile, w, lane, tile_last, order_flag);
+        const uint64_t D = D_dev ? (uint64_t)*D_dev : (uint64_t)D_host;
+        const bool overflow = slab_mode && hdr->pad0 != 0u;
+        host[4] = (uint64_t)acc | (overflow ? (1ull << 63) : 0ull);
+        host[5] = (uint64_t)tag | ((uint64_t)(slab_mode ? hdr->n_open : 0xFFFFFFFFu) << 32);
+        host[6] = slab_mode ? ((uint64_t)hdr->DA | ((uint64_t)hdr->DB << 32)) : 0ull;
+        __threadfence_system();
+        host[7] = (D & 0xFFFFFFFFFFull) | ((ticket & 0xFFFFFFull) << 40);
     }
 }
 
@@ -851,9 +762,9 @@ __global__ __launch_bounds__(64 * WAVES) void blend_backward_fine_kernel(ViewPar
 }
 
 // ---------------------------------------------------------------------------------------------
-// v2 kernels: ONE wave64 per tile, four pixels per lane (lane l owns pixel (l & 7, l >> 3) of each of the
+// one-wave-per-tile backward: ONE wave64 per tile, four pixels per lane (lane l owns pixel (l & 7, l >> 3) of each of the
 // four 8x8 quadrants).  Everything that is uniform over the tile — record fetch from LDS, loop control,
-// and in the backward the 64-lane reduction and the atomics — is paid once per (tile, Gaussian) instead of
+// the 64-lane reduction and the atomics — is paid once per (tile, Gaussian) instead of
 // once per (quadrant, Gaussian); the quadrant hit mask becomes a wave-uniform branch per quadrant; there is
 // no workgroup barrier (a single wave owns the tile) and the next batch of 64 records is prefetched into
 // registers while the current one is consumed.  The four per-quadrant evaluations are independent, which
@@ -865,126 +776,6 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// per-quadrant pixel state kept as independent scalars (arrays indexed by an unrolled q made the compiler
-// pack them into register tuples and copy whole tuples at every branch merge)
-struct FwdQuad {
-    float T, C0, C1, C2, aps, adp;
-    uint32_t last;
-    bool done;
-};
-
-// one (pixel, Gaussian) forward step; returns true (wave-uniform) when the quadrant just became fully done
-__device__ __forceinline__ bool fwd_quad_step(FwdQuad& s, const float4& r0, const float4& r1, const float4& r2,
-                                              float dx, float dy, uint32_t pos) {
-    const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
-    const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(ev.p));
-    const bool valid = !s.done && ev.p <= r2.w && alpha >= ALPHA_MIN;      // power <= 0 (sign_test_bound), alpha >= 1/255
-    const float test_T = __fmaf_rn(-s.T, alpha, s.T);
-    const bool stop = valid && test_T < T_MIN;
-    s.done = s.done || stop;
-    const bool blend = valid && !stop;
-    const float wgt = blend ? alpha * s.T : 0.0f;
-    s.C0 = fmaf(r1.z, wgt, s.C0); s.C1 = fmaf(r1.w, wgt, s.C1); s.C2 = fmaf(r2.x, wgt, s.C2);
-    s.adp = fmaf(r2.y, wgt, s.adp); s.aps = fmaf(r2.z, wgt, s.aps);
-    s.T = blend ? test_T : s.T;
-    s.last = blend ? pos : s.last;
-    return __ballot(stop) != 0 && __ballot(!s.done) == 0;
-}
-
-__device__ __forceinline__ void fwd_quad_store(const FwdQuad& s, int px, int py, const ViewParams& vp,
-                                               float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                               uint32_t* n_contrib) {
-    if (px < vp.W && py < vp.H) {
-        const size_t N = (size_t)vp.W * vp.H;
-        const size_t pix = (size_t)py * vp.W + px;
-        out_color[pix] = s.C0 + s.T * vp.bg[0];
-        out_color[N + pix] = s.C1 + s.T * vp.bg[1];
-        out_color[2 * N + pix] = s.C2 + s.T * vp.bg[2];
-        out_ps[pix] = s.aps;
-        out_depth[pix] = s.adp;
-        final_T[pix] = s.T;
-        n_contrib[pix] = s.last;
-    }
-}
-
-__global__ __launch_bounds__(64) void blend_forward_tile_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
-                                                                const uint32_t* __restrict__ ids,
-                                                                const uint2* __restrict__ ranges,
-                                                                float* __restrict__ out_color,
-                                                                float* __restrict__ out_ps,
-                                                                float* __restrict__ out_depth,
-                                                                float* __restrict__ final_T,
-                                                                uint32_t* __restrict__ n_contrib,
-                                                                uint4* __restrict__ clear_ptr, size_t clear_n16,
-                                                                uint32_t* __restrict__ tile_last,
-                                                                uint32_t* __restrict__ order_flag) {
-    __shared__ float4 s_r0[WB], s_r1[WB], s_r2[WB];
-    __shared__ uint32_t s_wlast[2];
-    clear_slice(clear_ptr, clear_n16);
-    const int num_tiles = vp.gx * vp.gy;
-    const int lane = threadIdx.x;
-    const int tile = swizzled_tile(blockIdx.x, num_tiles);
-    const int tx = tile % vp.gx, ty = tile / vp.gx;
-    const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);     // pixel of quadrant 0
-    const float bxf = (float)bx, byf = (float)by;
-    const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
-    const uint2 range = ranges[tile];
-    const int len = (int)(range.y - range.x);
-
-    FwdQuad q0, q1, q2, q3;
-    uint32_t alive = 0;                                   // wave-uniform: quadrants with a live pixel
-    {
-        auto init = [&](FwdQuad& s, int qi) {
-            s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.aps = s.adp = 0.f; s.last = 0;
-            s.done = !(bx + (qi & 1) * 8 < vp.W && by + (qi >> 1) * 8 < vp.H);
-            if (__ballot(!s.done) != 0) alive |= 1u << qi;
-        };
-        init(q0, 0); init(q1, 1); init(q2, 2); init(q3, 3);
-    }
-
-    // prefetch of the first batch
-    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-    if (lane < len) {
-        const uint32_t id = ids[range.x + lane];
-        n0 = rec[id].r0; n1 = rec[id].r1; n2 = rec[id].r2;
-    }
-    for (int base = 0; base < len && alive; base += WB) {
-        const int n = min(WB, len - base);
-        wave_fence();                                     // previous batch fully consumed
-        s_r0[lane] = doubled_w(n0); s_r1[lane] = n1; s_r2[lane] = with_bound(n2, n1.y);
-        // quadrant hit masks of the whole batch as four 64-bit ballots (bit e = record e): wave-uniform, in SGPRs
-        const uint32_t mymask = lane < n ? quadrant_mask(n0, n1.x, n2.w, tx0, ty0) : 0u;
-        const uint64_t h0 = __ballot(mymask & 1u), h1 = __ballot(mymask & 2u), h2 = __ballot(mymask & 4u),
-                       h3 = __ballot(mymask & 8u);
-        wave_fence();
-        if (base + WB + lane < len) {                     // prefetch the next batch
-            const uint32_t id = ids[range.x + base + WB + lane];
-            n0 = rec[id].r0; n1 = rec[id].r1; n2 = rec[id].r2;
-        }
-        uint64_t todo = h0 | h1 | h2 | h3;
-        while (todo && alive) {
-            const int e = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint64_t bit = 1ull << e;
-            const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
-            const float dx = r0.x - bxf, dy = r0.y - byf;
-            const uint32_t pos = (uint32_t)(base + e + 1);
-            if ((h0 & bit) && (alive & 1u)) { if (fwd_quad_step(q0, r0, r1, r2, dx, dy, pos)) alive &= ~1u; }
-            if ((h1 & bit) && (alive & 2u)) { if (fwd_quad_step(q1, r0, r1, r2, dx - 8.0f, dy, pos)) alive &= ~2u; }
-            if ((h2 & bit) && (alive & 4u)) { if (fwd_quad_step(q2, r0, r1, r2, dx, dy - 8.0f, pos)) alive &= ~4u; }
-            if ((h3 & bit) && (alive & 8u)) { if (fwd_quad_step(q3, r0, r1, r2, dx - 8.0f, dy - 8.0f, pos)) alive &= ~8u; }
-        }
-    }
-    fwd_quad_store(q0, bx, by, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    fwd_quad_store(q1, bx + 8, by, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    fwd_quad_store(q2, bx, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    fwd_quad_store(q3, bx + 8, by + 8, vp, out_color, out_ps, out_depth, final_T, n_contrib);
-    {
-        const uint32_t l = max(max(q0.last, q1.last), max(q2.last, q3.last));
-        note_tile_last(s_wlast, 1, l, 2u * __builtin_amdgcn_readfirstlane(wave_max_u32(l)), tile, 0, lane, tile_last, order_flag);
-    }
 }
 
 // 64-lane all-reduce of a double (deterministic mode only): the same butterfly as wave_allreduce_sum, every move on the two
@@ -1097,7 +888,6 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
     if (tile_order != nullptr) {
         const uint32_t flag = tile_order[num_tiles];
         if (flag == TILE_ORDER_MAGIC) tile = (int)tile_order[tile];                       // per XCD run
-        else if (flag == TILE_ORDER_MAGIC + 1u) tile = (int)tile_order[blockIdx.x];       // one global sequence
     }
     const int tx = tile % vp.gx, ty = tile / vp.gx;
     const int bx = tx * TILE + (lane & 7), by = ty * TILE + (lane >> 3);
@@ -1259,17 +1049,12 @@ __global__ __launch_bounds__(256) void visible_count_kernel(int P, const int32_t
 
 }  // namespace
 
-// Two generations of blend kernels exist (A/B numbers in profiles/r1_notes.md):
-//   gen 1: one 256-thread workgroup per tile, one quadrant per wave        (forward 229 us, backward 663 us at C3)
-//   gen 2: one wave64 per tile, four pixels per lane, reduction per tile   (forward 405 us, backward ~550 us)
-// Default = gen-1 forward + gen-2 backward.  MSGS_FWD_GEN / MSGS_BWD_GEN = 1 | 2 override for measurements.
-// (A packed-fp32 forward with two pixels per lane was also built and measured: correct but 17 % slower —
-// v_pk_*_f32 is not full rate on gfx950 — and removed; for the same reason this library is compiled with
-// -fno-slp-vectorize, which alone took the backward from 558 to 495 us.)
-static int env_gen(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : dflt;
-}
+// Forward: one 256-thread workgroup per tile, one 8x8 quadrant per wave (229 us at C3 in round 1 against 405 us for one wave per
+// tile; the strip / 4x4-block list variants of rounds 3-4 measured slower as well — profiles/design_history_r1_r4.md, git history).
+// Backward: one wave64 per tile, four pixels per lane, one reduction per (tile, Gaussian) from 4096 tiles up; four waves per tile
+// below.  (A packed-fp32 forward with two pixels per lane was also built and measured: correct but 17 % slower — v_pk_*_f32 is
+// not full rate on gfx950 — and removed; for the same reason this library is compiled with -fno-slp-vectorize, which alone took
+// the backward from 558 to 495 us.)
 // backward generation: MSGS_BWD_GEN = 1 | 2 forces one; default (0) picks by tile count — one wave per tile (gen 2) needs
 // >= ~4000 tiles to occupy 1024 SIMDs, below that four waves per tile (gen 1) win (C3 scene, profiles/r1_notes.md:
 // 8160 tiles 437 vs 667 us; 2040 tiles 334 vs 297; 510 tiles 481 vs 205; 135 tiles 834 vs 303; 2 tiles 1378 vs 431)
@@ -1279,11 +1064,6 @@ constexpr int BWD_GEN2_MIN_TILES = 4096;
 // 135 tiles 262 -> 185, 40 tiles 372 -> 236
 constexpr int FINE_MAX_TILES_FWD = 300, FINE_MAX_TILES_BWD = 300;     // (round 3 sweep: 510 tiles forward 102 us coarse vs 127 fine;
                                                                        //  135 tiles 155 vs 104; backward 510 tiles 168 vs 229, 135 tiles 263 vs 182)
-// forward kernel variant: 1 = quadrant lists (one 8x8 quadrant per wave), 2 = one wave per tile, 3 = 8x2 strip lists with the
-// y-extent strip test, 4 = strip lists with the exact strip test; MSGS_FWD_GEN / msgs_set_forward_variant
-constexpr int FWD_GEN_DEFAULT = 1;
-static std::atomic<int> g_fwd_gen{env_gen("MSGS_FWD_GEN", FWD_GEN_DEFAULT)};
-int set_forward_variant(int v) { return g_fwd_gen.exchange(v >= 1 && v <= 6 ? v : FWD_GEN_DEFAULT); }
 static std::atomic<int> g_bwd_gen{[] { const char* e = getenv("MSGS_BWD_GEN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }()};
 int set_backward_generation(int gen) { return g_bwd_gen.exchange(gen == 1 || gen == 2 ? gen : 0); }
 // blend granularity: 0 = by tile count, 1 = coarse (quadrant / tile per wave), 2 = fine (4x4 sub-block per wave)
@@ -1291,8 +1071,7 @@ static std::atomic<int> g_granularity{[] { const char* e = getenv("MSGS_BLEND_GR
 int set_blend_granularity(int mode) { return g_granularity.exchange(mode == 1 || mode == 2 ? mode : 0); }
 // Shape of the fine-grained kernels: the sub-block side SB a wave owns (4 | 2 | 1 -> 16 | 64 | 256 waves per tile) and the
 // number G of workgroups a tile's waves are split over (every workgroup stages and classifies the tile's whole list).
-// MSGS_FINE_SB = 1 | 2 | 4 and MSGS_FINE_SPLIT = 1 .. 64 force them.  Measured on the pyramid of the C3 scene, forward / backward
-// us at 135, 40, 12, 2 tiles (profiles/r3_notes.md):
+// Measured on the pyramid of the C3 scene, forward / backward us at 135, 40, 12, 2 tiles (profiles/r3_notes.md):
 //   SB 4: G = 1: 105/184, 139/228, 146/241, 132/224;  G = 2: 87/152, 114/192, 115/194, 100/175;  G = 4: 87/140, 111/180, 108/182,
 //         98/166;  G = 8: 112/151, 133/190, 138/188, 117/166;  G = 16: 152/164, 158/198, 149/176, 130/162
 //   SB 2: G = 4: 156/251, 104/140, 100/133, 95/129;  G = 8: 128/181, 85/122, 83/117, 75/107;  G = 16: 122/168, 82/111, 82/107,
@@ -1301,15 +1080,10 @@ int set_blend_granularity(int mode) { return g_granularity.exchange(mode == 1 ||
 // i.e. the best shape keeps 2000-3000 waves in flight: 4x4 blocks down to ~64 tiles, 2x2 blocks down to ~16, single pixels below.
 struct FineShape { int sb, g; };
 static FineShape fine_shape(int tiles) {
-    static const int forced_sb = [] { const char* e = getenv("MSGS_FINE_SB"); const int v = e ? atoi(e) : 0;
-                                      return (v == 1 || v == 2 || v == 4) ? v : 0; }();
-    static const int forced_g = [] { const char* e = getenv("MSGS_FINE_SPLIT"); const int v = e ? atoi(e) : 0;
-                                     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0; }();
     FineShape f;
-    f.sb = forced_sb ? forced_sb : (tiles <= 16 ? 1 : (tiles <= 64 ? 2 : 4));
-    const int dflt = f.sb == 1 ? 64 : (f.sb == 2 ? 16 : (tiles < 768 ? 4 : 1));   // (>= 768 tiles only when forced: one workgroup
-    f.g = forced_g ? forced_g : dflt;                                               //  per tile fills the chip)
-    return f;
+    f.sb = tiles <= 16 ? 1 : (tiles <= 64 ? 2 : 4);
+    f.g = f.sb == 1 ? 64 : (f.sb == 2 ? 16 : (tiles < 768 ? 4 : 1));   // (>= 768 tiles — forced granularity only — one workgroup per
+    return f;                                                           //  tile fills the chip)
 }
 template <int WAVES, int SB = 4, class... Args>
 static void launch_fine_fwd(int tiles, hipStream_t s, Args... args) {
@@ -1340,17 +1114,16 @@ static bool bwd_v1(int tiles) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr int ORDER_BINS = 2048, ORDER_SHIFT = 3;
-// GLOBAL (one block): one heaviest-first sequence over all tiles, dealt to the XCDs round-robin by the dispatcher (block b ->
-// XCD b % 8): balances the XCDs against each other as well, at the price of the L2 locality of the contiguous runs.
+// (One global heaviest-first sequence dealt to the XCDs round-robin was measured too: no better, and it gives up the L2 locality
+//  of the contiguous runs.)
 // (256 threads per block since round 4: a 1024-thread block needs sixteen free wave slots on ONE CU, and with a second view in
 //  flight — host/multi_view.py — it waited 30-45 us for them behind the other view's blend workgroups; four slots are found at once)
 constexpr int ORDER_THREADS = 256, ORDER_PER_THREAD = ORDER_BINS / ORDER_THREADS;
-template <bool GLOBAL>
 __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(int num_tiles, const uint32_t* __restrict__ tile_last,
                                                                    uint32_t* __restrict__ order) {
     __shared__ uint32_t s_bin[ORDER_BINS];
     __shared__ uint32_t s_wave[ORDER_THREADS / 64];
-    const int per = GLOBAL ? num_tiles : num_tiles >> 3, main = GLOBAL ? num_tiles : per << 3;
+    const int per = num_tiles >> 3, main = per << 3;
     const int x = blockIdx.x;                           // XCD run x: swizzled positions = tiles [x * per, (x + 1) * per)
     const int tid = threadIdx.x;
     for (int b = tid; b < ORDER_BINS; b += ORDER_THREADS) s_bin[b] = 0;
@@ -1388,7 +1161,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(int num_tiles
     }
     if (x == 0) {
         for (int t = main + tid; t < num_tiles; t += ORDER_THREADS) order[t] = (uint32_t)t;      // ragged tail: identity
-        if (tid == 0) order[num_tiles] = TILE_ORDER_MAGIC + (GLOBAL ? 1u : 0u);     // visible to the backward through the stream order
+        if (tid == 0) order[num_tiles] = TILE_ORDER_MAGIC;     // visible to the backward through the stream order
     }
 }
 }  // namespace
@@ -1398,26 +1171,21 @@ static bool bwd_uses_tile_kernel(int tiles) {
 }
 
 hipError_t launch_tile_order(const ViewParams& vp, const uint32_t* tile_last, uint32_t* tile_order, hipStream_t s) {
-    // MSGS_BWD_LPT = 0: plain XCD swizzle; 1: heaviest first inside every XCD's contiguous run; 2: one global sequence
-    static const int mode = [] { const char* e = getenv("MSGS_BWD_LPT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
     const int tiles = vp.gx * vp.gy;
-    if (mode == 0 || tiles < 8 || !bwd_uses_tile_kernel(tiles)) return hipSuccess;
+    if (tiles < 8 || !bwd_uses_tile_kernel(tiles)) return hipSuccess;
     // the fine-grained forward kernels do not write tile_last (and clear the order's validity word): no order from garbage
-    if (g_granularity.load() == 2 || use_fine(tiles, FINE_MAX_TILES_FWD)) return hipSuccess;
-    if (mode == 2)
-        hipLaunchKernelGGL(tile_order_kernel<true>, dim3(1), dim3(ORDER_THREADS), 0, s, tiles, tile_last, tile_order);
-    else
-        hipLaunchKernelGGL(tile_order_kernel<false>, dim3(8), dim3(ORDER_THREADS), 0, s, tiles, tile_last, tile_order);
+    if (use_fine(tiles, FINE_MAX_TILES_FWD)) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(ORDER_THREADS), 0, s, tiles, tile_last, tile_order);
     return hipGetLastError();
 }
 
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s) {
+                                uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s,
+                                const FwdSlabArgs* slab) {
     const int tiles = vp.gx * vp.gy;
     if (tiles == 0) return clear_ptr && clear_bytes ? launch_zero(clear_ptr, clear_bytes, s) : hipSuccess;
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);   // GeomLayout::rec == 0
-    const int fwd_gen = g_fwd_gen.load();
     // the gradient records are cleared by the blend kernel itself when it has enough workgroups to spread the stores over the
     // chip; with few tiles (low pyramid levels: 2 .. 500 workgroups, measured 150 -> 410 us at 2 tiles for 80 MB) a fill
     // kernel in front of it is faster
@@ -1447,34 +1215,34 @@ hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const ui
         }
 #undef MSGS_FINE_FWD
     };
-    if (fwd_gen == 1 && use_fine(tiles, FINE_MAX_TILES_FWD))
+    FwdSlab sb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (slab) {
+        sb.dtrav = slab->dtrav;
+        if (slab->pass == 1) { sb.open_bits = slab->open_bits; sb.open_list = slab->open_list; sb.n_open = slab->n_open; }
+        if (slab->pass == 2) { sb.tile_list = slab->open_list; sb.n_tiles = slab->n_open; }
+    }
+    if (use_fine(tiles, FINE_MAX_TILES_FWD)) {
+        if (slab && slab->pass != 0) return hipErrorInvalidValue;        // (the caller engages slabs from SLAB_MIN_TILES tiles on)
         fine();
-    else if (fwd_gen == 1)
-        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
-                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last, order_flag);
-    else if (fwd_gen == 3 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 8x2 strip lists, strips by the level set's y-extent
-        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 0>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
-                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
-                           order_flag);
-    else if (fwd_gen == 4 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 8x2 strip lists, exact strip test
-        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 1>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
-                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
-                           order_flag);
-    else if (fwd_gen == 5 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 4x4 block lists by the level set's bounding box
-        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 2>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
-                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
-                           order_flag);
-    else if (fwd_gen == 6 && !use_fine(tiles, FINE_MAX_TILES_FWD))      // 4x4 block lists, exact block test
-        hipLaunchKernelGGL((blend_forward_strip_kernel<false, 3>), dim3(tiles), dim3(256), 0, s, vp, rec, ids, ranges,
-                           out_color, out_ps, out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last,
-                           order_flag);
-    else if (fwd_gen >= 3)
-        fine();
-    else
-        hipLaunchKernelGGL(blend_forward_tile_kernel, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, out_color,
-                           out_ps, out_depth, final_T, n_contrib, cp, cn, tile_last, order_flag);
+    } else {
+        // slab B walks the list of open tiles with a grid that fills the chip once (normally a handful of tiles)
+        const int grid = sb.tile_list ? std::min(tiles, 2048) : tiles;
+        hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(grid), dim3(256), 0, s, vp, rec, ids, ranges, out_color, out_ps,
+                           out_depth, final_T, n_contrib, (unsigned long long*)nullptr, cp, cn, tile_last, order_flag, sb);
+    }
     return hipGetLastError();
 }
+
+hipError_t launch_forward_feedback(const unsigned long long* dtrav, const SlabHeader* hdr, int slab_mode, int64_t D,
+                                   const uint32_t* D_dev, uint32_t tag, uint64_t ticket, uint64_t* host_mapped, hipStream_t s) {
+    if (!host_mapped || !dtrav) return hipSuccess;
+    hipLaunchKernelGGL(forward_feedback_kernel, dim3(1), dim3(64), 0, s, dtrav, hdr, slab_mode, D, D_dev, tag, ticket,
+                       (volatile uint64_t*)host_mapped);
+    return hipGetLastError();
+}
+
+// does the forward of a `tiles`-tile image run the quadrant-list kernel (the one that can publish open tiles / tile lengths)?
+bool forward_uses_quadrant_kernel(int tiles) { return tiles > 0 && !use_fine(tiles, FINE_MAX_TILES_FWD); }
 
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
@@ -1594,20 +1362,11 @@ hipError_t launch_blend_lane_stats(const ViewParams& vp, const char* geom, const
     hipError_t e = hipMemsetAsync(out3, 0, 24, s);
     if (e != hipSuccess) return e;
     const int tiles = vp.gx * vp.gy;
-    const int fwd_gen = g_fwd_gen.load();                            // the replica of the kernel variant in use
-    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
-    float* const nf = nullptr;
-#define MSGS_STRIP_COUNT(MODE) hipLaunchKernelGGL((blend_forward_strip_kernel<true, MODE>), dim3(tiles), dim3(256), 0, s, vp, rec, \
-        ids, ranges, nf, nf, nf, nf, (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr)
-    if (tiles && fwd_gen == 3) MSGS_STRIP_COUNT(0);
-    else if (tiles && fwd_gen == 4) MSGS_STRIP_COUNT(1);
-    else if (tiles && fwd_gen == 5) MSGS_STRIP_COUNT(2);
-    else if (tiles && fwd_gen == 6) MSGS_STRIP_COUNT(3);
-#undef MSGS_STRIP_COUNT
-    else if (tiles)
-        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, rec,
+    if (tiles)
+        hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(tiles), dim3(256), 0, s, vp, reinterpret_cast<const GaussRec*>(geom),
                            ids, ranges, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                           (uint32_t*)nullptr, out3, (uint4*)nullptr, (size_t)0, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                           FwdSlab{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
     return hipGetLastError();
 }
 

@@ -59,7 +59,7 @@ __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~size_
 // path.  What it buys: the multi-scale model rendered without its filters (render.py's defaults) has 427 M instances of which a
 // few million are traversed.
 // Region inside `geom` (fixed size: msgs_geom_bytes(P) does not know the image): header + one cut-off depth key per cover
-// BLOCK of B x B tiles, B = the smallest power of two from MSGS_OCC_BLOCK (default 4) up for which the grid has at most
+// BLOCK of B x B tiles, B = the smallest power of two from 4 up for which the grid has at most
 // OCC_MAX_BLOCKS blocks — the table then fits the LDS of the two kernels that look tiles up in it (emit, recount).
 // ---------------------------------------------------------------------------------------------
 constexpr int OCC_MAX_BLOCKS = 2048;
@@ -79,18 +79,34 @@ struct OccHeader {
     uint32_t nby;             // rows of cover blocks (nbx * nby <= OCC_MAX_BLOCKS)
     uint32_t n_written;       // candidate records appended so far (positions of the depth-selected gather; ends at n_cand)
     uint32_t depth_limit;     // depth bucket up to which candidates were kept (OCC_BUCKETS - 1: all; 0xFFFFFFFF: stride sample)
-    uint32_t pad[7];          // (no instance statistics: one atomic per wave on a shared word cost 0.4 ms on a view that
+    uint32_t bar[3];          // arrival counters of the pass's three grid barriers (occlusion.hip)
+    uint32_t watchdog;        // non-zero: a barrier wait expired (the pass stopped early; the state is valid, the cut weaker)
+    uint32_t pad[3];          // (no instance statistics: one atomic per wave on a shared word cost 0.4 ms on a view that
                               //  drops 420 M instances; run the view with msgs_set_occlusion(0) to learn the uncut count)
 };
 static_assert(sizeof(OccHeader) == 64, "OccHeader layout");
 // candidate record: { px, py, kA, kB | kC, log2 o, key bits, gaussian id | tile rect (minx | miny << 16, maxx | maxy << 16), -, - }
 // (the rect travels with the candidate: tile instances exist only inside it, and the alpha >= 1/255 level set of an opaque
 //  Gaussian — up to 3.33 sigma along the major axis — reaches past the 3-sigma rect: a block outside the rect is never covered)
+constexpr int SLAB_SCAN_CHUNK = 4096;       // = SCAN_CHUNK (scan_blocks), needed by GeomLayout ahead of its definition
 struct __attribute__((aligned(16))) OccCand { float4 c0, c1; uint32_t rect_lo, rect_hi, pad0, pad1; };
 static_assert(sizeof(OccCand) == 48, "OccCand layout");
 
+// Depth-slab binning (round 6; msgs_view_t.slab_fraction).  Device words of one forward:
+struct SlabHeader {
+    uint32_t rA;              // slab A = depth ranks [0, rA)                                   (slab_split_kernel)
+    uint32_t DA;              // its tile instances = offs[rA]
+    uint32_t DB;              // instances slab B emits: every instance of the view that falls into an OPEN tile (B's scan)
+    uint32_t active;          // 1 when this forward ran in slab mode
+    uint32_t n_open;          // tiles in which some pixel was still blending at the end of its slab-A list (blend A, atomics)
+    uint32_t pad0;
+    uint64_t total_b;         // B's scan total (64-bit twin of DB)
+    uint32_t pad[8];
+};
+static_assert(sizeof(SlabHeader) == 64, "SlabHeader layout");
+
 struct GeomLayout {
-    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, skey, occ_hdr, occ_cut, total;
+    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, skey, slab_hdr, occ_hdr, occ_cut, offs_b, scan_b, total;
     __host__ __device__ explicit GeomLayout(int64_t P) {
         size_t o = 0;
         rec = o;    o = align256(o + sizeof(GaussRec) * P);
@@ -104,47 +120,80 @@ struct GeomLayout {
         nvalid = o; o += 256;                       // one word: V = Gaussians that stayed in the (compacting) depth sort —
                                                     // order[0..V) / offs[0..V) are the ranks the scan and the emit cover
         skey = o;   o = align256(o + 4 * P);        // depth keys in depth order (the sort's key output): emit's cut-off test
+        slab_hdr = o; o += 256;                     // SlabHeader, directly in front of the occlusion header: K1 clears both with
+                                                    // one range
         occ_hdr = o; o = align256(o + sizeof(OccHeader) + 4 * (size_t)OCC_BUCKETS);   // header + depth histogram of the
                                                                                         // cover candidates (both cleared by K1)
         occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth bucket per cover block (0xFFFF = open)
+        offs_b = o; o = align256(o + 4 * P);        // slab B: per depth rank, instances in open tiles -> their exclusive scan
+        scan_b = o; o = align256(o + 8 * (size_t)((P + SLAB_SCAN_CHUNK - 1) / SLAB_SCAN_CHUNK + 2));   // block totals of that scan
         total = o;
     }
 };
 
-// radix sort geometry: 256 threads x SORT_ITEMS keys per block
+// radix sort geometry: 256 threads x ITEMS keys per block; ITEMS = 4 below SORT_MID_N keys (more, smaller blocks: 100k keys
+// 59 -> 50 us), 8 from there (at 1M keys 8 per thread is faster, 76 vs 88 us), 16 from SORT_BIG_N (longer digit runs per block ->
+// better write coalescing of the scatter: 94 -> 81 us at 4.1M pairs, 1.6 -> 1.2 ms at 55M)
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 4;
-constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;
-constexpr int64_t SORT_BIG_N = 2'000'000;   // from here on radix passes use 16 keys per thread
-constexpr int64_t SORT_MID_N = 400'000;     // from here on 8 keys per thread; below, SORT_ITEMS = 4 (more, smaller blocks:
-                                            // 100k keys 59 -> 50 us; at 1M keys 8 per thread is faster, 76 vs 88 us)
-constexpr int SORT_MAX_GROUPS = 128;   // group sums per digit (grouped radix path)
+constexpr int64_t SORT_BIG_N = 2'000'000;
+constexpr int64_t SORT_MID_N = 400'000;
+constexpr int SORT_MAX_GROUPS = 128;             // group sums per digit and pass below SORT_SCANNED_MIN_BLOCKS blocks
+constexpr int64_t SORT_SCANNED_MIN_BLOCKS = 4096;    // from here on (16.8 M pairs) a one-block kernel turns the group sums into bases
+constexpr int SORT_SCANNED_GSIZE = 32;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
+static_assert(SCAN_CHUNK == SLAB_SCAN_CHUNK, "GeomLayout::scan_b is sized with SLAB_SCAN_CHUNK");
 
-__host__ __device__ inline int64_t sort_blocks(int64_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
 __host__ __device__ inline int64_t scan_blocks(int64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK; }
 
-// scratch needed by one radix_sort_pairs call over n pairs (alt key/val buffers + histograms)
+// Geometry of one radix pass over n pairs: every block leaves a digit histogram (hist[block][digit]) and adds it to the sums of
+// its GROUP of gsize blocks (gsum[group][digit], integer atomics); a scatter block derives its output bases from the group sums
+// and the histograms of the earlier blocks of its own group.  Shared by the sort and by the callers that size and clear its tables.
+struct SortGeom {
+    bool big, mid, scanned;
+    int items, gsize, ngroups;
+    int64_t nb;
+    __host__ __device__ explicit SortGeom(int64_t n) {
+        if (n < 1) n = 1;
+        big = n >= SORT_BIG_N;
+        mid = !big && n >= SORT_MID_N;
+        items = big ? 16 : (mid ? 8 : SORT_ITEMS);
+        nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
+        scanned = big && nb >= SORT_SCANNED_MIN_BLOCKS;
+        if (scanned) {
+            gsize = SORT_SCANNED_GSIZE;  // short in-group walks; the number of groups is no longer what a block reads
+        } else {
+            // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
+            gsize = 8;
+            while ((int64_t)gsize * gsize < nb) gsize += 8;
+            const int64_t floor_g = (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS;
+            if (floor_g > gsize) gsize = (int)floor_g;
+        }
+        ngroups = (int)((nb + gsize - 1) / gsize);
+    }
+    // words behind the block-histogram table that have to be zero before the first pass: the group sums of every pass
+    __host__ __device__ size_t zero_words(int passes) const { return (size_t)passes * 256 * ngroups; }
+};
+
+// scratch needed by one radix_sort_pairs call over n pairs: the alternate key / value buffers of the ping-pong, the block
+// histograms and the group sums of up to four passes
 struct SortScratch {
-    size_t keys_alt, vals_alt, hist, partials, total;
+    size_t keys_alt, vals_alt, hist, total;
     __host__ __device__ explicit SortScratch(int64_t n) {
         size_t o = 0;
-        int64_t nb = sort_blocks(n > 0 ? n : 1);
-        keys_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
-        vals_alt = o; o = align256(o + 4 * (size_t)(n > 0 ? n : 1));
-        // classic path: 256 x nb block histograms; onesweep path: 4x256 digit histograms + tickets + error
-        // flag (64 words) + up to 4 passes x nb x 256 look-back status words
-        // (grouped path: 256 x nb block histograms followed by 4 x 256 x SORT_MAX_GROUPS group sums — smaller)
-        hist = o;     o = align256(o + 4 * ((size_t)4 * 256 + 64 + (size_t)4 * 256 * nb + (size_t)4 * 256 * SORT_MAX_GROUPS));
-        partials = o; o = align256(o + 8 * (size_t)(scan_blocks(256 * nb) + 2));
+        const size_t nn = (size_t)(n > 0 ? n : 1);
+        const SortGeom G(n);
+        keys_alt = o; o = align256(o + 4 * nn);
+        vals_alt = o; o = align256(o + 4 * nn);
+        hist = o;     o = align256(o + 4 * ((size_t)256 * G.nb + G.zero_words(4)));
         total = o;
     }
 };
 
 struct Stage1Scratch {
-    size_t sort, scan_partials, total_out, heavy_list, heavy_count, occ_cand, total;
+    size_t sort, scan_partials, total_out, heavy_list, heavy_count, heavy_blk, occ_cand, total;
     __host__ __device__ explicit Stage1Scratch(int64_t P) {
         size_t o = 0;
         const size_t Pn = (size_t)(P > 0 ? P : 1);
@@ -156,6 +205,8 @@ struct Stage1Scratch {
         // and their gathered records (one per candidate)
         heavy_list = o;    o = align256(o + 8 * 64 * waves);     // {Gaussian id, depth key} pairs
         heavy_count = o;   o = align256(o + 4 * waves);
+        heavy_blk = o;     o = align256(o + 2 * waves);          // ... and per workgroup of preprocess_kernel (four waves): {count, sum
+                                                                 //     of the candidates' largest possible cover weights}
         occ_cand = o;      o = align256(o + sizeof(OccCand) * OCC_MAX_CAND);
         total = o;
     }
@@ -163,13 +214,46 @@ struct Stage1Scratch {
 
 // (the tile ranges come FIRST: the position of every part is then independent of D, so that stage 2 can be launched on
 //  capacity-sized buffers before the host knows D, and the backward finds the parts whatever capacity the forward used)
+constexpr int DTRAV_SLOTS = 64;                  // accumulators of the traversed-entries count (feedback), one 8-byte word per slot
 struct BinningLayout {
-    size_t ids, ranges, total;
+    size_t ids, ranges, dtrav, total;
     __host__ __device__ BinningLayout(int64_t D, int64_t tiles) {
         size_t o = 0;
         ranges = o; o = align256(o + 8 * (size_t)tiles);
+        dtrav = o;  o = align256(o + 8 * (size_t)DTRAV_SLOTS);    // directly behind the ranges: the emit's zero job clears both at once
         ids = o;    o = align256(o + 4 * (size_t)(D > 0 ? D : 1));
         total = o;
+    }
+    // words from the start of `ranges` to the end of the D_trav accumulators
+    __host__ __device__ size_t ranges_and_dtrav_words() const { return (dtrav + 8 * (size_t)DTRAV_SLOTS - ranges) / 4; }
+};
+
+// Depth-slab binning: how the instance array `ids` (capacity cb) and the stage-2 scratch (capacity cs) are shared.
+//   slab A's sorted ids         ids[0, nA)        nA <= n_a_max = fraction * D + tiles (+ alignment)
+//   slab B's sorted ids         ids[n_a_max, n_a_max + DB)
+// DB counts every instance of the view that falls into an open tile: DB <= D up to the handful of tiles by which two
+// evaluations of a row extent may differ (msgs_internal.h, levelset_row_interval) — SLAB_SLACK instances are kept free for
+// them in both buffers (one such tile per 5.5e7 instances was observed), and a count beyond the capacity raises
+// SlabHeader::pad0 (reported with the feedback publication; asserted zero by the tests).
+constexpr int64_t SLAB_SLACK = 65536;
+constexpr int SLAB_MIN_TILES = 2048;             // below: the blend kernels are latency-bound, slabs only add launches
+struct SlabGeom {
+    int64_t cap_d, n_a_max, cap_b;               // largest D served; start of slab B's ids; capacity of slab B (instances)
+    bool ok;
+    // cap_d_limit: the largest D the caller wants served (the exact D when it is known, else a huge number)
+    __host__ SlabGeom(int64_t cb, int64_t cs, double fraction, int64_t tiles, int64_t cap_d_limit) {
+        const int64_t by_ids = (int64_t)((double)(cb - tiles - SLAB_SLACK - 256) / (1.0 + fraction));
+        const int64_t by_scratch = cs - SLAB_SLACK;
+        cap_d = by_ids < by_scratch ? by_ids : by_scratch;
+        if (cap_d > cap_d_limit) cap_d = cap_d_limit;
+        if (cap_d < 0) cap_d = 0;
+        n_a_max = (((int64_t)(fraction * (double)cap_d) + tiles + 64) + 63) & ~(int64_t)63;
+        cap_b = cap_d + SLAB_SLACK;
+        ok = cap_d > 0 && n_a_max + cap_b <= cb && cap_b <= cs && n_a_max + cap_b <= 0xFFFFFFFFll;
+    }
+    // instance capacity of `ids` that serves D instances
+    __host__ static int64_t ids_needed(int64_t D, double fraction, int64_t tiles) {
+        return (int64_t)((double)(D + 1) * (1.0 + fraction)) + tiles + SLAB_SLACK + 512;
     }
 };
 
@@ -192,7 +276,7 @@ struct Stage2Scratch {
 };
 
 struct ImageLayout {
-    size_t final_T, n_contrib, tile_last, tile_order, total;
+    size_t final_T, n_contrib, tile_last, tile_order, open_bits, open_list, total;
     __host__ __device__ ImageLayout(int64_t W, int64_t H) {
         size_t o = 0;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)((H + TILE - 1) / TILE);
@@ -203,6 +287,8 @@ struct ImageLayout {
         tile_order = o; o = align256(o + 4 * (tiles + 1));   // backward launch order: heaviest tiles first inside every XCD's
                                                        // run; word [tiles] = TILE_ORDER_MAGIC when valid (written by the
                                                        // forward's order kernel, cleared by every forward blend)
+        open_bits = o;  o = align256(o + 4 * ((tiles + 31) / 32 + 1));   // slab mode: bit t = tile t is open after slab A
+        open_list = o;  o = align256(o + 4 * tiles);   // ... and the open tiles as a list (SlabHeader::n_open entries, any order)
         total = o;
     }
 };
@@ -432,14 +518,14 @@ struct ZeroJob { uint32_t* p0; size_t n0; uint32_t* p1; size_t n1; };
 // instances (cover candidates of the occlusion cut-off) and their number
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
                              char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0},
-                             uint32_t* heavy_list = nullptr, uint32_t* heavy_count = nullptr);
+                             uint32_t* heavy_list = nullptr, uint32_t* heavy_count = nullptr, uint32_t* heavy_blk = nullptr);
 // occlusion.hip: gather the candidates, accumulate the covers per block of tiles front to back, recount the Gaussians behind a
 // cut-off (tiles[] / key[] of `geom` are updated in place, before the depth sort)
 hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint32_t* heavy_list, const uint32_t* heavy_count,
-                            OccCand* cand, hipStream_t s);
+                            const uint32_t* heavy_blk, OccCand* cand, hipStream_t s);
 int set_occlusion(int on);                // occlusion.hip: process-wide switch (MSGS_NO_OCCLUSION=1 initially off); returns previous
 int get_occlusion();
-int occlusion_block_log2(int gx, int gy);  // log2(tiles per side of a cover block) for a gx x gy grid (MSGS_OCC_BLOCK: minimum, default 4)
+int occlusion_block_log2(int gx, int gy);  // log2(tiles per side of a cover block) for a gx x gy grid (4 x 4 tiles unless the grid has more than 2048 such blocks)
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s, bool textbook = false);
@@ -469,10 +555,8 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
                               uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0,
                               const uint32_t* n_ptr = nullptr, uint32_t* clamped_total = nullptr, uint64_t clamp = 0,
                               const uint32_t* extra = nullptr,    // extra: two device words forwarded with the status
-                              uint32_t* zero_word = nullptr);     // zero_word: one device word cleared on behalf of a later launch
-bool use_classic_sort();
-hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
-                                 uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s);
+                              uint32_t* zero_word = nullptr,      // zero_word: one device word cleared on behalf of a later launch
+                              uint32_t* overflow_flag = nullptr); // set to 1 when the total exceeds `clamp`
 // device-side fill with zeros (sort.hip): an ordinary kernel launch — hipMemsetAsync costs ~10 us of queue latency per
 // call on this runtime (barrier packets around the fill), four of them per step were 3 % of the C3 step
 hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and bytes multiples of 4
@@ -480,16 +564,25 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and b
 // D_dev (optional, device word): the instance count when the host does not know it yet (speculative stage 2); D is then the
 // CAPACITY the grids and the geometry are sized for
 // keys16: the key arrays hold uint16 tile ids (grids of fewer than 65535 tiles)
+// slab: 0 = the whole view; 1 = slab A (ranks below SlabHeader::rA of `geom`; D_dev = &SlabHeader::DA); 2 = slab B (every rank,
+// into the tiles of open_bits only, slots from GeomLayout::offs_b; D_dev = &SlabHeader::DB)
 hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* keys, uint32_t* ids,
                        int64_t D, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0}, const uint32_t* D_dev = nullptr,
-                       bool keys16 = false, uint32_t* heavy_q = nullptr);
+                       bool keys16 = false, uint32_t* heavy_q = nullptr, int slab = 0, const uint32_t* open_bits = nullptr,
+                       int64_t density_D = 0);      // density_D: the WHOLE view's instance count (LDS stage choice of slab A)
+// slab mode, between stage 1 and slab A's emit: SlabHeader {rA, DA, ...} from the scanned offsets; clears the open-tile bitmap
+hipError_t launch_slab_split(int P, char* geom, int64_t D, const uint32_t* D_dev, float fraction, uint32_t* open_bits,
+                             int num_tiles, hipStream_t s);
+// slab mode, behind slab A's blend: GeomLayout::offs_b[r] = instances of rank r in open tiles (not yet scanned)
+hipError_t launch_slab_recount(const ViewParams& vp, int P, char* geom, const uint32_t* open_bits, int64_t D,
+                               const uint32_t* D_dev, hipStream_t s);
 // heavy_q (Stage2Scratch::heavy_q; word 0 must be zero when the launch starts): Gaussians with more than EMIT_HEAVY_MIN
 // instances in blocks that write straight to HBM are queued and emitted by a second launch, one workgroup per Gaussian
+// base: position in `ids` of the first id that belongs to keys[0] (slab B's ids start behind slab A's)
 hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num_tiles, hipStream_t s,
-                         bool pre_zeroed = false, const uint32_t* D_dev = nullptr, bool keys16 = false);
+                         bool pre_zeroed = false, const uint32_t* D_dev = nullptr, bool keys16 = false, uint32_t base = 0);
 int set_backward_generation(int gen);     // blend.hip: 0 = by tile count, 1 | 2 = forced; returns the previous value
 int set_blend_granularity(int mode);      // blend.hip: 0 = by tile count, 1 = coarse, 2 = fine (16 waves per tile)
-int set_forward_variant(int v);           // blend.hip: 0 = default, 1 quadrant lists, 2 tile, 3 | 4 strip lists; returns the previous
 // blend.hip, deterministic backward: scratch = [grad_rec | inst_grad | sort buffers]
 struct DetScratch {
     size_t grad_rec, inst_grad, keys, keys_s, entry, sort, total;
@@ -523,9 +616,23 @@ hipError_t voxel_pool_build(const float* positions, int64_t M, float voxel_size,
 hipError_t voxel_pool_average(const float* features, int F, const uint32_t* order, const uint32_t* seg_start,
                               int64_t Mv, float* out, hipStream_t s);
 // blend.hip
+// slab (nullable): pass 0 = plain (only tile_len is used), 1 = slab A (publishes the tiles left open), 2 = slab B (blends the
+// listed tiles only).  Passes 1 / 2 need forward_uses_quadrant_kernel(tiles).
+struct FwdSlabArgs {
+    int pass;
+    uint32_t* open_bits;      // ImageLayout::open_bits
+    uint32_t* open_list;      // ImageLayout::open_list
+    uint32_t* n_open;         // &SlabHeader::n_open
+    unsigned long long* dtrav;   // BinningLayout::dtrav (nullable: no feedback)
+};
 hipError_t launch_blend_forward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                 float* out_color, float* out_ps, float* out_depth, float* final_T,
-                                uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s);
+                                uint32_t* n_contrib, uint32_t* tile_last, void* clear_ptr, size_t clear_bytes, hipStream_t s,
+                                const FwdSlabArgs* slab = nullptr);
+bool forward_uses_quadrant_kernel(int tiles);
+// msgs_view_t.feedback_tag: {D_trav, tag, slab numbers, D} into words 4..7 of a pinned status block (host_mapped: its device address)
+hipError_t launch_forward_feedback(const unsigned long long* dtrav, const SlabHeader* hdr, int slab_mode, int64_t D,
+                                   const uint32_t* D_dev, uint32_t tag, uint64_t ticket, uint64_t* host_mapped, hipStream_t s);
 hipError_t launch_blend_backward(const ViewParams& vp, const char* geom, const uint32_t* ids, const uint2* ranges,
                                  const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor,
                                  grad_acc_t* grad_rec, hipStream_t s, const uint32_t* tile_order = nullptr);

@@ -1,4 +1,4 @@
-// occlusion.hip — exact per-tile occlusion cut-off in front of the depth sort and the emit (round 5).
+// occlusion.hip — exact per-tile occlusion cut-off in front of the depth sort and the emit (round 5; one launch since round 6).
 //
 // The reference emits, sorts and walks every (tile, Gaussian) instance of a view; a pixel stops walking its tile's list at the
 // first entry where T (1 - alpha) < 1e-4.  When a multi-scale MS-GS model is rendered WITHOUT its
@@ -6,28 +6,43 @@
 // the default flags) the coarse-level Gaussians — scaled x4 .. x64 — are all drawn at level 0: 427 M instances at 1080p for
 // 1 M Gaussians, of which a few million are ever walked, because a handful of opaque giants in front terminates every pixel.
 //
-// What this pass proves and uses.  Let a Gaussian's alpha >= 1/255 level set contain a whole block of tiles.  alpha is a
-// concave function of the pixel offset in the log domain, so its minimum over the block's pixel centres is at one of the four
-// corner pixels: alpha_min.  EVERY pixel of the block then blends the Gaussian with alpha >= alpha_min (it is not skipped: the
-// skip rule is alpha < 1/255), i.e. its transmittance behind that entry is at most (1 - alpha_min) times the one in front.
-// With the covers of a block taken front to back, the first depth at which  prod (1 - alpha_min) < 0.5e-4  (the rule's 1e-4
-// with a factor 2 of slack for float32 rounding on either side) is a depth behind which NO pixel of the block evaluates
-// anything: every one of them has met the termination test at or before that entry.  Instances behind it are dropped from the
-// tile counts (here, before the depth sort and the scan) and from the emit (binning.hip).  The lists every pixel actually walks
-// are unchanged, entry for entry: image, n_contrib, final_T and every gradient are bit-identical to the uncut path
-// (tests/test_occlusion_gpu.py).  Any SUBSET of the covers gives a valid (later) cut-off, so the pass may ignore what it
-// likes: it only looks at Gaussians with more than OCC_HEAVY_MIN tile instances, only at blocks they cover completely, and it
-// accumulates per depth BUCKET (1/16 octave of view depth) instead of per rank — the cut-off is the far end of the bucket in
-// which the product crosses.  Integer (fixed-point) sums: the result does not depend on the order the candidates arrive in.
+// What this pass proves and uses.  Let a Gaussian's alpha >= 1/255 level set contain a whole block of tiles that lies inside
+// its tile rect.  alpha is a concave function of the pixel offset in the log domain, so its minimum over the block's pixel
+// centres is at one of the four corner pixels: alpha_min.  EVERY pixel of the block then blends the Gaussian with
+// alpha >= alpha_min (it is not skipped: the skip rule is alpha < 1/255), i.e. its transmittance behind that entry is at most
+// (1 - alpha_min) times the one in front.  With the covers of a block taken front to back, the first depth at which
+// prod (1 - alpha_min) < 0.5e-4  (the rule's 1e-4 with a factor 2 of slack for float32 rounding on either side) is a depth
+// behind which NO pixel of the block evaluates anything: every one of them has met the termination test at or before that
+// entry.  Instances behind it are dropped from the tile counts (here, before the depth sort and the scan) and from the emit
+// (binning.hip).  The lists every pixel actually walks are unchanged, entry for entry: image, n_contrib, final_T and every
+// gradient are bit-identical to the uncut path (tests/test_occlusion_gpu.py).  Any SUBSET of the covers gives a valid (later)
+// cut-off, so the pass may ignore what it likes: it only looks at Gaussians with more than OCC_HEAVY_MIN tile instances, only
+// at blocks they cover completely, and it accumulates per depth BUCKET (1/16 octave of view depth) instead of per rank — the
+// cut-off is the far end of the bucket in which the product crosses.  Integer (fixed-point) sums: the result does not depend
+// on the order the candidates arrive in.
 //
-// Four launches between preprocess_kernel and the depth sort:
-//   occ_hist_kernel      depth histogram of the candidates preprocess_kernel left behind, per wave slot
-//   occ_gather_kernel    keeps the nearest OCC_MAX_CAND of them (whole depth buckets) and gathers their records
-//   occ_cover_kernel     one workgroup per block of tiles: bucketed sums of -log2(1 - alpha_min), prefix, cut-off key per tile
-//   occ_recount_kernel   Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in
-//                        place; a Gaussian left without instances leaves the depth sort: key 0xFFFFFFFF)
-// On a view where nothing closes (the BASELINE C3 headline: four candidates) they cost 16-21 us; the Python wrapper then skips the
-// pass for that kind of view and probes again every 32nd call (msgs_view_t.skip_occlusion, msgs_forward_info).
+// ONE launch between preprocess_kernel and the depth sort (four in round 5): occ_pass_kernel, a persistent grid of OCC_GRID
+// workgroups.  Every workgroup first adds up the candidate counts preprocess_kernel left per workgroup (a few KB) — no barrier,
+// no shared counter to clear:
+//   fewer than three candidates in the whole view (a cover weighs at most 6.65 of the 14.3 bits needed; an ordinary training
+//     view has none): every workgroup leaves — ~3 us;
+//   up to OCC_SMALL candidates (BASELINE C3: four): every workgroup collects ALL of them into its LDS, ranks them by depth
+//     bucket, and its waves take the tile blocks one each: lane <-> candidate, one 64-lane prefix sum, the bucket of the lane
+//     at which the product crosses;
+//   more: the phases of round 5 behind grid barriers — depth histogram of the candidates -- barrier -- keep the nearest
+//     OCC_MAX_CAND (whole depth buckets) and gather their records -- barrier -- per block of tiles: bucketed sums of
+//     -log2(1 - alpha_min), prefix, cut-off bucket.
+// Then ONE more grid barrier, behind which every workgroup knows whether anything closed: if not (the rule), it leaves; if so,
+// the Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in place; a Gaussian left
+// without instances leaves the depth sort: key 0xFFFFFFFF).  The pass runs on EVERY forward, and the wrapper's adaptive skip
+// policy of round 5 — with its cliff, a closing view inside the 31 skipped calls rendered uncut — is gone.
+// Grid barriers: one counter per barrier in the header preprocess_kernel clears; the table and the flags are written with
+// agent-scope (write-through) stores, the candidate records with plain stores behind an agent-scope release; every workgroup
+// takes one agent-scope acquire before it reads another workgroup's data (cdna_hip_programming.md G16).  The waits are bounded.
+// A workgroup whose wait expires raises OccHeader::watchdog and leaves, and whatever the others still do the state stays VALID:
+// a table entry is either open or a proven cut-off; the cover phase starts only after EVERY workgroup has finished the gather;
+// any subset of covers, of blocks and of recounted Gaussians is a valid (weaker) cut (count >= emitted, surplus slots go to the
+// sentinel tile).  Never observed; msgs_occlusion_stats reports it.
 #include "msgs_internal.h"
 
 #include <atomic>
@@ -45,17 +60,40 @@ constexpr uint32_t OCC_THRESHOLD = (uint32_t)(OCC_LOG2_T * OCC_FIX) + 1u;
 // (sums stay below 2^32: a cover adds at most -log2(0.01) * 2048 = 13 607, and a view has fewer than 2^31 / 13 607 candidates
 //  per bucket in any scene this library accepts — P < 2^31 — while the prefix saturates below)
 
-// Cover candidates.  preprocess_kernel left, per wave slot, {id, depth key} of its heavy Gaussians and their number.  Only the
-// NEAREST candidates matter (the product crosses within the first few dozen covers of a block), so at most OCC_MAX_CAND are kept,
-// chosen by depth:
-//   occ_hist_kernel    every workgroup (256 slots, one per thread) counts its candidates per depth bucket in LDS and adds the
-//                      non-empty buckets and its total to the view's histogram / counter (cleared by preprocess_kernel)
-//   occ_gather_kernel  every workgroup prefix-sums the histogram itself, finds the deepest bucket kappa up to which the candidates
-//                      still fit, keeps its candidates with bucket <= kappa (positions: one atomic per workgroup — the ORDER of the
-//                      records is irrelevant, the cover sums are integers; the SET is deterministic) and gathers their records.
-//                      When the nearest non-empty bucket alone holds more than fit (thousands of covers at one depth), every
-//                      stride-th candidate in index order is kept instead: positions by formula from all slot counts.
-constexpr int OCC_GATHER_SLOTS = 256;       // wave slots per workgroup (one per thread)
+constexpr int OCC_THREADS = 256;            // threads per workgroup of the pass
+constexpr int OCC_GRID = 256;               // persistent workgroups: one per CU (1024 waves of the chip's 8192)
+constexpr int OCC_GATHER_SLOTS = 256;       // wave slots per chunk of phases 1 / 2 (one per thread)
+constexpr int OCC_MAX_SPINS = 1 << 20;      // bound of a barrier wait (~1 s)
+
+#define OCC_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// Grid barrier k of the pass: every wave drains its stores, the workgroup meets, ONE lane publishes (agent-scope release, then
+// the arrival on the counter), polls the counter with relaxed agent-scope loads and takes ONE agent-scope acquire; the second
+// __syncthreads() extends it to the workgroup.  Returns false when the wait expired (or somebody else's had).
+// RELEASE = false: everything the workgroup published was written with agent-scope (write-through) atomic stores or atomics.
+template <bool RELEASE>
+__device__ __forceinline__ bool occ_grid_barrier(OccHeader* hdr, int k, uint32_t* s_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (RELEASE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&hdr->bar[k], 1u, OCC_RLX_AGENT);
+        uint32_t ok = 1u;
+        for (int spins = 0; __hip_atomic_load(&hdr->bar[k], OCC_RLX_AGENT) < gridDim.x; ++spins) {
+            if (spins > OCC_MAX_SPINS || __hip_atomic_load(&hdr->watchdog, OCC_RLX_AGENT) != 0u) {
+                __hip_atomic_store(&hdr->watchdog, 1u, OCC_RLX_AGENT);
+                ok = 0u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        // (the acquire is the caller's: behind the last barrier only the workgroups that go on to read the table need one)
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0u;
+}
 
 __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* s_w, uint32_t* block_total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -64,123 +102,140 @@ __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t* s_
         const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
         if (lane >= off) inc += o;
     }
+    __syncthreads();                                   // (s_w may still be read from the previous use)
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
     uint32_t base = 0;
     for (int k = 0; k < wv; ++k) base += s_w[k];
     *block_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void occ_hist_kernel(const uint32_t* __restrict__ heavy_list,
-                                                       const uint32_t* __restrict__ heavy_count, int n_slots,
-                                                       OccHeader* __restrict__ hdr, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_h[OCC_BUCKETS];
-    __shared__ uint32_t s_w[4];
-    const int slot = blockIdx.x * OCC_GATHER_SLOTS + threadIdx.x;
+// LDS of the pass: the phases use it one after the other
+struct OccGatherLds {
+    uint16_t kept[OCC_GATHER_SLOTS * 64];     // (local slot << 6) | index in the slot
+    uint32_t prefix[OCC_GATHER_SLOTS];
+    uint32_t red[4], scan[4], kappa, keep, base;
+};
+constexpr int OCC_SMALL = 64;               // up to this many candidates every workgroup handles the whole view's covers itself
+union OccLds {
+    uint32_t hist[OCC_BUCKETS];               // depth histogram of a chunk; bucket sums of a cover block
+    OccGatherLds g;                           // selection + gather
+    OccTable table;                           // recount
+};
+
+// ---- phase 1: one chunk of OCC_GATHER_SLOTS wave slots -------------------------------------------------------------------
+// preprocess_kernel left, per wave slot, {id, depth key} of its heavy Gaussians and their number.  Every chunk counts its
+// candidates per depth bucket in LDS and adds the non-empty buckets and its total to the view's histogram / counter (cleared
+// by preprocess_kernel).
+__device__ __forceinline__ void occ_hist_chunk(int chunk, const uint32_t* __restrict__ heavy_list,
+                                               const uint32_t* __restrict__ heavy_count, int n_slots,
+                                               uint32_t* hist, uint32_t* s_h, uint32_t* s_w) {
+    const int slot = chunk * OCC_GATHER_SLOTS + threadIdx.x;
     const uint32_t cnt = slot < n_slots ? heavy_count[slot] : 0u;
     uint32_t total;
     block_exclusive_256(cnt, s_w, &total);
-    if (total == 0) return;                                             // (block-uniform)
-    for (int k = threadIdx.x; k < OCC_BUCKETS; k += 256) s_h[k] = 0u;
+    if (total == 0) return;                                             // (workgroup-uniform)
+    __syncthreads();
+    for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) s_h[k] = 0u;
     __syncthreads();
     const uint2* e = reinterpret_cast<const uint2*>(heavy_list) + (size_t)slot * 64;
     for (uint32_t j = 0; j < cnt; ++j) atomicAdd(&s_h[occ_bucket(e[j].y)], 1u);
     __syncthreads();
-    for (int k = threadIdx.x; k < OCC_BUCKETS; k += 256)
+    for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS)
         if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
-    if (threadIdx.x == 0) atomicAdd(&hdr->n_heavy, total);
 }
 
-__global__ __launch_bounds__(256) void occ_gather_kernel(int P, const char* __restrict__ geom,
-                                                         const uint32_t* __restrict__ heavy_list,
-                                                         const uint32_t* __restrict__ heavy_count, int n_slots,
-                                                         OccHeader* __restrict__ hdr, const uint32_t* __restrict__ hist,
-                                                         OccCand* __restrict__ cand,
-                                                         uint32_t block_log2, uint32_t nbx, uint32_t nby) {
-    __shared__ uint16_t s_kept[OCC_GATHER_SLOTS * 64];     // (local slot << 6) | index in the slot
-    __shared__ uint32_t s_prefix[OCC_GATHER_SLOTS];
-    __shared__ uint32_t s_red[2][4], s_scan[4], s_kappa, s_keep, s_base;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int slot0 = blockIdx.x * OCC_GATHER_SLOTS;
-    const uint32_t total = hdr->n_heavy;                    // final: occ_hist_kernel has completed
-    // deepest bucket kappa with (candidates in buckets <= kappa) <= OCC_MAX_CAND; thread t owns 8 consecutive buckets
-    constexpr int PER = OCC_BUCKETS / 256;
+// ---- phase 2: selection of the candidates ---------------------------------------------------------------------------------
+// Only the NEAREST candidates matter (the product crosses within the first few dozen covers of a block), so at most
+// OCC_MAX_CAND are kept, chosen by depth: every workgroup prefix-sums the histogram itself and finds the deepest bucket kappa up
+// to which the candidates still fit (OccSelect); a chunk keeps its candidates with bucket <= kappa (positions: one atomic per
+// chunk — the ORDER of the records is irrelevant, the cover sums are integers; the SET is deterministic) and gathers their
+// records.  When the nearest non-empty bucket alone holds more than fit (thousands of covers at one depth), every stride-th
+// candidate in index order is kept instead: positions by formula from all slot counts.
+struct OccSelect { uint32_t total, limit, stride, keep_total; bool by_depth; };
+__device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* hist, OccGatherLds& L) {
+    // deepest bucket kappa with (candidates in buckets <= kappa) <= OCC_MAX_CAND; thread t owns PER consecutive buckets
+    constexpr int PER = OCC_BUCKETS / OCC_THREADS;
     uint32_t hv[PER], hsum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) { hv[k] = hist[threadIdx.x * PER + k]; hsum += hv[k]; }
-    if (threadIdx.x == 0) { s_kappa = 0xFFFFFFFFu; s_keep = 0u; }
+    if (threadIdx.x == 0) { L.kappa = 0xFFFFFFFFu; L.keep = 0u; }
     uint32_t dummy;
-    uint32_t run = block_exclusive_256(hsum, s_scan, &dummy);
-    {
-        uint32_t best = 0xFFFFFFFFu, keep = 0;
+    uint32_t run = block_exclusive_256(hsum, L.scan, &dummy);           // (its barriers order the two stores above)
+    uint32_t best = 0xFFFFFFFFu, keep = 0;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            run += hv[k];
-            if (hv[k] && run <= (uint32_t)OCC_MAX_CAND) { best = (uint32_t)(threadIdx.x * PER + k); keep = run; }
-        }
-        if (best != 0xFFFFFFFFu) { atomicMax(&s_keep, keep); }          // cumulative counts grow with the bucket index: the
-        __syncthreads();                                                //   largest admissible cumulative count marks kappa
-        if (best != 0xFFFFFFFFu && keep == s_keep) s_kappa = best;
-        __syncthreads();
+    for (int k = 0; k < PER; ++k) {
+        run += hv[k];
+        if (hv[k] && run <= (uint32_t)OCC_MAX_CAND) { best = (uint32_t)(threadIdx.x * PER + k); keep = run; }
     }
-    const uint32_t kappa = s_kappa, keep_total = s_keep;
-    const bool by_depth = total <= (uint32_t)OCC_MAX_CAND || kappa != 0xFFFFFFFFu;
-    const uint32_t limit = total <= (uint32_t)OCC_MAX_CAND ? (uint32_t)(OCC_BUCKETS - 1) : kappa;
-    uint32_t stride = 1u, before = 0u;
-    if (!by_depth) {
+    if (best != 0xFFFFFFFFu) atomicMax(&L.keep, keep);                  // cumulative counts grow with the bucket index: the
+    __syncthreads();                                                    //   largest admissible cumulative count marks kappa
+    if (best != 0xFFFFFFFFu && keep == L.keep) L.kappa = best;
+    __syncthreads();
+    OccSelect S;
+    S.total = total;
+    S.keep_total = L.keep;
+    S.by_depth = total <= (uint32_t)OCC_MAX_CAND || L.kappa != 0xFFFFFFFFu;
+    S.limit = total <= (uint32_t)OCC_MAX_CAND ? (uint32_t)(OCC_BUCKETS - 1) : L.kappa;
+    S.stride = S.by_depth ? 1u : (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND;
+    __syncthreads();
+    return S;
+}
+
+__device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, int P, const char* __restrict__ geom,
+                                                 const uint32_t* __restrict__ heavy_list,
+                                                 const uint32_t* __restrict__ heavy_count, int n_slots, OccHeader* hdr,
+                                                 OccCand* cand, OccGatherLds& L) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot0 = chunk * OCC_GATHER_SLOTS;
+    const int slot = slot0 + threadIdx.x;
+    const uint32_t cnt = slot < n_slots ? heavy_count[slot] : 0u;
+    uint32_t dummy, chunk_total;
+    const uint32_t before_in_chunk = block_exclusive_256(cnt, L.scan, &chunk_total);
+    if (chunk_total == 0) return;                                       // (workgroup-uniform)
+    uint32_t before = 0u;
+    if (!S.by_depth) {
         // the nearest bucket alone is too full: every stride-th candidate in index order; the candidates in front of this
-        // workgroup's slots from ALL slot counts (62 KB at 1 M Gaussians, four counts per load)
-        stride = (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND;
+        // chunk's slots from ALL slot counts (62 KB at 1 M Gaussians, four counts per load)
         const int n4 = n_slots >> 2;                        // n_slots is a multiple of 4
         const uint4* c4 = reinterpret_cast<const uint4*>(heavy_count);
-        for (int q = threadIdx.x; q < n4 && 4 * q < slot0; q += 256) {
+        for (int q = threadIdx.x; q < n4 && 4 * q < slot0; q += OCC_THREADS) {
             const uint4 v = c4[q];
             before += v.x + v.y + v.z + v.w;
         }
         for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off);
-        if (lane == 0) s_red[1][wv] = before;
         __syncthreads();
-        before = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        if (lane == 0) L.red[wv] = before;
+        __syncthreads();
+        before = L.red[0] + L.red[1] + L.red[2] + L.red[3];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {              // (the header was zeroed by preprocess_kernel)
-        hdr->n_cand = by_depth ? (total <= (uint32_t)OCC_MAX_CAND ? total : keep_total) : (total + stride - 1) / stride;
-        hdr->depth_limit = by_depth ? limit : 0xFFFFFFFFu;
-        hdr->enabled = 1u;
-        hdr->block_log2 = block_log2;
-        hdr->nbx = nbx;
-        hdr->nby = nby;
-    }
-    if (total == 0) return;
-    const int slot = slot0 + threadIdx.x;
-    const uint32_t cnt = slot < n_slots ? heavy_count[slot] : 0u;
     const uint2* ent = reinterpret_cast<const uint2*>(heavy_list);
     uint32_t kept = 0, first = 0, g0 = 0;
-    if (by_depth) {
-        for (uint32_t j = 0; j < cnt; ++j) kept += occ_bucket(ent[(size_t)slot * 64 + j].y) <= limit ? 1u : 0u;
+    if (S.by_depth) {
+        for (uint32_t j = 0; j < cnt; ++j) kept += occ_bucket(ent[(size_t)slot * 64 + j].y) <= S.limit ? 1u : 0u;
     } else {
         // position (index order) of this slot's first candidate; positions g with g % stride == 0 are kept
-        first = before + block_exclusive_256(cnt, s_scan, &dummy);
-        g0 = ((first + stride - 1) / stride) * stride;
-        kept = g0 < first + cnt ? (first + cnt - 1 - g0) / stride + 1 : 0u;
+        first = before + before_in_chunk;
+        g0 = ((first + S.stride - 1) / S.stride) * S.stride;
+        kept = g0 < first + cnt ? (first + cnt - 1 - g0) / S.stride + 1 : 0u;
     }
-    s_prefix[threadIdx.x] = first;
+    L.prefix[threadIdx.x] = first;
     uint32_t kept_total;
-    uint32_t at = block_exclusive_256(kept, s_scan, &kept_total);       // <= 256 * 64 entries
-    if (by_depth) {
+    uint32_t at = block_exclusive_256(kept, L.scan, &kept_total);       // <= 256 * 64 entries
+    if (S.by_depth) {
         for (uint32_t j = 0; j < cnt; ++j)
-            if (occ_bucket(ent[(size_t)slot * 64 + j].y) <= limit) s_kept[at++] = (uint16_t)((threadIdx.x << 6) | j);
-        if (threadIdx.x == 0) s_base = kept_total ? atomicAdd(&hdr->n_written, kept_total) : 0u;
+            if (occ_bucket(ent[(size_t)slot * 64 + j].y) <= S.limit) L.kept[at++] = (uint16_t)((threadIdx.x << 6) | j);
+        if (threadIdx.x == 0) L.base = kept_total ? atomicAdd(&hdr->n_written, kept_total) : 0u;
     } else {
-        for (uint32_t g = g0; g < first + cnt; g += stride) s_kept[at++] = (uint16_t)((threadIdx.x << 6) | (g - first));
+        for (uint32_t g = g0; g < first + cnt; g += S.stride) L.kept[at++] = (uint16_t)((threadIdx.x << 6) | (g - first));
     }
     __syncthreads();
-    const GeomLayout L(P);
-    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
-    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + L.rec);
-    for (uint32_t e = threadIdx.x; e < kept_total; e += 256) {
-        const uint32_t code = s_kept[e];
+    const GeomLayout GL(P);
+    const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + GL.binrec);
+    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + GL.rec);
+    for (uint32_t e = threadIdx.x; e < kept_total; e += OCC_THREADS) {
+        const uint32_t code = L.kept[e];
         const uint32_t ls = code >> 6, j = code & 63u;
         const uint2 ge = ent[(size_t)(slot0 + ls) * 64 + j];
         const BinRec b = binrec[ge.x];
@@ -190,8 +245,11 @@ __global__ __launch_bounds__(256) void occ_gather_kernel(int P, const char* __re
         c.rect_lo = __float_as_uint(b.q1.z);                                          // minx | miny << 16   (tiles)
         c.rect_hi = __float_as_uint(b.q1.w);                                          // maxx | maxy << 16   (exclusive)
         c.pad0 = c.pad1 = 0u;
-        cand[by_depth ? s_base + e : (s_prefix[ls] + j) / stride] = c;
+        const uint32_t pos = S.by_depth ? L.base + e : (L.prefix[ls] + j) / S.stride;
+        if (pos < (uint32_t)OCC_MAX_CAND) cand[pos] = c;
     }
+    __syncthreads();
+    (void)dummy;
 }
 
 // fixed-point weight -log2(1 - alpha_min) of candidate c over the pixel-centre rectangle [x0, x1] x [y0, y1] of the block of
@@ -227,93 +285,74 @@ __device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, flo
     return (uint32_t)(w * (OCC_FIX * 0.999f));          // rounded down
 }
 
-// one workgroup per block of B x B tiles
-constexpr int OCC_COVER_THREADS = 256;
-__global__ __launch_bounds__(OCC_COVER_THREADS) void occ_cover_kernel(ViewParams vp, int B, int nbx, OccHeader* __restrict__ hdr,
-                                                                      const OccCand* __restrict__ cand,
-                                                                      uint32_t* __restrict__ occ_cut) {
-    __shared__ uint32_t s_b[OCC_BUCKETS];
-    __shared__ uint32_t s_wave[OCC_COVER_THREADS / 64];
-    __shared__ uint32_t s_cross;
-    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+// ---- phase 3: one block of B x B tiles ---------------------------------------------------------------------------------------
+// returns (to every thread) the depth bucket in which the block's product crosses, 0xFFFFFFFF when it does not; a crossing in
+// the last bucket — which also holds the keys clamped into it — closes nothing (callers test < OCC_BUCKETS - 1)
+__device__ __forceinline__ uint32_t occ_cover_block(int blk, const ViewParams& vp, int B, int nbx, uint32_t n,
+                                                    const OccCand* cand, uint32_t* s_b, uint32_t* s_wave, uint32_t* s_cross) {
+    const int bx = blk % nbx, by = blk / nbx;
     const int tx0 = bx * B, ty0 = by * B;
     const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
-    const uint32_t n = hdr->n_cand;
-    uint32_t cut = 0xFFFFu;                             // depth bucket behind which the block is dead (0xFFFF: open)
-    bool closed = false;
-    if (n >= 3) {                                       // (a cover weighs at most 6.65 bits: fewer than three cannot close anything)
-        for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_COVER_THREADS) s_b[k] = 0u;
-        if (threadIdx.x == 0) s_cross = 0xFFFFFFFFu;
-        __syncthreads();
-        const float x0 = (float)(tx0 * TILE), y0 = (float)(ty0 * TILE);
-        const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);   // pixels inside the image
-        auto add = [&](const OccCand& cc) {
-            const uint32_t w = cover_weight(cc, x0, x1, y0, y1, tx0, tx1, ty0, ty1);
-            if (w) atomicAdd(&s_b[occ_bucket(__float_as_uint(cc.c1.z))], w);
-        };
-        uint32_t c = threadIdx.x;
-        for (; c + OCC_COVER_THREADS < n; c += 2 * OCC_COVER_THREADS) {      // two records in flight per thread
-            const OccCand ca = cand[c], cb = cand[c + OCC_COVER_THREADS];
-            add(ca);
-            add(cb);
-        }
-        if (c < n) add(cand[c]);
-        __syncthreads();
-        // front-to-back prefix over the buckets: thread t owns PER consecutive buckets
-        constexpr int PER = OCC_BUCKETS / OCC_COVER_THREADS;
-        uint32_t v[PER], sum = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) { v[k] = min(s_b[threadIdx.x * PER + k], 0x00FFFFFFu); sum += v[k]; }
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        uint32_t inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-            if (lane >= off) inc += o;
-        }
-        if (lane == 63) s_wave[wv] = inc;
-        __syncthreads();
-        uint32_t run = inc - sum;
-        for (int k = 0; k < wv; ++k) run += s_wave[k];
-        uint32_t cross = 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            run += v[k];
-            if (cross == 0xFFFFFFFFu && run >= OCC_THRESHOLD) cross = (uint32_t)(threadIdx.x * PER + k);
-        }
-        if (cross != 0xFFFFFFFFu) atomicMin(&s_cross, cross);
-        __syncthreads();
-        const uint32_t q = s_cross;
-        // everything up to and including the crossing bucket stays; the last bucket also holds the keys clamped into it, so a
-        // crossing there closes nothing
-        closed = q < (uint32_t)(OCC_BUCKETS - 1);
-        if (closed) cut = q;
+    __syncthreads();                                    // (LDS of the previous block consumed)
+    for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) s_b[k] = 0u;
+    if (threadIdx.x == 0) *s_cross = 0xFFFFFFFFu;
+    __syncthreads();
+    const float x0 = (float)(tx0 * TILE), y0 = (float)(ty0 * TILE);
+    const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);   // pixels inside the image
+    auto add = [&](const OccCand& cc) {
+        const uint32_t w = cover_weight(cc, x0, x1, y0, y1, tx0, tx1, ty0, ty1);
+        if (w) atomicAdd(&s_b[occ_bucket(__float_as_uint(cc.c1.z))], w);
+    };
+    uint32_t c = threadIdx.x;
+    for (; c + OCC_THREADS < n; c += 2 * OCC_THREADS) {                 // two records in flight per thread
+        const OccCand ca = cand[c], cb = cand[c + OCC_THREADS];
+        add(ca);
+        add(cb);
     }
-    if (threadIdx.x == 0) {
-        occ_cut[blockIdx.x] = cut;
-        if (closed) hdr->any_closed = 1u;               // plain store (every writer writes the same value): no atomics here — the
-    }                                                   // readers reduce the table themselves (occ_table_load)
+    if (c < n) add(cand[c]);
+    __syncthreads();
+    // front-to-back prefix over the buckets: thread t owns PER consecutive buckets
+    constexpr int PER = OCC_BUCKETS / OCC_THREADS;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = min(s_b[threadIdx.x * PER + k], 0x00FFFFFFu); sum += v[k]; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int k = 0; k < wv; ++k) run += s_wave[k];
+    uint32_t cross = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        run += v[k];
+        if (cross == 0xFFFFFFFFu && run >= OCC_THRESHOLD) cross = (uint32_t)(threadIdx.x * PER + k);
+    }
+    if (cross != 0xFFFFFFFFu) atomicMin(s_cross, cross);
+    __syncthreads();
+    return *s_cross;        // everything up to and including the crossing bucket stays
 }
 
+// ---- recount --------------------------------------------------------------------------------------------------------------
 // Gaussians behind the nearest cut-off count their instances again: the same per-row level-set extents and margin as the
 // count in preprocess_kernel, restricted to the tiles whose block's cut-off they are in front of.  Index order (before the
 // depth sort).  The block table sits in LDS.  Footprints with a rect of at most OCC_LIGHT_RECT tiles are recounted by their own
-// thread — rows of blocks and blocks that are closed at this depth are skipped whole; larger ones by their whole wave: lane <-> tile row for the row extents, then only the
-// rows whose row of blocks is still open at this depth, with the lanes on consecutive tiles.
-constexpr int OCC_RECOUNT_THREADS = 1024;     // (few, fat workgroups: on a view where nothing closed every one of them only reads
-                                              //  the header and leaves)
-__global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewParams vp, int P, char* __restrict__ geom) {
-    __shared__ OccTable T;
+// thread — rows of blocks and blocks that are closed at this depth are skipped whole; larger ones by their whole wave: lane <->
+// tile row for the row extents, then only the rows whose row of blocks is still open at this depth, with the lanes on
+// consecutive tiles.
+__device__ __forceinline__ void occ_recount_chunk(int chunk, const ViewParams& vp, int P, char* __restrict__ geom, int lb, int nbx,
+                                                  const OccTable& T) {
     const GeomLayout L(P);
-    OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + L.occ_hdr);
-    if (hdr->any_closed == 0u) return;                                  // nothing closed in this view
-    const int lb = (int)hdr->block_log2, nbx = (int)hdr->nbx;
-    occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), nbx, (int)hdr->nby);
     const uint32_t cut_min = T.cut_min, cut_max = T.cut_max;
     uint32_t* tiles = reinterpret_cast<uint32_t*>(geom + L.tiles);
     uint32_t* key = reinterpret_cast<uint32_t*>(geom + L.key);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + L.binrec);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = chunk * OCC_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0, k = 0;
     if (i < P) { cnt = tiles[i]; k = occ_bucket(key[i]); }             // k: this Gaussian's depth bucket
@@ -385,17 +424,173 @@ __global__ __launch_bounds__(OCC_RECOUNT_THREADS) void occ_recount_kernel(ViewPa
     }
 }
 
+// ---- the pass ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, int P, char* geom,
+                                                               const uint32_t* __restrict__ heavy_list,
+                                                               const uint32_t* __restrict__ heavy_count,
+                                                               const uint32_t* __restrict__ heavy_blk, int n_slots,
+                                                               OccCand* cand, int block_log2, int nbx, int nby) {
+    __shared__ OccLds lds;
+    __shared__ OccCand s_cand[OCC_SMALL];
+    __shared__ uint8_t s_rank[OCC_SMALL];
+    __shared__ uint32_t s_w[4], s_ws[4], s_ok, s_cross, s_n;
+    const GeomLayout GL(P);
+    OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + GL.occ_hdr);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(geom + GL.occ_hdr + sizeof(OccHeader));
+    uint32_t* occ_cut = reinterpret_cast<uint32_t*>(geom + GL.occ_cut);
+    const int n_blocks = nbx * nby;
+    const int n_chunks = (n_slots + OCC_GATHER_SLOTS - 1) / OCC_GATHER_SLOTS;
+    const int n_wg = n_slots >> 2;                          // workgroups of preprocess_kernel (four wave slots each)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // ---- how many candidates does the view have?  Every workgroup adds up preprocess_kernel's per-workgroup counts itself
+    // ... and the sum of the largest weights they could possibly have (a cover's weight over any block is at most the one at its
+    // own centre, -log2(1 - min(0.99, opacity))): below the threshold no block can close (BASELINE C3: four heavy Gaussians of
+    // ordinary opacity)
+    uint32_t total = 0, wsum = 0;
+    const uint2* blk2 = reinterpret_cast<const uint2*>(heavy_blk);
+    for (int q = threadIdx.x; q < n_wg; q += OCC_THREADS) {
+        const uint2 v = blk2[q];
+        total += v.x;
+        wsum = min(wsum + v.y, 0x3FFFFFFFu);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        total += (uint32_t)__shfl_xor((int)total, off);
+        wsum = min(wsum + (uint32_t)__shfl_xor((int)wsum, off), 0x3FFFFFFFu);
+    }
+    if (lane == 0) { s_w[wv] = total; s_ws[wv] = wsum; }
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    wsum = min(min(s_ws[0] + s_ws[1], 0x3FFFFFFFu) + min(s_ws[2] + s_ws[3], 0x3FFFFFFFu), 0x7FFFFFFFu);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // (the header was zeroed by preprocess_kernel)
+        hdr->enabled = 1u;
+        hdr->n_heavy = total;
+        hdr->block_log2 = (uint32_t)block_log2;
+        hdr->nbx = (uint32_t)nbx;
+        hdr->nby = (uint32_t)nby;
+        hdr->depth_limit = (uint32_t)(OCC_BUCKETS - 1);
+        if (total >= 3u && wsum >= OCC_THRESHOLD && total <= (uint32_t)OCC_SMALL) hdr->n_cand = total;
+    }
+    if (total < 3u || wsum < OCC_THRESHOLD) return;     // nothing can close: n_cand = 0 / any_closed = 0, nobody reads the table
+    const int B = 1 << block_log2;
+    if (total <= (uint32_t)OCC_SMALL) {
+        // ---- few candidates: every workgroup collects ALL of them (the set, not the order, matters: the sums are integers) ...
+        for (int q = threadIdx.x; q < n_wg; q += OCC_THREADS) {
+            if (blk2[q].x == 0u) continue;
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const int slot = 4 * q + w4;
+                const uint32_t c = heavy_count[slot];
+                if (c == 0u) continue;
+                const uint32_t at = atomicAdd(&s_n, c);
+                const uint2* e = reinterpret_cast<const uint2*>(heavy_list) + (size_t)slot * 64;
+                const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + GL.binrec);
+                const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + GL.rec);
+                for (uint32_t j = 0; j < c && at + j < (uint32_t)OCC_SMALL; ++j) {
+                    const uint2 ge = e[j];
+                    const BinRec b = binrec[ge.x];
+                    OccCand cc;
+                    cc.c0 = b.q0;
+                    cc.c1 = make_float4(b.q1.x, rec[ge.x].r1.y, __uint_as_float(ge.y), __uint_as_float(ge.x));
+                    cc.rect_lo = __float_as_uint(b.q1.z);
+                    cc.rect_hi = __float_as_uint(b.q1.w);
+                    cc.pad0 = cc.pad1 = 0u;
+                    s_cand[at + j] = cc;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n = min(s_n, (uint32_t)OCC_SMALL);
+        // ... ranks them front to back by (depth bucket, Gaussian id) — lane i of every wave then owns the i-th nearest ...
+        if (threadIdx.x < n) {
+            const uint32_t kb = occ_bucket(__float_as_uint(s_cand[threadIdx.x].c1.z)), id = __float_as_uint(s_cand[threadIdx.x].c1.w);
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t kj = occ_bucket(__float_as_uint(s_cand[j].c1.z)), ij = __float_as_uint(s_cand[j].c1.w);
+                r += (kj < kb || (kj == kb && ij < id)) ? 1u : 0u;
+            }
+            s_rank[r] = (uint8_t)threadIdx.x;
+        }
+        __syncthreads();
+        OccCand mine;
+        uint32_t my_bucket = 0;
+        if ((uint32_t)lane < n) { mine = s_cand[s_rank[lane]]; my_bucket = occ_bucket(__float_as_uint(mine.c1.z)); }
+        // ... and the waves take the tile blocks one each: weight per lane, inclusive prefix over the lanes, the bucket of the
+        // lane at which the sum reaches the threshold (= the bucket in which the bucketed sums of the large path cross)
+        for (int b = blockIdx.x * 4 + wv; b < n_blocks; b += gridDim.x * 4) {
+            const int bx = b % nbx, by = b / nbx;
+            const int tx0 = bx * B, ty0 = by * B;
+            const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
+            const float x0 = (float)(tx0 * TILE), y0 = (float)(ty0 * TILE);
+            const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);
+            uint32_t w = (uint32_t)lane < n ? cover_weight(mine, x0, x1, y0, y1, tx0, tx1, ty0, ty1) : 0u;
+            uint32_t inc = w;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += o;
+            }
+            const uint64_t reached = __ballot(inc >= OCC_THRESHOLD);
+            uint32_t q = 0xFFFFu;
+            if (reached) {
+                const uint32_t kq = (uint32_t)__shfl((int)my_bucket, __ffsll((long long)reached) - 1);
+                if (kq < (uint32_t)(OCC_BUCKETS - 1)) q = kq;       // (a crossing in the last bucket closes nothing)
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&occ_cut[b], q, OCC_RLX_AGENT);
+                if (q != 0xFFFFu) __hip_atomic_store(&hdr->any_closed, 1u, OCC_RLX_AGENT);
+            }
+        }
+    } else {
+        // ---- many candidates: histogram -- barrier -- selection + gather -- barrier -- covers
+        for (int q = blockIdx.x * OCC_THREADS + threadIdx.x; q < n_blocks; q += gridDim.x * OCC_THREADS)
+            __hip_atomic_store(&occ_cut[q], 0xFFFFu, OCC_RLX_AGENT);
+        for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) occ_hist_chunk(c, heavy_list, heavy_count, n_slots, hist, lds.hist, s_w);
+        if (!occ_grid_barrier<false>(hdr, 0, &s_ok)) return;              // (the histogram: atomics only)
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        {
+            const OccSelect S = occ_select(total, hist, lds.g);
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                __hip_atomic_store(&hdr->n_cand, S.by_depth ? (total <= (uint32_t)OCC_MAX_CAND ? total : S.keep_total)
+                                                             : (total + S.stride - 1) / S.stride, OCC_RLX_AGENT);
+                hdr->depth_limit = S.by_depth ? S.limit : 0xFFFFFFFFu;
+            }
+            for (int c = blockIdx.x; c < n_chunks; c += gridDim.x)
+                occ_gather_chunk(c, S, P, geom, heavy_list, heavy_count, n_slots, hdr, cand, lds.g);
+        }
+        if (!occ_grid_barrier<true>(hdr, 1, &s_ok)) return;               // (the candidate records: plain stores)
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        {
+            const uint32_t n = min(__hip_atomic_load(&hdr->n_cand, OCC_RLX_AGENT), (uint32_t)OCC_MAX_CAND);
+            for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+                const uint32_t q = occ_cover_block(b, vp, B, nbx, n, cand, lds.hist, s_w, &s_cross);
+                if (threadIdx.x == 0 && q < (uint32_t)(OCC_BUCKETS - 1)) {
+                    __hip_atomic_store(&occ_cut[b], q, OCC_RLX_AGENT);    // (the table started all-open: only proven cut-offs)
+                    __hip_atomic_store(&hdr->any_closed, 1u, OCC_RLX_AGENT);
+                }
+            }
+        }
+    }
+
+    // ---- did anything close?  One more barrier (the table and the flag were written write-through: no release); if not — the
+    // rule — every workgroup leaves
+    if (!occ_grid_barrier<false>(hdr, 2, &s_ok)) return;
+    if (__hip_atomic_load(&hdr->any_closed, OCC_RLX_AGENT) == 0u) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    occ_table_load(lds.table, occ_cut, nbx, nby);
+    const int n_gchunks = (P + OCC_THREADS - 1) / OCC_THREADS;
+    for (int c = blockIdx.x; c < n_gchunks; c += gridDim.x) occ_recount_chunk(c, vp, P, geom, block_log2, nbx, lds.table);
+}
+
 }  // namespace
 
 int set_occlusion(int on) { return g_occlusion.exchange(on ? 1 : 0); }
 int get_occlusion() { return g_occlusion.load(); }
 int occlusion_block_log2(int gx, int gy) {
-    static const int lb_min = [] {
-        const char* e = getenv("MSGS_OCC_BLOCK");
-        const int v = e ? atoi(e) : 4;
-        return v >= 16 ? 4 : v >= 8 ? 3 : v >= 4 ? 2 : v >= 2 ? 1 : 0;
-    }();
-    int lb = lb_min;
+    int lb = 2;                                        // 4 x 4 tiles, larger when the grid has more than OCC_MAX_BLOCKS of them
     while ((int64_t)((gx + (1 << lb) - 1) >> lb) * ((gy + (1 << lb) - 1) >> lb) > OCC_MAX_BLOCKS ||
            ((gy + (1 << lb) - 1) >> lb) > OCC_MAX_BLOCK_ROWS)
         ++lb;
@@ -403,22 +598,13 @@ int occlusion_block_log2(int gx, int gy) {
 }
 
 hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint32_t* heavy_list, const uint32_t* heavy_count,
-                            OccCand* cand, hipStream_t s) {
+                            const uint32_t* heavy_blk, OccCand* cand, hipStream_t s) {
     if (P == 0) return hipSuccess;
-    const GeomLayout L(P);
-    OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + L.occ_hdr);
     const int n_slots = 4 * ((P + 255) / 256);
     const int lb = occlusion_block_log2(vp.gx, vp.gy), B = 1 << lb;
     const int nbx = (vp.gx + B - 1) / B, nby = (vp.gy + B - 1) / B;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(geom + L.occ_hdr + sizeof(OccHeader));
-    const dim3 gslots((n_slots + OCC_GATHER_SLOTS - 1) / OCC_GATHER_SLOTS);
-    hipLaunchKernelGGL(occ_hist_kernel, gslots, dim3(256), 0, s, heavy_list, heavy_count, n_slots, hdr, hist);
-    hipLaunchKernelGGL(occ_gather_kernel, gslots, dim3(256), 0, s, P, (const char*)geom, heavy_list, heavy_count, n_slots, hdr,
-                       (const uint32_t*)hist, cand, (uint32_t)lb, (uint32_t)nbx, (uint32_t)nby);
-    hipLaunchKernelGGL(occ_cover_kernel, dim3(nbx * nby), dim3(OCC_COVER_THREADS), 0, s, vp, B, nbx, hdr, (const OccCand*)cand,
-                       reinterpret_cast<uint32_t*>(geom + L.occ_cut));
-    hipLaunchKernelGGL(occ_recount_kernel, dim3((P + OCC_RECOUNT_THREADS - 1) / OCC_RECOUNT_THREADS), dim3(OCC_RECOUNT_THREADS), 0, s, vp,
-                       P, geom);
+    hipLaunchKernelGGL(occ_pass_kernel, dim3(OCC_GRID), dim3(OCC_THREADS), 0, s, vp, P, geom, heavy_list, heavy_count, heavy_blk,
+                       n_slots, cand, lb, nbx, nby);
     return hipGetLastError();
 }
 

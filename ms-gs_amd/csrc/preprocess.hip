@@ -424,9 +424,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                                                          float* __restrict__ pixel_sizes,
                                                          char* __restrict__ geom, ZeroJob zj,
                                                          uint32_t* __restrict__ heavy_list,
-                                                         uint32_t* __restrict__ heavy_count) {
+                                                         uint32_t* __restrict__ heavy_count,
+                                                         uint32_t* __restrict__ heavy_blk) {
     __shared__ float s_rows[4][64 * HALF_LDS];
     __shared__ uint8_t s_idx[4][64];
+    __shared__ uint32_t s_heavy[4], s_hvw[4];
     const int P = g.P;
     {   // housekeeping for the depth sort that follows: clear its group-sum table (one word per thread)
         const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
@@ -621,7 +623,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
         const uint64_t m = __ballot(hv);
         const size_t slot = (size_t)blockIdx.x * 4 + wv;
         if (hv) reinterpret_cast<uint2*>(heavy_list)[slot * 64 + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)i, out_key);
-        if (lane == 0) heavy_count[slot] = (uint32_t)__popcll(m);
+        // ... and per workgroup {candidates, sum of their largest possible cover weights}: what the occlusion pass adds up to
+        // learn whether the view has candidates that could close anything at all.  A cover's weight over any block is at most
+        // the one at its own centre, -log2(1 - min(0.99, opacity)) in the pass's fixed point (OCC_FIX = 2048), rounded UP
+        uint32_t wmax = hv ? (uint32_t)(-__log2f(1.0f - fminf(0.99f, o_eff)) * 2048.0f) + 2u : 0u;
+        for (int off = 32; off > 0; off >>= 1) wmax += (uint32_t)__shfl_xor((int)wmax, off);
+        if (lane == 0) { heavy_count[slot] = (uint32_t)__popcll(m); s_heavy[wv] = (uint32_t)__popcll(m); s_hvw[wv] = wmax; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            reinterpret_cast<uint2*>(heavy_blk)[blockIdx.x] = make_uint2(s_heavy[0] + s_heavy[1] + s_heavy[2] + s_heavy[3],
+                                                                         min(s_hvw[0] + s_hvw[1] + s_hvw[2] + s_hvw[3], 0x0FFFFFFFu));
     }
 }
 
@@ -1072,14 +1083,14 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s, ZeroJob zj, uint32_t* heavy_list, uint32_t* heavy_count) {
+                             char* geom, hipStream_t s, ZeroJob zj, uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* heavy_blk) {
     if (g.P == 0) return hipSuccess;
     if (g.raw_params != 0 && g.shs == nullptr)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
-                           heavy_list, heavy_count);
+                           heavy_list, heavy_count, heavy_blk);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
-                           heavy_list, heavy_count);
+                           heavy_list, heavy_count, heavy_blk);
     return hipGetLastError();
 }
 

@@ -9,10 +9,13 @@
 // reference order (tile, depth bits, Gaussian index) at ~20 B x 2 passes per instance instead of
 // ~24 B x 6 passes.
 //
-// One pass = three kernels: per-block digit histogram -> exclusive scan of the digit-major
-// histogram table -> stable scatter.  Stability inside a block comes from wave-level match-any
+// One pass = two kernels (three from 16.8 M pairs up): per-block digit histograms + per-group digit sums (integer atomics),
+// [a one-block scan of the group sums,] and a stable scatter whose blocks derive their own output bases from the two tables and
+// reorder their chunk by digit in LDS before writing it out.  Stability inside a block comes from wave-level match-any
 // (8 ballots) ranking with each wave owning a contiguous key segment, waves ordered by id.
-// Every kernel is HBM-streaming: 4 B (hist) + 8 B read + 8 B write per pair per pass.
+// Every kernel is HBM-streaming: 4 B (hist) + 8 B read + 8 B write per pair per pass (6 + 6 with 16-bit tile keys).
+// No inter-workgroup waiting anywhere.  (The look-back single-pass variants, the scanned-table and unstaged scatters of rounds
+// 1-5 measured the same or slower and are gone from the product: profiles/r1_notes.md, git history.)
 #include "msgs_internal.h"
 
 #include <algorithm>
@@ -104,60 +107,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of the per-block totals (u64), grand total to partials[nb]
-// (status / host: optional stage-1 status block {total, 0} on the device and {total, 0, ticket} in pinned host words —
-//  the grand total is final HERE, one kernel before the offsets are, so the host learns D while scan_apply still runs)
-__global__ __launch_bounds__(256) void scan_partials_kernel(uint64_t* __restrict__ partials, int64_t nb,
-                                                            uint64_t* __restrict__ total_out,
-                                                            uint64_t* __restrict__ status = nullptr,
-                                                            volatile uint64_t* host = nullptr, uint64_t ticket = 0,
-                                                            uint32_t* __restrict__ clamped_total = nullptr,
-                                                            uint64_t clamp = 0,
-                                                            const uint32_t* __restrict__ extra = nullptr,
-                                                            uint32_t* __restrict__ zero_word = nullptr) {
-    __shared__ uint64_t s_w[4];
-    __shared__ uint64_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int64_t start = 0; start < nb; start += 256) {
-        const int64_t i = start + threadIdx.x;
-        const uint64_t v = i < nb ? partials[i] : 0;
-        uint64_t inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, off);
-            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), off);
-            if (lane >= off) inc += ((uint64_t)hi << 32) | lo;
-        }
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        uint64_t base = s_carry;
-        for (int k = 0; k < w; ++k) base += s_w[k];
-        if (i < nb) partials[i] = base + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = base + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        partials[nb] = s_carry;
-        if (total_out) *total_out = s_carry;
-        if (clamped_total) *clamped_total = (uint32_t)(s_carry < clamp ? s_carry : clamp);   // speculative stage 2's D
-        // `extra`: two device words that travel with the count (the occlusion pass's {candidates, any block closed})
-        const uint64_t info = extra ? ((uint64_t)extra[0] | ((uint64_t)extra[1] << 32)) : 0ull;
-        if (zero_word) *zero_word = 0u;
-        if (status) { status[0] = s_carry; status[1] = 0; status[2] = info; }
-        if (host) {
-            host[0] = s_carry;
-            host[1] = 0;
-            host[3] = info;
-            __threadfence_system();
-            host[2] = ticket;
-        }
-    }
-}
-
-// Two-kernel scan (default since round 5): scan_reduce_kernel leaves one total per block; every block of THIS kernel sums the
+// Two-kernel scan: scan_reduce_kernel leaves one total per block; every block of THIS kernel sums the
 // totals in front of it itself (nb <= a few thousand values, L2-resident: 1 - 5 loads per thread) instead of waiting for a
 // one-block kernel in between, and block 0 — which sums ALL of them — publishes the grand total first thing: device word,
 // clamped copy for a speculative stage 2, status words and the polled host words.  One launch less per forward (~5 us).
@@ -169,7 +119,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_fused_kernel(const ui
                                                                         volatile uint64_t* host, uint64_t ticket,
                                                                         uint32_t* __restrict__ clamped_total, uint64_t clamp,
                                                                         const uint32_t* __restrict__ extra,
-                                                                        uint32_t* __restrict__ zero_word) {
+                                                                        uint32_t* __restrict__ zero_word,
+                                                                        uint32_t* __restrict__ overflow_flag) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_sum[4];
     if (n_ptr) n = (int64_t)*n_ptr;
@@ -192,6 +143,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_fused_kernel(const ui
             if (total_out) *total_out = sum;
             if (zero_word) *zero_word = 0u;
             if (clamped_total) *clamped_total = (uint32_t)(sum < clamp ? sum : clamp);
+            if (overflow_flag && sum > clamp) *overflow_flag = 1u;
             const uint64_t info = extra ? ((uint64_t)extra[0] | ((uint64_t)extra[1] << 32)) : 0ull;
             if (status) { status[0] = sum; status[1] = 0; status[2] = info; }
             if (host) {
@@ -219,37 +171,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_fused_kernel(const ui
         run += x;
     }
     scan_store_items(out, tb, n, v);
-}
-
-// `in` may alias `out` (in-place: every thread reads its SCAN_ITEMS values before it writes them)
-__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather,
-                                                                  uint32_t* out, int64_t n,
-                                                                  const uint64_t* __restrict__ partials,
-                                                                  const uint32_t* __restrict__ n_ptr) {
-    __shared__ uint32_t s_wave[4];
-    if (n_ptr) n = (int64_t)*n_ptr;
-    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    if (gather) {
-        uint32_t g[SCAN_ITEMS];
-        scan_load_items(gather, base, n, g);
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < n ? in[g[k]] : 0u;
-    } else {
-        scan_load_items(in, base, n, v);
-    }
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) sum += v[k];
-    uint32_t total;
-    uint32_t run = block_exclusive_scan(sum, s_wave, &total) + (uint32_t)partials[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const uint32_t x = v[k];
-        v[k] = run;
-        run += x;
-    }
-    scan_store_items(out, base, n, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,12 +233,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
     }
     __syncthreads();
     const uint32_t c = s_hist[threadIdx.x];
-    if (gsum) {       // grouped path: both tables are [block or group][digit] so that thread = digit accesses coalesce
-        hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
-        if (c) atomicAdd(&gsum[(int64_t)(blockIdx.x / gsize) * 256 + threadIdx.x], c);
-    } else {
-        hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = c;
-    }
+    // both tables are [block or group][digit] so that thread = digit accesses coalesce
+    hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
+    if (c) atomicAdd(&gsum[(int64_t)(blockIdx.x / gsize) * 256 + threadIdx.x], c);
 }
 
 // Large inputs (SCANNED_MIN_BLOCKS): one small block turns the group sums into the scatter's bases in place —
@@ -330,7 +248,15 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT* __
 // in place): a scatter block then reads ONE histogram row and ONE group row instead of walking the rows of the earlier blocks of
 // its group (on average 15.5 KB of table per 32 KB of keys and values, and a chain of dependent loads).
 __global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ gsum, int ngroups,
-                                                         uint32_t* __restrict__ hist, int gsize, int64_t nblocks) {
+                                                         uint32_t* __restrict__ hist, int gsize, int64_t nblocks,
+                                                         const uint32_t* __restrict__ n_ptr, int chunk) {
+    if (n_ptr) {        // device-side element count (capacity-sized launch): only the blocks that hold keys wrote their tables
+        const int64_t n = (int64_t)*n_ptr;
+        nblocks = (n + chunk - 1) / chunk;
+        ngroups = (int)((nblocks + gsize - 1) / gsize);
+        if ((int)blockIdx.x > ngroups) return;              // (ngroups == 0: every workgroup leaves)
+        if (nblocks == 0) return;
+    }
     const int d = threadIdx.x;
     if ((int)blockIdx.x < ngroups) {
         const int64_t first = (int64_t)blockIdx.x * gsize;
@@ -360,7 +286,7 @@ __global__ __launch_bounds__(256) void group_scan_kernel(uint32_t* __restrict__ 
     }
 }
 
-template <bool STAGED, int ITEMS, bool DROP = false, typename KeyT = uint32_t>
+template <int ITEMS, bool DROP = false, typename KeyT = uint32_t>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      KeyT* __restrict__ keys_out,
@@ -409,11 +335,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
     uint32_t gbase;
     {   // digit d = threadIdx.x: global base of this block's run of digit d
         const uint32_t d = threadIdx.x;
-        if (gsum && gsum_is_base) {
+        if (gsum_is_base) {
             // group_scan_kernel turned the group sums into bases and the block histograms into in-group prefixes (large inputs)
             const int g = blockIdx.x / gsize;
             gbase = gsum[(int64_t)g * 256 + d] + hist_scanned[(int64_t)blockIdx.x * 256 + d];
-        } else if (gsum) {
+        } else {
             // base = (keys with a smaller digit) + (same digit in earlier groups) + (same digit in earlier blocks of
             // this group); hist_scanned holds the RAW block histograms here
             const int g = blockIdx.x / gsize;
@@ -431,34 +357,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
             uint32_t total;
             gbase = block_exclusive_scan(tot, s_wave, &total) + before;
             if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = total;     // survivors of a DROP pass
-        } else {
-            gbase = hist_scanned[(int64_t)d * nblocks + blockIdx.x];
         }
     }
-    if (!STAGED) {
-        uint32_t base = gbase;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t c = s_cnt[k][threadIdx.x];
-            s_cnt[k][threadIdx.x] = base;
-            base += c;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const int64_t i = elem_index<ITEMS>(chunk_base, w, r, lane);
-            if (i < n && (!DROP || key[r] != 0xFFFFFFFFu)) {
-                const uint32_t d = (key[r] >> shift) & mask;
-                const uint32_t pos = s_cnt[w][d] + rank[r];
-                keys_out[pos] = (KeyT)key[r];
-                vals_out[pos] = val[r];
-            }
-        }
-        return;
-    }
-    // STAGED: reorder the chunk by digit in LDS first, then write it out in local order — consecutive lanes write
+    // reorder the chunk by digit in LDS first, then write it out in local order — consecutive lanes write
     // consecutive addresses inside each digit run (a wave store touches a few runs instead of 64 scattered words)
-    __shared__ uint32_t s_key[STAGED ? SORT_THREADS * ITEMS : 1], s_val[STAGED ? SORT_THREADS * ITEMS : 1], s_delta[256];
+    __shared__ uint32_t s_key[SORT_THREADS * ITEMS], s_val[SORT_THREADS * ITEMS], s_delta[256];
     uint32_t nkept;                                                        // keys of this chunk that stay in the sort
     {
         const uint32_t d = threadIdx.x;
@@ -495,275 +398,27 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// single-pass ("onesweep") variants with decoupled look-back
-// ---------------------------------------------------------------------------------------------
-// Inter-workgroup protocol (cdna_hip_programming.md §6 G16, form R2 "the data IS the flag"): every
-// exchanged quantity is ONE naturally aligned word {2-bit state | value} written with a single relaxed
-// agent-scope atomic store and polled with relaxed agent-scope atomic loads, so no payload ordering or
-// fence is needed.  Workgroups take their logical index from an atomic ticket, so a workgroup only ever
-// waits for workgroups that started before it (no dependence on dispatch order or placement).  All
-// status words and tickets are zeroed by a memset node ahead of the launch.  Spins are bounded: on
-// expiry the kernel raises *err and gives up (results are then garbage and the host reports it).
-constexpr uint32_t LB_AGG = 1u, LB_INC = 2u;
-constexpr uint32_t LB_VALUE_MASK = 0x3FFFFFFFu;
-constexpr int LB_MAX_SPINS = 1 << 24;
-
-__device__ __forceinline__ void lb_store32(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t lb_load32(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void lb_store64(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long lb_load64(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// digit histograms of up to 4 digit places in one pass over the keys: out[pass][256]
-__global__ __launch_bounds__(256) void radix_hist_all_kernel(const uint32_t* __restrict__ keys, int64_t n,
-                                                             int begin_bit, int end_bit, int passes,
-                                                             uint32_t* __restrict__ out) {
-    __shared__ uint32_t s_hist[4][256];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) s_hist[p][threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t k = keys[i];
-        for (int p = 0; p < passes; ++p) {
-            const int shift = begin_bit + 8 * p;
-            const int bits = min(8, end_bit - shift);
-            atomicAdd(&s_hist[p][(k >> shift) & ((1u << bits) - 1u)], 1u);
-        }
-    }
-    __syncthreads();
-    for (int p = 0; p < passes; ++p) {
-        const uint32_t c = s_hist[p][threadIdx.x];
-        if (c) atomicAdd(&out[p * 256 + threadIdx.x], c);
-    }
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void onesweep_kernel(const uint32_t* __restrict__ keys_in,
-                                                                const uint32_t* __restrict__ vals_in,
-                                                                uint32_t* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out, int64_t n,
-                                                                int shift, uint32_t mask,
-                                                                const uint32_t* __restrict__ digit_hist,
-                                                                uint32_t* __restrict__ status,
-                                                                uint32_t* __restrict__ ticket,
-                                                                uint32_t* __restrict__ err) {
-    __shared__ uint32_t s_cnt[4][256];
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_block;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_block = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t b = s_block;
-    const int64_t chunk_base = (int64_t)b * SORT_CHUNK;
-
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = elem_index(chunk_base, w, r, lane);
-        const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
-        val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
-        const uint32_t d = (key[r] >> shift) & mask;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const uint64_t m = __ballot((d >> bb) & 1u);
-            peers &= ((d >> bb) & 1u) ? m : ~m;
-        }
-        const uint32_t prev = s_cnt[w][d];
-        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-        rank[r] = prev + before;
-        if (valid && before == 0) s_cnt[w][d] = prev + (uint32_t)__popcll(peers);
-    }
-    __syncthreads();
-    {   // thread t owns digit t
-        const uint32_t d = threadIdx.x;
-        const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
-        const uint32_t total = c0 + c1 + c2 + c3;
-        uint32_t* my = status + (size_t)b * 256 + d;
-        lb_store32(my, ((b == 0 ? LB_INC : LB_AGG) << 30) | total);
-        // position of digit d in the output = (keys with a smaller digit) + (same digit in earlier chunks)
-        uint32_t dummy;
-        const uint32_t digit_base = block_exclusive_scan(digit_hist[d], s_wave, &dummy);
-        uint32_t excl = 0;
-        if (b > 0) {
-            int64_t p = (int64_t)b - 1;
-            int spins = 0;
-            while (true) {
-                const uint32_t sv = lb_load32(status + (size_t)p * 256 + d);
-                const uint32_t st = sv >> 30;
-                if (st == 0) {
-                    if (++spins > LB_MAX_SPINS) { atomicExch(err, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += sv & LB_VALUE_MASK;
-                if (st == LB_INC || p == 0) break;
-                --p;
-            }
-            lb_store32(my, (LB_INC << 30) | ((excl + total) & LB_VALUE_MASK));
-        }
-        const uint32_t base = digit_base + excl;
-        s_cnt[0][d] = base;
-        s_cnt[1][d] = base + c0;
-        s_cnt[2][d] = base + c0 + c1;
-        s_cnt[3][d] = base + c0 + c1 + c2;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int64_t i = elem_index(chunk_base, w, r, lane);
-        if (i < n) {
-            const uint32_t d = (key[r] >> shift) & mask;
-            const uint32_t pos = s_cnt[w][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
-        }
-    }
-}
-
-// single-pass exclusive scan with look-back; status words are {2-bit state | 62-bit value}
-__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback_kernel(const uint32_t* __restrict__ in,
-                                                                     const uint32_t* __restrict__ gather,
-                                                                     uint32_t* __restrict__ out, int64_t n,
-                                                                     unsigned long long* __restrict__ status,
-                                                                     uint32_t* __restrict__ ticket,
-                                                                     uint64_t* __restrict__ total_out,
-                                                                     uint32_t* __restrict__ err) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_block;
-    __shared__ unsigned long long s_excl;
-    if (threadIdx.x == 0) s_block = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t b = s_block;
-    const int64_t nb = scan_blocks(n);
-    const int64_t base = (int64_t)b * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int64_t i = base + k;
-        v[k] = i < n ? (gather ? in[gather[i]] : in[i]) : 0u;
-        sum += v[k];
-    }
-    uint32_t total;
-    const uint32_t local = block_exclusive_scan(sum, s_wave, &total);
-    if (threadIdx.x == 0) {
-        constexpr unsigned long long VM = (1ull << 62) - 1ull;
-        lb_store64(status + b, ((unsigned long long)(b == 0 ? LB_INC : LB_AGG) << 62) | total);
-        unsigned long long excl = 0;
-        if (b > 0) {
-            int64_t p = (int64_t)b - 1;
-            int spins = 0;
-            while (true) {
-                const unsigned long long sv = lb_load64(status + p);
-                const uint32_t st = (uint32_t)(sv >> 62);
-                if (st == 0) {
-                    if (++spins > LB_MAX_SPINS) { atomicExch(err, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += sv & VM;
-                if (st == LB_INC || p == 0) break;
-                --p;
-            }
-            lb_store64(status + b, ((unsigned long long)LB_INC << 62) | ((excl + total) & VM));
-        }
-        s_excl = excl;
-        if ((int64_t)b == nb - 1 && total_out) *total_out = excl + total;
-    }
-    __syncthreads();
-    uint32_t run = local + (uint32_t)s_excl;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int64_t i = base + k;
-        if (i < n) out[i] = run;
-        run += v[k];
-    }
-}
-
 }  // namespace
-
-// Default: the three-kernel-per-pass path (no inter-workgroup waiting).  MSGS_SORT_ONESWEEP=1 selects the
-// single-kernel-per-pass look-back variants; on MI355X they measured the same per-pass time (every
-// workgroup of a 1-4 M key pass is resident at once, so the per-digit look-back walk costs ~0.1 us per
-// workgroup and cancels the saved launches: profiles/r1_notes.md), so the spin-free path is the default.
-bool use_classic_sort() {
-    static const bool v = [] { const char* e = getenv("MSGS_SORT_ONESWEEP"); return !(e && e[0] == '1'); }();
-    return v;
-}
-
-// stage-1 status block {u64 total, u32 sort watchdog, u32 scan watchdog, ...}: one D2H copy for the host
-__global__ void collect_status_kernel(const uint64_t* __restrict__ total, const uint32_t* __restrict__ sort_err,
-                                      const uint32_t* __restrict__ scan_err, uint64_t* __restrict__ out,
-                                      volatile uint64_t* host, uint64_t ticket) {
-    const uint64_t t = *total;
-    const uint64_t e = (uint64_t)(sort_err ? *sort_err : 0u) | ((uint64_t)(scan_err ? *scan_err : 0u) << 32);
-    out[0] = t;
-    out[1] = e;
-    out[2] = 0;                     // (no occlusion info on this route)
-    if (host) {                     // pinned, device-mapped host words {total, flags, ticket}: the host polls `ticket`
-        host[0] = t;
-        host[1] = e;
-        host[3] = 0;
-        __threadfence_system();
-        host[2] = ticket;
-    }
-}
-
-hipError_t launch_collect_status(const uint64_t* total, const uint32_t* sort_err, const uint32_t* scan_err,
-                                 uint64_t* out, uint64_t* host_mapped, uint64_t ticket, hipStream_t s) {
-    hipLaunchKernelGGL(collect_status_kernel, dim3(1), dim3(1), 0, s, total, sort_err, scan_err, out,
-                       (volatile uint64_t*)host_mapped, ticket);
-    return hipGetLastError();
-}
 
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
                               uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr, uint32_t* clamped_total,
-                              uint64_t clamp, const uint32_t* extra, uint32_t* zero_word) {
-    const int64_t nb = scan_blocks(n > 0 ? n : 1);
-    if (n <= 0) {
-        hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, (int64_t)0, total, status,
-                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word);
+                              uint64_t clamp, const uint32_t* extra, uint32_t* zero_word, uint32_t* overflow_flag) {
+    if (n <= 0) {       // nothing to scan: one block publishes a total of zero (no partials are read)
+        hipLaunchKernelGGL(scan_apply_fused_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, in, out, (int64_t)0,
+                           (const uint64_t*)partials, (int64_t)0, (const uint32_t*)nullptr, total, status,
+                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word, overflow_flag);
         return hipGetLastError();
     }
-    if (!use_classic_sort()) {
-        // partials[0..nb) = status words, partials[nb] = ticket (low half) + error flag (high half)
-        hipError_t e = hipMemsetAsync(partials, 0, sizeof(uint64_t) * (size_t)(nb + 2), s);
-        if (e != hipSuccess) return e;
-        uint32_t* tk = reinterpret_cast<uint32_t*>(partials + nb);
-        hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, out, n,
-                           reinterpret_cast<unsigned long long*>(partials), tk, total, tk + 1);
-        return hipGetLastError();
-    }
-    // with a gather the first pass leaves the gathered values in `out` and the last pass scans `out` in place
-    const bool stage = gather != nullptr && out != in;
+    if (gather != nullptr && out == in) return hipErrorInvalidValue;     // a gathered scan is staged through `out`
+    const int64_t nb = scan_blocks(n);
+    // with a gather the first pass leaves the gathered values in `out` and the second pass scans `out` in place
+    const bool stage = gather != nullptr;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
                        stage ? out : (uint32_t*)nullptr, n_ptr);
-    // MSGS_SCAN_THREE_KERNELS=1: the round-1..4 route (reduce, one-block scan of the totals, apply) for A/B runs
-    static const bool three = [] { const char* e = getenv("MSGS_SCAN_THREE_KERNELS"); return e && e[0] == '1'; }();
-    if (!three && (stage || gather == nullptr)) {
-        hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s,
-                           stage ? (const uint32_t*)out : in, out, n, (const uint64_t*)partials, nb, n_ptr, total, status,
-                           (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, partials, nb, total, status,
-                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, stage ? (const uint32_t*)out : in,
-                       stage ? (const uint32_t*)nullptr : gather, out, n, partials, n_ptr);
+    hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s,
+                       stage ? (const uint32_t*)out : in, out, n, (const uint64_t*)partials, nb, n_ptr, total, status,
+                       (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word, overflow_flag);
     return hipGetLastError();
 }
 
@@ -788,78 +443,29 @@ hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
-// The words radix_sort_pairs(n, bits) needs zeroed beforehand in its default (grouped) configuration — an upper bound on
-// the group-sum table, so that a kernel running earlier on the stream can clear them and the sort can be called with
-// pre_zeroed = true (one launch less).  Returns false when the sort will not take the grouped path.
-// geometry of the grouped radix pass (shared by the sort and by the callers that clear its tables ahead of time)
-constexpr int64_t SCANNED_MIN_BLOCKS = 4096;     // from here on the histogram kernel's last block scans the group sums
-constexpr int SCANNED_GSIZE = 32;
-// MSGS_SORT_TILE_PASSES=n forces n passes for sorts of fewer than 32 bits (the tile sort): A/B of digit width against passes
 static int passes_for(int begin_bit, int end_bit) {
-    static const int forced = [] { const char* e = getenv("MSGS_SORT_TILE_PASSES"); return e ? atoi(e) : 0; }();
-    int passes = (end_bit - begin_bit + 7) / 8;
-    if (forced >= passes && forced <= 4 && end_bit - begin_bit < 32) passes = forced;
-    return passes;
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    return passes < 1 ? 1 : passes;
 }
+typedef SortGeom GroupGeom;
 
-struct GroupGeom {
-    bool big, mid, scanned;
-    int items, gsize, ngroups;
-    int64_t nb;
-    GroupGeom(int64_t n, bool grouped, bool staged) {
-        big = grouped && staged && n >= SORT_BIG_N;
-        mid = !big && grouped && staged && n >= SORT_MID_N;
-        items = big ? 16 : (mid ? 8 : SORT_ITEMS);
-        nb = (n + (int64_t)SORT_THREADS * items - 1) / ((int64_t)SORT_THREADS * items);
-        // MSGS_SORT_GROUP_SCAN=0: never; =<n>: from n blocks on (tests exercise the variant at small sizes with it)
-        static const int64_t min_blocks = [] {
-            const char* e = getenv("MSGS_SORT_GROUP_SCAN");
-            if (!e) return SCANNED_MIN_BLOCKS;
-            const long v = atol(e);
-            return v <= 0 ? (int64_t)1 << 62 : (int64_t)v;
-        }();
-        scanned = grouped && big && nb >= min_blocks;
-        if (scanned) {
-            gsize = SCANNED_GSIZE;       // short in-group walks; the number of groups is no longer what a block reads
-        } else {
-            // a scatter block reads `ngroups` group sums + on average gsize/2 block histograms per digit: balance them
-            gsize = 8;
-            while ((int64_t)gsize * gsize < nb) gsize += 8;
-            gsize = (int)std::max<int64_t>(gsize, (nb + SORT_MAX_GROUPS - 1) / SORT_MAX_GROUPS);
-        }
-        ngroups = (int)((nb + gsize - 1) / gsize);
-    }
-    // words behind the block-histogram table that have to be zero before the first pass: the group sums of every pass
-    size_t zero_words(int passes) const { return (size_t)passes * 256 * ngroups; }
-};
-
-// does radix_sort_pairs(n, bits) honour a device-side element count?  (the grouped, staged configurations do)
+// does radix_sort_pairs(n, bits) honour a device-side element count?  (every sort of up to 32 key bits does)
 bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit) {
-    if (n <= 0) return false;
-    int passes = passes_for(begin_bit, end_bit);
-    if (passes < 1) passes = 1;
-    static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
-    static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
-    const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
-    return use_classic_sort() && !onesweep && !scan_table && passes <= 4 && staged;
+    return n > 0 && passes_for(begin_bit, end_bit) <= 4;
 }
 
-// may radix_sort_pairs(..., keys16 = true) be used for this sort?  (16-bit key arrays: grouped, staged configurations only;
-// MSGS_SORT_KEYS32=1 keeps 32-bit keys for A/B runs)
+// may radix_sort_pairs(..., keys16 = true) be used for this sort?  (16-bit key arrays: 6 instead of 8 bytes per pair and pass)
 bool radix_sort_keys16_ok(int64_t n, int begin_bit, int end_bit) {
-    static const bool off = [] { const char* e = getenv("MSGS_SORT_KEYS32"); return e && e[0] == '1'; }();
-    return !off && end_bit <= 16 && radix_sort_supports_device_count(n, begin_bit, end_bit);
+    return end_bit <= 16 && radix_sort_supports_device_count(n, begin_bit, end_bit);
 }
 
+// The words radix_sort_pairs(n, bits) needs zeroed beforehand — the group-sum tables of its passes — so that a kernel running
+// earlier on the stream can clear them and the sort can be called with pre_zeroed = true (one launch less).
 bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch, uint32_t** ptr, size_t* words) {
     if (n <= 0) return false;
-    int passes = passes_for(begin_bit, end_bit);
-    if (passes < 1) passes = 1;
-    static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
-    static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
-    const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
-    if (onesweep || scan_table || passes > 4) return false;
-    const GroupGeom G(n, true, staged);
+    const int passes = passes_for(begin_bit, end_bit);
+    if (passes > 4) return false;
+    const GroupGeom G(n);
     const SortScratch L(n);
     *ptr = reinterpret_cast<uint32_t*>(scratch + L.hist) + (size_t)256 * G.nb;
     *words = G.zero_words(passes);
@@ -869,32 +475,39 @@ bool radix_sort_zero_region(int64_t n, int begin_bit, int end_bit, char* scratch
 namespace {
 __global__ void store_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 
-// one grouped pass (histogram + scatter) with ITEMS keys per thread; drop / n_ptr / n_out: compaction (radix_hist_kernel)
-template <int ITEMS, typename KeyT = uint32_t>
-void launch_grouped_pass(const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v, int64_t n, int shift,
-                         uint32_t mask, int64_t nb, uint32_t* hist, uint32_t* gs, int gsize, int ngroups, bool drop,
-                         const uint32_t* n_ptr, uint32_t* n_out, hipStream_t s) {
-    const dim3 grid((unsigned)nb), block(SORT_THREADS);
+// one radix pass with ITEMS keys per thread: block histograms + group sums, [the one-block scan of the group sums for inputs of
+// >= 4096 blocks,] then a stable scatter through LDS that derives its own bases.
+// drop / n_ptr / n_out: compaction (radix_hist_kernel)
+template <int ITEMS, typename KeyT>
+void launch_pass(const KeyT* src_k, const uint32_t* src_v, KeyT* dst_k, uint32_t* dst_v, int64_t n, int shift, uint32_t mask,
+                 const GroupGeom& G, uint32_t* hist, uint32_t* gs, bool drop, const uint32_t* n_ptr, uint32_t* n_out,
+                 hipStream_t s) {
+    const dim3 grid((unsigned)G.nb), block(SORT_THREADS);
     if (drop) {
-        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, true, KeyT>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
-                           ngroups, (const uint32_t*)nullptr);
-        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, true, KeyT>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                           mask, nb, hist, gs, gsize, ngroups, false, (const uint32_t*)nullptr, n_out);
-    } else {
-        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, false, KeyT>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
-                           ngroups, n_ptr);
-        hipLaunchKernelGGL((radix_scatter_kernel<true, ITEMS, false, KeyT>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
-                           shift, mask, nb, hist, gs, gsize, ngroups, false, n_ptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL((radix_hist_kernel<ITEMS, true, KeyT>), grid, block, 0, s, src_k, n, shift, mask, G.nb, hist, gs, G.gsize,
+                           G.ngroups, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, true, KeyT>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
+                           mask, G.nb, hist, gs, G.gsize, G.ngroups, false, (const uint32_t*)nullptr, n_out);
+        return;
     }
+    hipLaunchKernelGGL((radix_hist_kernel<ITEMS, false, KeyT>), grid, block, 0, s, src_k, n, shift, mask, G.nb, hist, gs, G.gsize,
+                       G.ngroups, n_ptr);
+    if (G.scanned)
+        hipLaunchKernelGGL(group_scan_kernel, dim3((unsigned)G.ngroups + 1), dim3(256), 0, s, gs, G.ngroups, hist, G.gsize, G.nb, n_ptr,
+                           SORT_THREADS * ITEMS);
+    hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, false, KeyT>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask,
+                       G.nb, hist, gs, G.gsize, G.ngroups, G.scanned, n_ptr, (uint32_t*)nullptr);
 }
 
-// The tile sort with 16-bit keys (grouped, staged configurations; no compaction): the same passes as radix_sort_pairs over
-// uint16 key arrays.  keys_in / keys_out / the alternate key buffer are addressed as uint16 (the caller's 4-byte-per-key
-// buffers are simply half used).
-hipError_t radix_sort_pairs_u16(uint16_t* keys_in, uint32_t* vals_in, uint16_t* keys_out, uint32_t* vals_out, int64_t n,
-                                int passes, int begin_bit, int end_bit, const GroupGeom& G, uint16_t* keys_alt, uint32_t* vals_alt,
-                                uint32_t* hist, uint32_t* gsum_all, const uint32_t* n_dev, hipStream_t s) {
-    const uint16_t* src_k = keys_in;
+// all passes of one sort over KeyT key arrays (uint16_t: the tile sort whenever the tile ids and the sentinel fit 16 bits — the
+// caller's 4-byte-per-key buffers are then simply half used).  Ping-pong so that the LAST pass writes keys_out / vals_out.
+// Digit widths are balanced over the passes (13 tile bits -> 7 + 6, not 8 + 5): a block's keys of one digit leave as one run,
+// and the run length — hence the write coalescing of the scatter — is set by the pass with the MOST digits.
+template <typename KeyT>
+hipError_t sort_passes(KeyT* keys_in, uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, int64_t n, int passes,
+                       int begin_bit, int end_bit, const GroupGeom& G, KeyT* keys_alt, uint32_t* vals_alt, uint32_t* hist,
+                       uint32_t* gsum_all, bool compact, uint32_t* n_valid_dev, const uint32_t* n_dev, hipStream_t s) {
+    const KeyT* src_k = keys_in;
     const uint32_t* src_v = vals_in;
     int next_shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
@@ -904,26 +517,15 @@ hipError_t radix_sort_pairs_u16(uint16_t* keys_in, uint32_t* vals_in, uint16_t* 
         next_shift = shift + bits;
         const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << (bits > 0 ? bits : 1)) - 1u);
         const bool to_out = ((passes - 1 - p) % 2) == 0;
-        uint16_t* dst_k = to_out ? keys_out : keys_alt;
+        KeyT* dst_k = to_out ? keys_out : keys_alt;
         uint32_t* dst_v = to_out ? vals_out : vals_alt;
         uint32_t* gs = gsum_all + (size_t)p * 256 * G.ngroups;
-        const dim3 grid((unsigned)G.nb), block(SORT_THREADS);
-        if (G.big && G.scanned) {
-            hipLaunchKernelGGL((radix_hist_kernel<16, false, uint16_t>), grid, block, 0, s, src_k, n, shift, mask, G.nb, hist, gs,
-                               G.gsize, G.ngroups, n_dev);
-            hipLaunchKernelGGL(group_scan_kernel, dim3((unsigned)G.ngroups + 1), dim3(256), 0, s, gs, G.ngroups, hist, G.gsize, G.nb);
-            hipLaunchKernelGGL((radix_scatter_kernel<true, 16, false, uint16_t>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
-                               shift, mask, G.nb, hist, gs, G.gsize, G.ngroups, true, n_dev, (uint32_t*)nullptr);
-        } else if (G.big) {
-            launch_grouped_pass<16, uint16_t>(src_k, src_v, dst_k, dst_v, n, shift, mask, G.nb, hist, gs, G.gsize, G.ngroups, false,
-                                              n_dev, nullptr, s);
-        } else if (G.mid) {
-            launch_grouped_pass<8, uint16_t>(src_k, src_v, dst_k, dst_v, n, shift, mask, G.nb, hist, gs, G.gsize, G.ngroups, false,
-                                             n_dev, nullptr, s);
-        } else {
-            launch_grouped_pass<SORT_ITEMS, uint16_t>(src_k, src_v, dst_k, dst_v, n, shift, mask, G.nb, hist, gs, G.gsize, G.ngroups,
-                                                      false, n_dev, nullptr, s);
-        }
+        const bool drop = compact && p == 0;
+        const uint32_t* np = n_dev ? n_dev : (compact && p > 0 ? n_valid_dev : nullptr);
+        uint32_t* no = drop ? n_valid_dev : nullptr;
+        if (G.big) launch_pass<16, KeyT>(src_k, src_v, dst_k, dst_v, n, shift, mask, G, hist, gs, drop, np, no, s);
+        else if (G.mid) launch_pass<8, KeyT>(src_k, src_v, dst_k, dst_v, n, shift, mask, G, hist, gs, drop, np, no, s);
+        else launch_pass<SORT_ITEMS, KeyT>(src_k, src_v, dst_k, dst_v, n, shift, mask, G, hist, gs, drop, np, no, s);
         src_k = dst_k;
         src_v = dst_v;
     }
@@ -933,11 +535,10 @@ hipError_t radix_sort_pairs_u16(uint16_t* keys_in, uint32_t* vals_in, uint16_t* 
 
 // n_valid_dev (optional, device word): COMPACTING sort — pairs whose key is 0xFFFFFFFF are dropped by the first pass, the
 // number of survivors V is written to *n_valid_dev, the remaining passes run over V pairs, and keys_out / vals_out hold the V
-// sorted survivors (the tail beyond V is unspecified).  Configurations without the compacting kernels sort all n pairs
-// (the dropped keys sort last) and report V = n: every consumer of *n_valid_dev stays correct either way.
+// sorted survivors (the tail beyond V is unspecified).  Inputs of >= 4096 blocks (16.8 M pairs) sort all n pairs (the dropped
+// keys sort last) and report V = n: every consumer of *n_valid_dev stays correct either way.
 // n_dev (optional, device word): the element count when the host only knows an upper bound n (speculative stage 2): every pass
-// takes its count from it, grids and group geometry are those of n.  Grouped configurations only (the caller checks with
-// radix_sort_supports_device_count).
+// takes its count from it, grids and group geometry are those of n.
 hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                             int64_t n, int begin_bit, int end_bit, char* scratch, hipStream_t s, bool pre_zeroed,
                             uint32_t* n_valid_dev, const uint32_t* n_dev, bool keys16) {
@@ -945,109 +546,30 @@ hipError_t radix_sort_pairs(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys
         if (n_valid_dev) hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, n_valid_dev, 0u);
         return hipSuccess;
     }
+    const int passes = passes_for(begin_bit, end_bit);
+    if (passes > 4) return hipErrorInvalidValue;            // keys of up to 32 bits
     const SortScratch L(n);
     uint32_t* keys_alt = reinterpret_cast<uint32_t*>(scratch + L.keys_alt);
     uint32_t* vals_alt = reinterpret_cast<uint32_t*>(scratch + L.vals_alt);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + L.hist);
-    uint64_t* partials = reinterpret_cast<uint64_t*>(scratch + L.partials);
-    int passes = passes_for(begin_bit, end_bit);
-    if (passes < 1) passes = 1;
-    const bool onesweep = !use_classic_sort() && n < (int64_t)LB_VALUE_MASK && passes <= 4;
-    // grouped variant of the spin-free path (default): group sums live behind the block-histogram table
-    static const bool scan_table = [] { const char* e = getenv("MSGS_SORT_SCAN_TABLE"); return e && e[0] == '1'; }();
-    const bool grouped = !onesweep && !scan_table && passes <= 4;
-    static const bool staged = !(getenv("MSGS_SORT_DIRECT_SCATTER") && getenv("MSGS_SORT_DIRECT_SCATTER")[0] == '1');
     // 16 keys per thread for big inputs (longer digit runs per block -> better write coalescing; measured on the
     // tile sort: 94 -> 81 us at 4.1M pairs, 1.6 -> 1.2 ms at 55M); 8 below that, where 16 would leave CUs idle
-    const GroupGeom G(n, grouped, staged);
-    const bool big = G.big, mid = G.mid;
-    const int64_t nb = G.nb;
-    const int gsize = G.gsize, ngroups = G.ngroups;
-    uint32_t* gsum_all = hist + (size_t)256 * nb;
-    if (grouped && !pre_zeroed) {
+    const GroupGeom G(n);
+    uint32_t* gsum_all = hist + (size_t)256 * G.nb;         // group sums live behind the block-histogram table
+    if (!pre_zeroed) {
         hipError_t e = launch_zero(gsum_all, sizeof(uint32_t) * G.zero_words(passes), s);
         if (e != hipSuccess) return e;
     }
-    // onesweep carve-up of the `hist` region: [4][256] digit histograms, [4] tickets, [1] error flag,
-    // then per pass nb x 256 status words
-    uint32_t* digit_hist = hist;
-    uint32_t* tickets = hist + 4 * 256;
-    uint32_t* err = tickets + 4;
-    uint32_t* status = hist + 4 * 256 + 64;
-    if (onesweep) {
-        hipError_t e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * (4 * 256 + 64 + (size_t)passes * 256 * nb), s);
-        if (e != hipSuccess) return e;
-        const int hb = (int)(nb < 1024 ? nb : 1024);
-        hipLaunchKernelGGL(radix_hist_all_kernel, dim3(hb), dim3(256), 0, s, keys_in, n, begin_bit, end_bit, passes,
-                           digit_hist);
+    if (keys16) {          // (the caller asked radix_sort_keys16_ok first; no compaction)
+        if (n_valid_dev || end_bit > 16) return hipErrorInvalidValue;
+        return sort_passes<uint16_t>(reinterpret_cast<uint16_t*>(keys_in), vals_in, reinterpret_cast<uint16_t*>(keys_out), vals_out,
+                                     n, passes, begin_bit, end_bit, G, reinterpret_cast<uint16_t*>(keys_alt), vals_alt, hist,
+                                     gsum_all, false, nullptr, n_dev, s);
     }
-    if (keys16) {          // (the caller asked radix_sort_keys16_ok first: grouped + staged, no compaction)
-        if (!grouped || !staged || n_valid_dev || end_bit > 16) return hipErrorInvalidValue;
-        return radix_sort_pairs_u16(reinterpret_cast<uint16_t*>(keys_in), vals_in, reinterpret_cast<uint16_t*>(keys_out), vals_out,
-                                    n, passes, begin_bit, end_bit, G, reinterpret_cast<uint16_t*>(keys_alt), vals_alt, hist,
-                                    gsum_all, n_dev, s);
-    }
-    static const bool no_compact = [] { const char* e = getenv("MSGS_SORT_NO_COMPACT"); return e && e[0] == '1'; }();
-    const bool compact = n_valid_dev != nullptr && grouped && staged && !G.scanned && !no_compact;
+    const bool compact = n_valid_dev != nullptr && !G.scanned;
     if (n_valid_dev && !compact) hipLaunchKernelGGL(store_u32_kernel, dim3(1), dim3(1), 0, s, n_valid_dev, (uint32_t)n);
-    // ping-pong so that the LAST pass writes keys_out/vals_out
-    const uint32_t* src_k = keys_in;
-    const uint32_t* src_v = vals_in;
-    int next_shift = begin_bit;
-    for (int p = 0; p < passes; ++p) {
-        // grouped path: digit widths balanced over the passes (13 tile bits -> 7 + 6, not 8 + 5): a block's keys of one
-        // digit leave as one run, and the run length — hence the write coalescing of the scatter — is set by the pass
-        // with the MOST digits
-        const int shift = grouped ? next_shift : begin_bit + 8 * p;
-        const int left = end_bit - shift;
-        const int bits = grouped ? (left + (passes - p) - 1) / (passes - p) : (left < 8 ? left : 8);
-        next_shift = shift + bits;
-        const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << (bits > 0 ? bits : 1)) - 1u);
-        const bool to_out = ((passes - 1 - p) % 2) == 0;
-        uint32_t* dst_k = to_out ? keys_out : keys_alt;
-        uint32_t* dst_v = to_out ? vals_out : vals_alt;
-        if (onesweep) {
-            hipLaunchKernelGGL(onesweep_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v, dst_k, dst_v,
-                               n, shift, mask, digit_hist + p * 256, status + (size_t)p * 256 * nb, tickets + p, err);
-        } else if (grouped) {
-            // two kernels per pass: block histograms + group sums, then a scatter that derives its own bases
-            uint32_t* gs = gsum_all + (size_t)p * 256 * ngroups;
-            const dim3 grid((unsigned)nb), block(SORT_THREADS);
-            const bool drop = compact && p == 0;
-            const uint32_t* np = n_dev ? n_dev : (compact && p > 0 ? n_valid_dev : nullptr);
-            uint32_t* no = drop ? n_valid_dev : nullptr;
-            if (big && G.scanned) {
-                hipLaunchKernelGGL((radix_hist_kernel<16>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize, ngroups,
-                                   np);
-                hipLaunchKernelGGL(group_scan_kernel, dim3((unsigned)ngroups + 1), dim3(256), 0, s, gs, ngroups, hist, gsize, nb);
-                hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                                   mask, nb, hist, gs, gsize, ngroups, true, np, (uint32_t*)nullptr);
-            } else if (big) {
-                launch_grouped_pass<16>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np, no, s);
-            } else if (mid) {
-                launch_grouped_pass<8>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np, no, s);
-            } else if (staged) {
-                launch_grouped_pass<SORT_ITEMS>(src_k, src_v, dst_k, dst_v, n, shift, mask, nb, hist, gs, gsize, ngroups, drop, np,
-                                                no, s);
-            } else {
-                hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), grid, block, 0, s, src_k, n, shift, mask, nb, hist, gs, gsize,
-                                   ngroups, (const uint32_t*)nullptr);
-                hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), grid, block, 0, s, src_k, src_v, dst_k, dst_v, n,
-                                   shift, mask, nb, hist, gs, gsize, ngroups, false, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-            }
-        } else {
-            hipLaunchKernelGGL((radix_hist_kernel<SORT_ITEMS>), dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, n, shift, mask,
-                               nb, hist, (uint32_t*)nullptr, 1, 1, (const uint32_t*)nullptr);
-            hipError_t e = exclusive_scan_u32(hist, nullptr, hist, 256 * nb, partials, nullptr, s);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((radix_scatter_kernel<false, SORT_ITEMS>), dim3((unsigned)nb), dim3(SORT_THREADS), 0, s, src_k, src_v,
-                               dst_k, dst_v, n, shift, mask, nb, hist, (const uint32_t*)nullptr, 1, 1, false,
-                               (const uint32_t*)nullptr, (uint32_t*)nullptr);
-        }
-        src_k = dst_k;
-        src_v = dst_v;
-    }
-    return hipGetLastError();
+    return sort_passes<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, passes, begin_bit, end_bit, G, keys_alt, vals_alt, hist,
+                                 gsum_all, compact, n_valid_dev, n_dev, s);
 }
 
 }  // namespace msgs

@@ -194,7 +194,7 @@ class _Call:
         self.view = _C.View(self.H, self.W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
                             float(rs.fade_size), int(rs.sh_degree), self.K,
                             int(bool(rs.filter_small)), int(bool(rs.filter_large)), int(bool(rs.prefiltered)),
-                            int(bool(rs.debug)), 0, 0, _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
+                            int(bool(rs.debug)), 0, 0, 0.0, 0, _ptr(self.bg), _ptr(self.vm), _ptr(self.pm), _ptr(self.cp))
         # mode 1: raw parameters everywhere; mode 2: activated inputs + raw quaternions, gradients chained to the raw
         # parameters inside msgs_backward (include/msgs.h, msgs_gaussians_t::raw_params)
         self.rot_raw = _f32c(rotations_raw) if rotations_raw is not None else None
@@ -266,50 +266,93 @@ def set_deterministic(on=True):
 _last_instances = {}
 
 
-# Occlusion cut-off pass (include/msgs.h, msgs_set_occlusion): four small launches between the per-Gaussian stage and the depth
-# sort — 16-21 us on a view where they find nothing to cut, milliseconds saved where opaque covers hide most of the scene (a
-# multi-scale model rendered without its filters, /root/reference/render.py:32).  The outputs never depend on it.  Policy per
-# (device, P, W, H, filters) key:
-#   "adaptive" (default)  the pass runs on the first call and then on every OCCLUSION_PROBE_PERIOD-th call; in between it runs only
-#                         while one of the key's last OCCLUSION_PROBE_PERIOD calls closed at least one block (msgs_forward_info:
-#                         the answer travels with the count).  The key does not know the camera: in a sweep that alternates views
-#                         that close with views that do not, the latter must not switch the pass off for the former (skipping
-#                         costs milliseconds where it would have cut, running costs ~20 us where it does not).  The number of
-#                         cover candidates is NOT a criterion: the C5 headline view has 10 751 of them and closes nothing
-#   "always" / "never"    MSGS_OCCLUSION_POLICY, or assign diff_gaussian_rasterization.occlusion_policy
-occlusion_policy = os.environ.get("MSGS_OCCLUSION_POLICY", "adaptive")
-OCCLUSION_PROBE_PERIOD = 32
-_occ_countdown = {}          # key -> calls left before the next probe (absent / 0: run the pass)
-_occ_hot = {}                # key -> calls for which the pass keeps running whatever they find: refreshed to OCCLUSION_PROBE_PERIOD by
-                             # every call that closes a block
+# Occlusion cut-off pass (include/msgs.h, msgs_set_occlusion): ONE launch between the per-Gaussian stage and the depth sort that a
+# view without cover candidates leaves after its first grid barrier (~5 us) — it runs on EVERY forward; the adaptive skip policy
+# of round 5 (and its cliff: a closing view among the skipped calls rendered uncut) is gone.  What is left per (device, P, W, H,
+# filters) key is a performance HINT for one small launch: the queue that gives every Gaussian with more than 96 tile instances
+# a workgroup of its own (msgs_view_t.no_heavy_queue) pays off when covers closed blocks — the nearest ranks are then all
+# giants — and is a wasted ~3 us launch otherwise; it is kept on for HEAVY_QUEUE_MEMORY calls after the key last closed a block
+# (msgs_forward_info: the answer travels with the instance count) and on the key's first call.  Outputs never depend on it.
+HEAVY_QUEUE_MEMORY = 32
+_occ_hot = {}                # key -> calls for which the queue stays on: refreshed by every call of the key that closes a block
 
 
-def _occlusion_skip(key):
-    if occlusion_policy == "always":
-        return False
-    if occlusion_policy == "never":
-        return True
-    return _occ_hot.get(key, 0) == 0 and _occ_countdown.get(key, 0) > 0
+def _heavy_queue_off(key):
+    return _occ_hot.get(key, 1) == 0
 
 
-def _occlusion_note(key, skipped):
-    """after the instance count of a forward has been collected on this thread"""
-    if occlusion_policy != "adaptive":
-        return
-    if skipped:
-        _occ_countdown[key] = _occ_countdown.get(key, 1) - 1
-        return
-    info = (C.c_int64 * 2)()
+# Depth-slab binning (include/msgs.h, msgs_view_t.slab_fraction).  Stage 2 bins and blends the nearest depth ranks
+# first and then only the tiles in which a pixel is still blending: bit-identical outputs, and on a view whose pixels terminate
+# early (BASELINE C5: 54.9 M instances, 4.35 M traversed) emit / tile sort / ranges shrink to a fraction.  On a view whose
+# pixels walk most of their lists (C3: 44 %) it would only add launches, so the wrapper engages it per (device, P, W, H, filters)
+# key from what the library publishes about the key's EARLIER frames (msgs_view_t.feedback_tag -> msgs_forward_info: instances D,
+# traversed entries D_trav; one frame late, no synchronisation):
+#   slab_policy "adaptive" (default)   on while D >= SLAB_MIN_INSTANCES and D >= SLAB_MIN_RATIO * D_trav (else the key asks for a
+#                                      publication on every SLAB_RECHECK-th call only), with
+#                                      slab_fraction = 2 * D_trav / D clamped to [0.04, 0.30]; off for SLAB_BACKOFF calls of the key
+#                                      when a slab frame emitted more than 70 % of D anyway (the view changed)
+#   "never" / a float                  never / always with that fraction (tests, A/B runs)
+# Either way the result is exact; the worst case of a wrong guess is ~15 % of a binning pass.
+slab_policy = os.environ.get("MSGS_SLAB_POLICY", "adaptive")
+SLAB_MIN_INSTANCES = 2_000_000
+SLAB_MIN_RATIO = 6.0
+SLAB_BACKOFF = 64
+SLAB_RECHECK = 16
+_fb_stats = {}               # key -> {"D", "D_trav", "backoff", ...}: the latest publication of the key
+_fb_tag_of = {}              # key -> tag (1 .. 2^31 - 1)
+_fb_key_of = {}              # tag -> key
+_fb_next_tag = [0]
+
+
+def _slab_plan(key, guess, tiles):
+    """(slab_fraction, feedback_tag) for the next forward of `key`"""
+    pol = slab_policy
+    if pol == "never":
+        return 0.0, 0
+    if pol != "adaptive":
+        return float(pol), 0
+    if tiles < 2048 or guess is None or guess < SLAB_MIN_INSTANCES // 2:
+        return 0.0, 0                                   # small frames: no feedback launch either
+    tag = _fb_tag_of.get(key)
+    if tag is None:
+        if len(_fb_tag_of) > 1024:
+            _fb_tag_of.clear(); _fb_key_of.clear(); _fb_stats.clear()
+        _fb_next_tag[0] = _fb_next_tag[0] % 0x7FFFFFF0 + 1        # never reused while an old publication may still sit in a status block
+        tag = _fb_tag_of[key] = _fb_next_tag[0]
+        _fb_key_of[tag] = key
+    st = _fb_stats.get(key)
+    if st is None:
+        return 0.0, tag
+    if st["D"] < SLAB_MIN_INSTANCES or st["D"] < SLAB_MIN_RATIO * max(st["D_trav"], 1):
+        # not a view for slabs (BASELINE C3: D = 2.3 x D_trav): look again every SLAB_RECHECK-th call only — the publication is
+        # one small kernel with a system-scope store, ~4 us per forward
+        st["idle"] = (st.get("idle", 0) + 1) % SLAB_RECHECK
+        return 0.0, (tag if st["idle"] == 0 else 0)
+    if st.get("backoff", 0) > 0:
+        st["backoff"] -= 1
+        return 0.0, tag
+    return min(0.30, max(0.04, 2.0 * st["D_trav"] / st["D"])), tag
+
+
+def _note_info(key):
+    """after the instance count of a forward has been collected on this thread: what travelled with it"""
+    info = (C.c_int64 * 8)()
     _C.lib.msgs_forward_info(info)
-    if len(_occ_countdown) > 256:
-        _occ_countdown.clear()
+    tag = int(info[2])
+    if tag:
+        k = _fb_key_of.get(tag)
+        if k is not None:
+            st = _fb_stats.setdefault(k, {})
+            st["D"], st["D_trav"] = int(info[3]), int(info[4])
+            if info[5] >= 0:                            # that frame ran in slab mode: did it pay?
+                st["n_open"], st["DA"], st["DB"] = int(info[5]), int(info[6]), int(info[7])
+                if info[7] < 0:
+                    raise RuntimeError("diff_gaussian_rasterization: slab B outgrew its buffers (SlabHeader overflow flag)")
+                if int(info[6]) + int(info[7]) > 0.7 * max(int(info[3]), 1):
+                    st["backoff"] = SLAB_BACKOFF
+    if len(_occ_hot) > 1024:
         _occ_hot.clear()
-    if info[1]:
-        hot = OCCLUSION_PROBE_PERIOD
-    else:
-        hot = max(_occ_hot.get(key, 0) - 1, 0)
-    _occ_hot[key] = hot
-    _occ_countdown[key] = 0 if hot else OCCLUSION_PROBE_PERIOD - 1
+    _occ_hot[key] = HEAVY_QUEUE_MEMORY if info[1] else max(_occ_hot.get(key, 1) - 1, 0)
 
 
 _size_cache = {}
@@ -329,6 +372,15 @@ def _sizes(P, W, H):
 
 def _a256(n):
     return (int(n) + 255) & ~255
+
+
+def _stage2_bytes(D, W, H, frac):
+    """(binning, stage-2 scratch) byte counts that serve D instances — with room for slab A's ids in front of slab B's when the call
+    asks for depth slabs"""
+    lib = _C.lib
+    if frac > 0.0:
+        return int(lib.msgs_binning_bytes_slab(D, W, H, frac)), int(lib.msgs_stage2_scratch_bytes_slab(D, W, H))
+    return int(lib.msgs_binning_bytes(D, W, H)), int(lib.msgs_stage2_scratch_bytes(D, W, H))
 
 
 # ---- deferred forwards: several views in flight from one host thread (include/msgs.h msgs_forward_launch / _finish) ----
@@ -416,14 +468,15 @@ class _PendingForward:
             D = int(D.value)
             guess = self.guess
             _last_instances[self.key] = max(D, (guess + D) // 2) if guess is not None else D
-            _occlusion_note(self.key, getattr(self, "skip_occ", False))
+            _note_info(self.key)
             if not done.value:                          # first frame of this shape, or the scene grew past the margin
                 dev, W, H = call.device, call.W, call.H
                 color, acc_ps, depth = self.outs
                 self.error = RuntimeError("stage 2 on exact buffers failed")     # cleared below
                 with _on_device(dev), torch.cuda.stream(self.stream):
-                    self.binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
-                    scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
+                    nb_, ns_ = _stage2_bytes(D, W, H, float(call.view.slab_fraction))
+                    self.binning = _bytes(nb_, dev)
+                    scratch2 = _bytes(ns_, dev)
                     grad_rec = self.grad_rec
                     _C.check(lib.msgs_forward_stage2(call.view_ref, call.g_ref, _ptr(self.geom), self.geom.numel(), D,
                                                      _ptr(self.binning), self.binning.numel(), _ptr(scratch2),
@@ -455,8 +508,11 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
     lib = _C.lib
     key = (dev.index, P, W, H, call.view.filter_small, call.view.filter_large)
     pending = getattr(_deferred, "pending", None)
-    skip_occ = _occlusion_skip(key)
-    call.view.skip_occlusion = int(skip_occ)
+    call.view.no_heavy_queue = int(_heavy_queue_off(key))
+    frac, tag = _slab_plan(key, _last_instances.get(key), ((W + 15) // 16) * ((H + 15) // 16))
+    if frac > 0.0 and lib.msgs_get_deterministic():
+        frac = 0.0
+    call.view.slab_fraction, call.view.feedback_tag = frac, tag
     with _on_device(dev):
         cur = torch.cuda.current_stream(dev)
         stream = C.c_void_p(cur.cuda_stream)
@@ -472,7 +528,7 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
         n_bin = n_s2 = 0
         if guess is not None:
             cap = guess + (guess >> 3) + 4096
-            n_bin, n_s2 = int(lib.msgs_binning_bytes(cap, W, H)), int(lib.msgs_stage2_scratch_bytes(cap, W, H))
+            n_bin, n_s2 = _stage2_bytes(cap, W, H, frac)
         keep = _bytes(_a256(n_geom) + _a256(n_img) + n_bin, dev)
         geom, image = keep[:n_geom], keep[_a256(n_geom):_a256(n_geom) + n_img]
         binning = keep[_a256(n_geom) + _a256(n_img):] if n_bin else None
@@ -497,7 +553,6 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
                 raise
             state = _PendingForward(call, status, cur, key, guess, geom, binning, image, (color, acc_ps, depth), grad_rec, keep,
                                     backward_follows, scratch1)
-            state.skip_occ = skip_occ
             pending.append(state)
             return color, acc_ps, depth, radii, pixel_sizes, state
         tmp = _bytes(_a256(n_s1) + n_s2, dev)
@@ -512,11 +567,12 @@ def _forward_impl(call, grad_rec=None, backward_follows=False):
                                   C.byref(D), C.byref(done), _C.timer_ptr(), stream), "msgs_forward")
         D = int(D.value)
         _last_instances[key] = max(D, (guess + D) // 2) if guess is not None else D
-        _occlusion_note(key, skip_occ)
+        _note_info(key)
         del scratch1, scratch2, tmp
         if not done.value:                              # first frame of this shape, or the scene grew past the margin
-            binning = _bytes(lib.msgs_binning_bytes(D, W, H), dev)
-            scratch2 = _bytes(lib.msgs_stage2_scratch_bytes(D, W, H), dev)
+            nb_, ns_ = _stage2_bytes(D, W, H, frac)
+            binning = _bytes(nb_, dev)
+            scratch2 = _bytes(ns_, dev)
             _C.check(lib.msgs_forward_stage2(call.view_ref, call.g_ref, _ptr(geom), n_geom, D,
                                              _ptr(binning), binning.numel(), _ptr(scratch2), scratch2.numel(),
                                              _ptr(image), n_img, _ptr(color), _ptr(acc_ps), _ptr(depth),

@@ -16,10 +16,10 @@ _LIB_PATH = os.environ.get("MSGS_HIP_LIB") or next(
     (p for p in (os.path.join(_PKG, "libmsgs_hip.so"),) if os.path.exists(p)),
     os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
-           "preprocess_bwd")
+           "preprocess_bwd", "slab_b")
 K_COUNT = len(K_NAMES)
 
 
@@ -30,7 +30,8 @@ class View(C.Structure):
                 ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("filter_small", C.c_int32), ("filter_large", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
-                ("skip_occlusion", C.c_int32), ("reserved0", C.c_int32),
+                ("no_heavy_queue", C.c_int32), ("feedback_tag", C.c_int32),
+                ("slab_fraction", C.c_float), ("reserved1", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 
@@ -91,6 +92,8 @@ def _load():
                        ("msgs_binning_bytes", [C.c_int64, C.c_int32, C.c_int32]),
                        ("msgs_stage2_scratch_bytes", [C.c_int64, C.c_int32, C.c_int32]),
                        ("msgs_image_bytes", [C.c_int32, C.c_int32]),
+                       ("msgs_binning_bytes_slab", [C.c_int64, C.c_int32, C.c_int32, C.c_float]),
+                       ("msgs_stage2_scratch_bytes_slab", [C.c_int64, C.c_int32, C.c_int32]),
                        ("msgs_backward_scratch_bytes", [C.c_int32])):
         f = getattr(lib, name)
         f.restype = sz
@@ -108,14 +111,14 @@ def _load():
     lib.msgs_set_backward_generation.argtypes = [C.c_int32]
     lib.msgs_set_blend_granularity.restype = C.c_int
     lib.msgs_set_blend_granularity.argtypes = [C.c_int32]
-    lib.msgs_set_forward_variant.restype = C.c_int
-    lib.msgs_set_forward_variant.argtypes = [C.c_int32]
     lib.msgs_forward_info.restype = C.c_int
     lib.msgs_forward_info.argtypes = [C.POINTER(C.c_int64)]
     lib.msgs_set_occlusion.restype = C.c_int
     lib.msgs_set_occlusion.argtypes = [C.c_int32]
     lib.msgs_occlusion_stats.restype = C.c_int
     lib.msgs_occlusion_stats.argtypes = [vp, sz, C.c_int32, C.POINTER(C.c_int64), vp]
+    lib.msgs_slab_stats.restype = C.c_int
+    lib.msgs_slab_stats.argtypes = [vp, sz, C.c_int32, C.POINTER(C.c_int64), vp]
     lib.msgs_forward.restype = C.c_int
     lib.msgs_forward.argtypes = [C.POINTER(View), C.POINTER(Gaussians), vp, vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz,
                                  vp, vp, vp, vp, sz, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(Timing), vp]
@@ -195,9 +198,10 @@ EXPORTS = ("msgs_abi_version", "msgs_error_string", "msgs_geom_bytes", "msgs_sta
            "msgs_dist2_knn3", "msgs_forward", "msgs_set_deterministic",
            "msgs_get_deterministic", "msgs_backward_scratch_bytes_deterministic",
            "msgs_set_backward_generation", "msgs_set_blend_granularity", "msgs_sh_grad_from_views",
-           "msgs_blend_lane_stats", "msgs_backward_per_gaussian", "msgs_set_forward_variant",
+           "msgs_blend_lane_stats", "msgs_backward_per_gaussian",
            "msgs_status_create", "msgs_status_destroy", "msgs_forward_launch", "msgs_forward_finish",
-           "msgs_set_occlusion", "msgs_occlusion_stats", "msgs_forward_info")
+           "msgs_set_occlusion", "msgs_occlusion_stats", "msgs_forward_info", "msgs_binning_bytes_slab",
+           "msgs_stage2_scratch_bytes_slab", "msgs_slab_stats")
 
 
 def check(rc, where):

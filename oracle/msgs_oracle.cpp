@@ -118,6 +118,20 @@ static inline real power_sign_window(const Geom& ge, real dx, real dy) {
     return RL(1.8e-7) * M + RL(3.3e-7) * std::max(RL(1.0), l2o);       // 3 x 2^-24 M  +  2^-21 ln 2 x max(1, |log2 opacity|)
 }
 
+// exp() of the blend kernels.  The float32 checker's default is glibc's expf — what rounds 1-5 were checked against.  With
+// msgs_oracle_set_exp_double(1) the exponential is evaluated in double and rounded to float ONCE: the product's literal
+// verification mode (msgs_set_deterministic, ms-gs_amd/csrc/literal.hip) does the same, so that the two sides take the SAME
+// float for every alpha (two float32 exponentials — glibc's expf, the GPU's v_exp_f32 — differ by an ulp on about a third of
+// their arguments; two double exponentials rounded once differ practically never).  No-op in the float64 build.
+static int g_exp_double = 0;
+extern "C" int msgs_oracle_set_exp_double(int on) { const int prev = g_exp_double; g_exp_double = on ? 1 : 0; return prev; }
+static inline real oracle_exp(real p) {
+#if !defined(MSGS_ORACLE_F64)
+    if (g_exp_double) return (real)std::exp((double)p);
+#endif
+    return std::exp(p);
+}
+
 struct msgs_oracle_state {
     int P = 0, W = 0, H = 0, gx = 0, gy = 0;
     std::vector<Geom> geom;
@@ -452,7 +466,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                         }
                         continue;
                     }
-                    real alpha = std::min(RL(0.99), ge.opacity * std::exp(power));        // Q6
+                    real alpha = std::min(RL(0.99), ge.opacity * oracle_exp(power));        // Q6
                     const real win = alpha_window(ge, dx, dy, power);
                     const bool reaches = alpha * 255.0f >= 1.0f - win;
                     const bool own_edge = std::fabs(alpha * 255.0f - 1.0f) < win || power_edge;
@@ -507,7 +521,7 @@ extern "C" int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians
                         real dx = ge.px - pxf, dy = ge.py - pyf;
                         real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                         if (power > 0.0f) continue;
-                        if (std::min(RL(0.99), ge.opacity * std::exp(power)) * 255.0f < 1.0f - alpha_window(ge, dx, dy, power)) continue;
+                        if (std::min(RL(0.99), ge.opacity * oracle_exp(power)) * 255.0f < 1.0f - alpha_window(ge, dx, dy, power)) continue;
                         uint8_t* sh_flag = &st->shared_gauss[id];
 #pragma omp atomic write
                         *sh_flag = 1;
@@ -590,7 +604,7 @@ extern "C" int msgs_oracle_backward_ex(const msgs_oracle_state_t* st, const msgs
                     real dx = ge.px - pxf, dy = ge.py - pyf;
                     real power = -0.5f * (ge.con[0] * dx * dx + ge.con[2] * dy * dy) - ge.con[1] * dx * dy;
                     if (power > 0.0f) continue;
-                    const real G = std::exp(power);
+                    const real G = oracle_exp(power);
                     const real alpha = std::min(RL(0.99), ge.opacity * G);
                     if (alpha < RL(1.0) / RL(255.0)) continue;
                     T = T / (1.f - alpha);

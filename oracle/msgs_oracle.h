@@ -26,6 +26,10 @@ int msgs_oracle_forward(const msgs_view_t* view, const msgs_gaussians_t* g,
                         int32_t* radii, float* pixel_sizes, uint8_t* borderline,
                         msgs_oracle_state_t** state_out, int num_threads);
 
+/* 1: exp() evaluated in double and rounded to float once (what the product's literal verification mode does); 0 (default):
+ * glibc expf.  Process-wide; returns the previous value.  No-op in the float64 build. */
+int msgs_oracle_set_exp_double(int on);
+
 int msgs_oracle_backward(const msgs_oracle_state_t* state, const msgs_view_t* view,
                          const msgs_gaussians_t* g, const float* dL_dcolor,
                          const msgs_grads_t* grads, int num_threads);

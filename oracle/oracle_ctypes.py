@@ -22,7 +22,8 @@ class View(C.Structure):
                 ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("filter_small", C.c_int32), ("filter_large", C.c_int32),
                 ("prefiltered", C.c_int32), ("debug", C.c_int32),
-                ("skip_occlusion", C.c_int32), ("reserved0", C.c_int32),
+                ("no_heavy_queue", C.c_int32), ("feedback_tag", C.c_int32),
+                ("slab_fraction", C.c_float), ("reserved1", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 
@@ -196,6 +197,22 @@ def _threads(num_threads):
     return int(num_threads) if num_threads and num_threads > 0 else _usable_cpus()
 
 
+class exp_double:
+    """`with exp_double():` — the float32 oracle evaluates exp() in double and rounds once (msgs_oracle_set_exp_double), like the
+    product's literal verification mode; forward AND backward of a comparison belong inside the block"""
+
+    def __enter__(self):
+        L = lib()
+        L.msgs_oracle_set_exp_double.restype = C.c_int
+        L.msgs_oracle_set_exp_double.argtypes = [C.c_int]
+        self.prev = L.msgs_oracle_set_exp_double(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().msgs_oracle_set_exp_double(self.prev)
+        return False
+
+
 def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_precomp=False,
               cov3D_precomp=None, colors_precomp=None, num_threads=0, scale_modifier=1.0, f64=False, fma=False):
     """Forward on a scenes.Scene.  Returns OracleResult with .color/.acc_pixel_size/.depth/.radii/
@@ -228,7 +245,7 @@ def rasterize(scene, cam, settings, bg, *, use_cov_precomp=False, use_colors_pre
     v = View(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(scale_modifier),
              float(settings.get("fade_size", 1.0)), int(scene.sh_degree), int(K),
              int(bool(settings.get("filter_small", False))), int(bool(settings.get("filter_large", False))),
-             0, 0, 0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
+             0, 0, 0, 0, 0.0, 0, _ptr(t["bg"]), _ptr(t["vm"]), _ptr(t["pm"]), _ptr(t["cp"]))
     g = Gaussians(P, 0, _ptr(t["means3D"]), _ptr(t["shs"]), _ptr(t["col"]), _ptr(t["opac"]),
                   _ptr(t["scales"]), _ptr(t["rot"]), _ptr(t["cov"]), _ptr(t["maxps"]), _ptr(t["minps"]),
                   _ptr(t["occ"]), _ptr(t["dcd"]), _ptr(t["base"]), None, None, None)

@@ -133,7 +133,7 @@ def test_c3_tile_lists_are_depth_sorted_and_ranges_checksum(c3):
     P = sc.P
     W, H = cam.image_width, cam.image_height
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    ioff = (8 * tiles + 255) // 256 * 256                                # BinningLayout: tile ranges first, then the ids
+    ioff = (8 * tiles + 255) // 256 * 256 + 512                          # BinningLayout: tile ranges, 64 D_trav accumulators, then the ids
     ids = binning[ioff:ioff + 4 * D].view(torch.int32).long()
     ranges = binning[:8 * tiles].view(torch.int32).view(tiles, 2).long()
     lo, hi = ranges[:, 0], ranges[:, 1]

@@ -1,5 +1,5 @@
 """The randomised three-way parity sweep in front of the driver (tests/fuzz_cases.py has the criterion and the classes): 320
-seeded configurations over every forward variant, both backward generations, the fine kernels, fade > 0, the chained and the
+seeded configurations over both backward generations, the fine kernels, fade > 0, the chained and the
 plain getter path, and the precomputed-colour / precomputed-covariance entries, each against the float32 oracle, the float64
 truth and the FMA-contracted float32 oracle.  Asserts ZERO unexplained exceedances and bounds every explained class by count."""
 import json
@@ -36,7 +36,7 @@ def test_randomised_three_way_sweep_has_no_unexplained_exceedance():
     assert mw["configurations"] >= 40 and mw["with_closed_blocks"] >= 8 and mw["with_every_block_closed"] >= 4, mw
     # every kernel variant was drawn
     cfgs = [r["cfg"] for r in results]
-    assert {c["fwd_var"] for c in cfgs} == {0, 1, 3, 4, 5, 6} and {c["bwd_gen"] for c in cfgs} == {0, 1, 2}
+    assert {c["bwd_gen"] for c in cfgs} == {0, 1, 2}
     assert {c["gran"] for c in cfgs} == {0, 1, 2} and {c["entry"] for c in cfgs} == {"render", "precomp_col", "precomp_cov", "precomp_both"}
     assert any(c["fade"] > 0 and c["ms"] for c in cfgs) and {c["chain"] for c in cfgs} == {True, False}
 

@@ -36,7 +36,6 @@ def _run(sc, cam, st, bg, dL, occlusion, backward=True, fused=False):
     from gaussian_renderer import render, render_fused
     from synthetic_model import SyntheticGaussians
     prev = dgr._C.lib.msgs_set_occlusion(1 if occlusion else 0)
-    prev_policy, dgr.occlusion_policy = dgr.occlusion_policy, "always"      # (the wrapper's adaptive skipping is tested below)
     try:
         dgr._last_instances.clear()
         pc = SyntheticGaussians(sc, "cuda", requires_grad=backward)
@@ -61,7 +60,6 @@ def _run(sc, cam, st, bg, dL, occlusion, backward=True, fused=False):
         return out, pc, D, stats, per_pixel
     finally:
         dgr._C.lib.msgs_set_occlusion(prev)
-        dgr.occlusion_policy = prev_policy
 
 
 def _assert_identical(a, b, what, backward=True):
@@ -256,7 +254,6 @@ def test_a_view_that_really_closes_blocks_matches_the_oracle():
     cam = scenes.front_camera(W, H)
     bg = torch.tensor([0.2, 0.5, 0.1])
     dL = scenes.grad_seed(W, H, 5)
-    prev_policy, dgr.occlusion_policy = dgr.occlusion_policy, "always"
     prev = dgr._C.lib.msgs_set_occlusion(1)
     try:
         dgr._last_instances.clear()
@@ -264,7 +261,6 @@ def test_a_view_that_really_closes_blocks_matches_the_oracle():
         stats = _stats(out["render"].grad_fn)
     finally:
         dgr._C.lib.msgs_set_occlusion(prev)
-        dgr.occlusion_policy = prev_policy
     assert stats["ran"] and stats["closed_blocks"] > 0, stats
     orc = oc.rasterize(pc.seen, cam, PLAIN, bg)
     og = oc.backward(orc, dL)
@@ -284,9 +280,7 @@ def test_two_views_in_flight_on_a_scene_that_closes_blocks():
     cams = [scenes.front_camera(W, H).to("cuda") for _ in range(4)]
     dLs = [scenes.grad_seed(W, H, 20 + v).cuda() for v in range(4)]
     bg = torch.tensor([0.4, 0.1, 0.2], device="cuda")
-    prev_policy = dgr.occlusion_policy
     try:
-        dgr.occlusion_policy = "always"
         prev = dgr._C.lib.msgs_set_occlusion(0)
         dgr._last_instances.clear()
         ref_pc = SyntheticGaussians(sc, "cuda")
@@ -321,7 +315,6 @@ def test_two_views_in_flight_on_a_scene_that_closes_blocks():
             assert D_on < D_off, (D_on, D_off)
     finally:
         dgr._C.lib.msgs_set_occlusion(prev)
-        dgr.occlusion_policy = prev_policy
 
 
 def test_8k_image_uses_larger_cover_blocks():
@@ -355,56 +348,57 @@ def test_pyramid_levels_and_filters_on_are_unchanged():
     assert dgr._C.lib.msgs_set_occlusion(1) == 1
 
 
-def test_adaptive_policy_probes_then_skips_then_probes_again():
-    """diff_gaussian_rasterization.occlusion_policy = "adaptive" (the default): the pass runs on the first call of a (model size,
-    image, filters) key; while a probe finds nothing to cut the next OCCLUSION_PROBE_PERIOD - 1 calls skip it
-    (msgs_view_t.skip_occlusion), and while one of the key's last OCCLUSION_PROBE_PERIOD calls did cut, every call runs it
-    — also for a view of the same key that cuts nothing itself.  Same image either way."""
+def test_the_pass_always_runs_and_the_heavy_queue_hint_follows_what_the_views_close():
+    """Round 6: the pass is one launch that a view without cover candidates leaves after its first grid barrier, so it runs on
+    EVERY forward (the adaptive skip policy of round 5 and its cliff are gone).  A sweep that alternates a view that closes with
+    one that looks away from everything — starting on the one that does not close — cuts the closing view every time.  What the
+    wrapper still adapts per (model, image, filters) key is a hint for one small launch (msgs_view_t.no_heavy_queue): on after a
+    call of the key closed a block, off after HEAVY_QUEUE_MEMORY calls that did not.  Same image either way."""
     import diff_gaussian_rasterization as dgr
     from gaussian_renderer import render
     from synthetic_model import SyntheticGaussians
-    prev_policy, dgr.occlusion_policy = dgr.occlusion_policy, "adaptive"       # (the default unless MSGS_OCCLUSION_POLICY says otherwise)
     W, H = 480, 320
     cam = scenes.front_camera(W, H).to("cuda")
+    away = scenes.ring_camera(0, 8, W, H, radius=50.0).to("cuda")        # far from the frustum scene, looking back at the origin
     bg = torch.zeros(3, device="cuda")
     quiet = scenes.frustum_scene(3000, W, H, seed=5, scale_k=0.004 * 1920.0 / W * 0.3)          # nothing to cut
     walls = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.9)                # opaque covers in front
-    info = (C.c_int64 * 2)()
-    # many heavy Gaussians, all nearly transparent: cover candidates, but nothing closes (the C5 headline view has 10 751
-    # candidates and closes nothing) — treated like the quiet scene
-    haze = _giants_scene(3000, W, H, 5, 60, giant_scale=1.5, giant_opacity=0.012)
-    for sc, cuts in ((quiet, False), (walls, True), (haze, False)):
-        dgr._occ_countdown.clear()
-        dgr._occ_hot.clear()
-        dgr._last_instances.clear()
-        pc = SyntheticGaussians(sc, "cuda", requires_grad=False)
-        ran, imgs = [], []
-        with torch.no_grad():
-            for it in range(dgr.OCCLUSION_PROBE_PERIOD + 2):
-                out = render(cam, pc, PIPE, bg, **PLAIN)
-                dgr._C.lib.msgs_forward_info(info)
-                ran.append(int(info[0]) > 0 or int(info[1]) > 0)
-                imgs.append(out["render"])
-        assert all(torch.equal(imgs[0], im) for im in imgs[1:])
-        if cuts:
-            assert all(ran), ran
-        else:            # candidates may be zero on a quiet scene: look at the wrapper's own bookkeeping instead
-            key = next(iter(dgr._occ_countdown))
-            assert dgr._occ_countdown[key] == dgr.OCCLUSION_PROBE_PERIOD - 2, dgr._occ_countdown
-    # a sweep that alternates a view that closes with one that looks away from everything (same key: the wrapper does not know
-    # the camera): the pass must keep running for the view that closes
-    dgr._occ_countdown.clear()
+    info = (C.c_int64 * 8)()
+    key = (0, 3000, W, H, 0, 0)
+    # (1) alternating sweep starting on the view that closes nothing: the closing view is cut on every visit
     dgr._occ_hot.clear()
     dgr._last_instances.clear()
-    away = scenes.ring_camera(0, 8, W, H, radius=50.0).to("cuda")        # far from the frustum scene, looking back at the origin
     pc = SyntheticGaussians(walls, "cuda", requires_grad=False)
-    closed_when_facing = []
+    prev = dgr._C.lib.msgs_set_occlusion(0)
+    with torch.no_grad():
+        render(cam, pc, PIPE, bg, **PLAIN)
+    D_uncut = dgr._last_instances[key]
+    dgr._C.lib.msgs_set_occlusion(1)
+    dgr._last_instances.clear()
+    closed, counts, imgs = [], [], []
     with torch.no_grad():
         for it in range(12):
-            facing = it % 2 == 0
-            render(cam if facing else away, pc, PIPE, bg, **PLAIN)
+            facing = it % 2 == 1
+            out = render(cam if facing else away, pc, PIPE, bg, **PLAIN)
             dgr._C.lib.msgs_forward_info(info)
             if facing:
-                closed_when_facing.append(int(info[1]))
-    assert all(closed_when_facing), closed_when_facing
-    dgr.occlusion_policy = prev_policy
+                closed.append(int(info[1]))
+                imgs.append(out["render"])
+    dgr._C.lib.msgs_set_occlusion(prev)
+    assert all(closed), closed
+    assert all(torch.equal(imgs[0], im) for im in imgs[1:])
+    assert dgr._occ_hot[key] >= dgr.HEAVY_QUEUE_MEMORY - 1            # the queue stays on for this key
+    # (2) a quiet scene: the hint switches the queue off after HEAVY_QUEUE_MEMORY calls, the image does not change
+    dgr._occ_hot.clear()
+    dgr._last_instances.clear()
+    pc = SyntheticGaussians(quiet, "cuda", requires_grad=False)
+    imgs, off = [], []
+    with torch.no_grad():
+        for it in range(3):
+            off.append(dgr._heavy_queue_off(key))
+            imgs.append(render(cam, pc, PIPE, bg, **PLAIN)["render"])
+            dgr._C.lib.msgs_forward_info(info)
+            assert int(info[1]) == 0
+    assert off == [False, True, True], off                             # (first call of a key: on; then the memory is 0)
+    assert all(torch.equal(imgs[0], im) for im in imgs[1:])
+    assert D_uncut > 0

@@ -19,7 +19,7 @@ st = dict(filter_small=ms, filter_large=ms, fade_size=fade)
 bg = torch.rand(3, generator=torch.Generator().manual_seed(seed))
 dL = scenes.grad_seed(W, H, seed % 97)
 lib = dgr._C.lib
-lib.msgs_set_blend_granularity(gran); lib.msgs_set_backward_generation(bwd_gen); lib.msgs_set_forward_variant(fwd_var)
+lib.msgs_set_blend_granularity(gran); lib.msgs_set_backward_generation(bwd_gen)
 out, pc, m2 = hip_render(sc, cam, st, bg, dL)
 ctx = out["render"].grad_fn
 call = ctx.call

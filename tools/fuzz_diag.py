@@ -21,10 +21,8 @@ from parity_utils import hip_render, small_scene  # noqa: E402
 def hip_forward(cfg, sc, cam, st, bg, dL, occlusion=True):
     import diff_gaussian_rasterization as dgr
     lib = dgr._C.lib
-    pg, pb, pf = lib.msgs_set_blend_granularity(cfg["gran"]), lib.msgs_set_backward_generation(cfg["bwd_gen"]), \
-        lib.msgs_set_forward_variant(cfg["fwd_var"])
+    pg, pb = lib.msgs_set_blend_granularity(cfg["gran"]), lib.msgs_set_backward_generation(cfg["bwd_gen"])
     po = lib.msgs_set_occlusion(1 if occlusion else 0)
-    ppol, dgr.occlusion_policy = dgr.occlusion_policy, "always"
     pchain = dgr.chain_reference_getters
     dgr.chain_reference_getters = bool(cfg["chain"])
     try:
@@ -38,9 +36,7 @@ def hip_forward(cfg, sc, cam, st, bg, dL, occlusion=True):
     finally:
         lib.msgs_set_blend_granularity(pg)
         lib.msgs_set_backward_generation(pb)
-        lib.msgs_set_forward_variant(pf)
         lib.msgs_set_occlusion(po)
-        dgr.occlusion_policy = ppol
         dgr.chain_reference_getters = pchain
 
 
@@ -70,7 +66,7 @@ def main():
 
     print("variant                           worst |HIP - oracle| on unflagged pixels   at (x, y)   radii equal")
     variants = [("as drawn", {})] + [(f"gran={g}", {"gran": g}) for g in (0, 1, 2)] + \
-               [(f"fwd_var={v}", {"fwd_var": v}) for v in (0, 1, 3, 4, 5, 6)] + [("occlusion off", {"_occ": False})]
+               [("occlusion off", {"_occ": False})]
     for name, kv in variants:
         c = dict(cfg, **{k: v for k, v in kv.items() if not k.startswith("_")})
         out, _, _ = hip_forward(c, sc, cam, st, bg, dL, occlusion=kv.get("_occ", True))

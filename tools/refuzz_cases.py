@@ -17,7 +17,7 @@ for c in cfgs:
         st = dict(filter_small=c["ms"], filter_large=c["ms"], fade_size=c["fade"])
         bg = torch.rand(3, generator=torch.Generator().manual_seed(c["seed"]))
         dL = scenes.grad_seed(c["W"], c["H"], c["seed"] % 97)
-        dgr._C.lib.msgs_set_blend_granularity(gran); dgr._C.lib.msgs_set_backward_generation(bwd_gen); dgr._C.lib.msgs_set_forward_variant(fwd_var)
+        dgr._C.lib.msgs_set_blend_granularity(gran); dgr._C.lib.msgs_set_backward_generation(bwd_gen)
         out, pc, m2 = hip_render(sc, cam, st, bg, dL)
         orc = oc.rasterize(pc.seen, cam, st, bg); og = oc.backward(orc, dL)
         try:
