@@ -529,6 +529,34 @@ def config_leg(name, scenes, dev, steps=20, warmup=3):
     return res
 
 
+def verification_mode_leg(scenes, dev, steps=5, warmup=2):
+    """What msgs_set_deterministic(1) costs: the C3 step through the literal verification kernels (ms-gs_amd/csrc/literal.hip)."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import PIPE, render
+    from synthetic_model import SyntheticGaussians
+    sc, cam, st = scenes.config("C3")
+    pc = SyntheticGaussians(sc, dev, requires_grad=True)
+    cam = cam.to(dev)
+    bg = torch.zeros(3, device=dev)
+    dL = scenes.grad_seed(cam.image_width, cam.image_height, 2).to(dev)
+
+    def step():
+        for p_ in pc.parameters():
+            p_.grad = None
+        render(cam, pc, PIPE, bg, **st)["render"].backward(dL)
+    prev = dgr.set_deterministic(True)
+    try:
+        med = period_median(step, steps, warmup, torch.cuda.synchronize)[0]
+    finally:
+        dgr.set_deterministic(prev)
+    del pc
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(med, 3),
+            "what": "C3 forward + backward in the verification mode (msgs_set_deterministic: the reference's blend loops restated "
+                    "literally, exp in double, double sums in a fixed order); against the float32 oracle evaluated the same way the "
+                    "forward is bit-identical and every gradient tensor within 3e-7 at C2 / C3 / C5 / C4 (tests/test_literal_gpu.py)"}
+
+
 def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, warmup, multi_view=True):
     import torch.nn.functional as F
     from gaussian_renderer import render
@@ -1241,6 +1269,10 @@ def main():
             pc = dL = call_out = None           # (the closures above keep the names alive: drop the tensors, not the names)
             gc.collect()
             torch.cuda.empty_cache()
+            try:
+                result["verification_mode"] = verification_mode_leg(scenes, dev)
+            except Exception as e:          # informational
+                result["verification_mode"] = {"error": repr(e)}
             for name in ("C2", "C5"):
                 try:
                     # (C2 is host-bound and a step takes 0.4 ms: 100 steps for a steadier median, still 50 ms)

@@ -228,7 +228,8 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
     uint32_t* heavy_count = occlusion ? (uint32_t*)(scratch + SL.heavy_count) : nullptr;
     uint32_t* heavy_blk = occlusion ? (uint32_t*)(scratch + SL.heavy_blk) : nullptr;
     tm.begin(MSGS_K_PREPROCESS);
-    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, heavy_list, heavy_count, heavy_blk));
+    // (verification mode: the kernel also leaves the raw conic and the effective opacity for the literal blend loops)
+    HIP_TRY(launch_preprocess(vp, *g, radii, pixel_sizes, geom, s, zj1, heavy_list, heavy_count, heavy_blk, g_deterministic.load() != 0));
     if (occlusion)      // (timed with K1: two launches that leave at once when the view has no cover candidates)
         HIP_TRY(launch_occlusion(vp, P, geom, heavy_list, heavy_count, heavy_blk, (OccCand*)(scratch + SL.occ_cand), s));
     tm.end(MSGS_K_PREPROCESS);
@@ -567,7 +568,8 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
     float* final_T = (float*)(image + IL.final_T);
     uint32_t* n_contrib = (uint32_t*)(image + IL.n_contrib);
     uint32_t* tile_last = (uint32_t*)(image + IL.tile_last);
-    const bool feedback = view->feedback_tag != 0 && fb_dev != nullptr && P > 0 && forward_uses_quadrant_kernel(num_tiles);
+    const bool literal = g_deterministic.load() != 0;
+    const bool feedback = view->feedback_tag != 0 && fb_dev != nullptr && P > 0 && forward_uses_quadrant_kernel(num_tiles) && !literal;
     unsigned long long* dtrav = feedback ? (unsigned long long*)(binning + BL.dtrav) : nullptr;
     const size_t clear_bytes = grad_records ? GRAD_REC_BYTES * (size_t)P : 0;
 
@@ -618,10 +620,16 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
         if ((rc = debug_sync(view, s))) return rc;
 
         tm.begin(MSGS_K_BLEND_FWD);
-        if (D == 0 && dtrav) HIP_TRY(launch_zero(dtrav, 8 * (size_t)DTRAV_SLOTS, s));      // (no emit ran: nobody cleared them)
-        const FwdSlabArgs fa{0, nullptr, nullptr, nullptr, dtrav};
-        HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth, final_T, n_contrib, tile_last,
-                                     grad_records, clear_bytes, s, dtrav ? &fa : nullptr));
+        if (literal) {          // verification mode: the reference's per-pixel loop restated literally (literal.hip)
+            if (grad_records && clear_bytes) HIP_TRY(launch_zero(grad_records, clear_bytes, s));
+            HIP_TRY(launch_blend_forward_literal(vp, geom, P, ids, ranges, out_color, out_acc_ps, out_depth, final_T, n_contrib,
+                                                 (uint32_t*)(image + IL.tile_order) + num_tiles, s));
+        } else {
+            if (D == 0 && dtrav) HIP_TRY(launch_zero(dtrav, 8 * (size_t)DTRAV_SLOTS, s));      // (no emit ran: nobody cleared them)
+            const FwdSlabArgs fa{0, nullptr, nullptr, nullptr, dtrav};
+            HIP_TRY(launch_blend_forward(vp, geom, ids, ranges, out_color, out_acc_ps, out_depth, final_T, n_contrib, tile_last,
+                                         grad_records, clear_bytes, s, dtrav ? &fa : nullptr));
+        }
     } else {
         // ---------------- slab A: the nearest ranks, up to slab_fraction * D instances ----------------
         const GeomLayout GL(P);
@@ -677,7 +685,7 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
                                      nullptr, 0, s, &fb));
         tm.end(MSGS_K_SLAB_B);
     }
-    if (backward_follows)  // give the backward's one-wave-per-tile kernel a heaviest-first launch order
+    if (backward_follows && !literal)  // give the backward's one-wave-per-tile kernel a heaviest-first launch order
         HIP_TRY(launch_tile_order(vp, tile_last, (uint32_t*)(image + IL.tile_order), s));
     if (feedback) {
         const GeomLayout GL(P);
@@ -741,7 +749,10 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     if ((rc = debug_sync(view, s))) return rc;
 
     tm.begin(MSGS_K_PREPROCESS_BWD);
-    HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s));
+    if (det)      // the nine TEXTBOOK sums per Gaussian ([P, 9] doubles) as they are
+        HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s, true));
+    else
+        HIP_TRY(launch_preprocess_backward(vp, *g, radii, geom, grad_rec, *grads, s));
     tm.end(MSGS_K_PREPROCESS_BWD);
     return debug_sync(view, s);
 }

@@ -778,37 +778,6 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 64-lane all-reduce of a double (deterministic mode only): the same butterfly as wave_allreduce_sum, every move on the two
-// dwords of the value
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = dpp_mov_u<CTRL>((uint32_t)u), hi = dpp_mov_u<CTRL>((uint32_t)(u >> 32));
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_allreduce_sum_f64(double v) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    v += dpp_mov_f64<0xB1>(v);            // xor 1
-    v += dpp_mov_f64<0x4E>(v);            // xor 2
-    v += dpp_mov_f64<0x124>(v);           // + quad (q-1)
-    v += dpp_mov_f64<0x128>(v);           // + quads (q-2, q-3): every lane = row sum
-    {
-        const uint64_t u = (uint64_t)__double_as_longlong(v);
-        const u2 lo = __builtin_amdgcn_permlane16_swap((uint32_t)u, (uint32_t)u, false, false);
-        const u2 hi = __builtin_amdgcn_permlane16_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
-        v = __longlong_as_double((long long)(((uint64_t)hi.x << 32) | lo.x)) +
-            __longlong_as_double((long long)(((uint64_t)hi.y << 32) | lo.y));
-    }
-    {
-        const uint64_t u = (uint64_t)__double_as_longlong(v);
-        const u2 lo = __builtin_amdgcn_permlane32_swap((uint32_t)u, (uint32_t)u, false, false);
-        const u2 hi = __builtin_amdgcn_permlane32_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
-        v = __longlong_as_double((long long)(((uint64_t)hi.x << 32) | lo.x)) +
-            __longlong_as_double((long long)(((uint64_t)hi.y << 32) | lo.y));
-    }
-    return v;
-}
-
 struct BwdQuad {
     float T, S, dL0, dL1, dL2;       // S: see blend_backward_kernel
     uint32_t last;
@@ -819,8 +788,7 @@ struct BwdQuad {
 // quadrant hit masks already removed the quadrants the record cannot touch)
 // (returns the lanes that contributed as a scalar mask: three ballots of direct comparisons and scalar ANDs — a ballot
 //  of a derived bool costs two VALU instructions, and the caller only needs "any lane?")
-template <class A>
-__device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSumsT<A>& v, const float4& r0, const float4& r1, float cb,
+__device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSums& v, const float4& r0, const float4& r1, float cb,
                                                   float bound, float dx, float dy, uint32_t pos0) {
     const PairEval ev = eval_pair(r0.z, r0.w, r1.x, r1.y, dx, dy);
     const float a_raw = __builtin_amdgcn_exp2f(ev.p);
@@ -840,20 +808,10 @@ __device__ __forceinline__ uint64_t bwd_quad_step(BwdQuad& s, BwdSumsT<A>& v, co
     const float dL_dalpha = sm * Tn;
     s.S = fmaf(alpha_m, sm, s.S);
     const float qq = a_m * dL_dalpha;                         // Q6: gradient passes the 0.99 clamp
-    if constexpr (sizeof(A) == 4) {
-        v.v0 = fmaf(qq, dx, v.v0); v.v1 = fmaf(qq, dy, v.v1);
-        v.v2 = fmaf(qq, ev.dxx, v.v2); v.v3 = fmaf(qq, ev.dxy, v.v3); v.v4 = fmaf(qq, ev.dyy, v.v4);
-        v.v5 += qq;
-        v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
-    } else {
-        // deterministic (verification) mode: the float32 per-pixel factors enter DOUBLE sums — the structure of the CPU
-        // oracle (float32 terms, double accumulators)
-        const double qd = (double)qq, dd = (double)dch;
-        v.v0 = fma(qd, (double)dx, v.v0); v.v1 = fma(qd, (double)dy, v.v1);
-        v.v2 = fma(qd, (double)ev.dxx, v.v2); v.v3 = fma(qd, (double)ev.dxy, v.v3); v.v4 = fma(qd, (double)ev.dyy, v.v4);
-        v.v5 += qd;
-        v.v6 = fma(dd, (double)s.dL0, v.v6); v.v7 = fma(dd, (double)s.dL1, v.v7); v.v8 = fma(dd, (double)s.dL2, v.v8);
-    }
+    v.v0 = fmaf(qq, dx, v.v0); v.v1 = fmaf(qq, dy, v.v1);
+    v.v2 = fmaf(qq, ev.dxx, v.v2); v.v3 = fmaf(qq, ev.dxy, v.v3); v.v4 = fmaf(qq, ev.dyy, v.v4);
+    v.v5 += qq;
+    v.v6 = fmaf(dch, s.dL0, v.v6); v.v7 = fmaf(dch, s.dL1, v.v7); v.v8 = fmaf(dch, s.dL2, v.v8);
     return validm;
 }
 
@@ -864,11 +822,10 @@ __device__ unsigned long long* g_tile_trace = nullptr;
 __global__ void trace_set_kernel(unsigned long long* p) { g_tile_trace = p; }
 #endif
 
-// DET = true (deterministic mode): instead of atomics, the nine sums of tile entry j (its position in the sorted instance
-// array) are STORED to inst_grad[j][0..8]; det_reduce_kernel then adds every Gaussian's entries in a fixed order.
 // COUNT = true (diagnostic replica, msgs_blend_lane_stats): nothing is reduced or written; grad_out receives four counters —
 // (tile, entry) visits, (quadrant, entry) evaluations (each 64 lanes), lanes that contributed, visits with a contribution.
-template <bool DET, bool COUNT = false>
+// (The verification mode — msgs_set_deterministic — does not run this kernel: literal.hip restates the reference's loop.)
+template <bool COUNT = false>
 __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, const GaussRec* __restrict__ rec,
                                                                  const uint32_t* __restrict__ ids,
                                                                  const uint2* __restrict__ ranges,
@@ -957,7 +914,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             const float2 bl = *reinterpret_cast<const float2*>(&s_bi[e]);      // {blue, sign_test_bound}: one 8-byte read
             const float cb = bl.x;
             const float dx = r0.x - bxf, dy = r0.y - byf;
-            BwdSumsT<typename std::conditional<DET, double, float>::type> v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            BwdSums v = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             uint64_t any = 0;
             if constexpr (COUNT) {
                 uint64_t m;
@@ -974,26 +931,11 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
             if (h2 & bit) any |= bwd_quad_step(q2, v, r0, r1, cb, bl.y, dx, dy - 8.0f, pos0);
             if (h3 & bit) any |= bwd_quad_step(q3, v, r0, r1, cb, bl.y, dx - 8.0f, dy - 8.0f, pos0);
             if (any == 0) continue;                        // no lane contributed: nothing to reduce
-            if constexpr (DET) {
-                // deterministic (verification) mode: double sums over the 256 pixels, reduced in double in a fixed tree,
-                // stored per tile entry; det_reduce_kernel adds a Gaussian's entries in double in ascending tile order
-                const double t0 = wave_allreduce_sum_f64(v.v0), t1 = wave_allreduce_sum_f64(v.v1),
-                             t2 = wave_allreduce_sum_f64(v.v2), t3 = wave_allreduce_sum_f64(v.v3),
-                             t4 = wave_allreduce_sum_f64(v.v4), t5 = wave_allreduce_sum_f64(v.v5),
-                             t6 = wave_allreduce_sum_f64(v.v6), t7 = wave_allreduce_sum_f64(v.v7),
-                             t8 = wave_allreduce_sum_f64(v.v8);
-                if (lane == 0) {
-                    double* idst = (double*)grad_out + ((size_t)range.x + pos0) * DET_INST_FLOATS;
-                    idst[0] = t0; idst[1] = t1; idst[2] = t2; idst[3] = t3; idst[4] = t4; idst[5] = t5; idst[6] = t6;
-                    idst[7] = t7; idst[8] = t8;
-                }
-                continue;
-            }
             // ---- one 64-lane reduction per (tile, Gaussian): rows by DPP (row_reduce_scatter9), then the four rows
             // through the LDS crossbar (ds_bpermute lane ^ 16, lane ^ 32: two adds on the VALU; v_permlane16/32_swap are
             // multi-cycle there).  Lanes 0,1,4,5,8,9,12,13 then hold components 0..7 and lane 2 component 8: one atomic
             // instruction; the record id is wave-uniform (scalar address arithmetic).
-            if constexpr (!DET) {
+            {
                 const float outv = cross_row_allreduce_bperm(row_reduce_scatter9(v), xrow16, xrow32);
                 // (record id through v_readlane of a register copy and a scalar-base atomic — no 64-bit VALU multiply-add —
                 //  were measured: no difference, 357..382 us for all four combinations)
@@ -1011,7 +953,7 @@ __global__ __launch_bounds__(64) void blend_backward_tile_kernel(ViewParams vp, 
         }
     }
 #if defined(MSGS_TRACE_TILES)
-    if (!DET && !COUNT && g_tile_trace && lane == 0) {
+    if (!COUNT && g_tile_trace && lane == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1282,7 +1224,7 @@ namespace {
 __global__ __launch_bounds__(256) void det_reduce_kernel(const uint32_t* __restrict__ gid_sorted,
                                                          const uint32_t* __restrict__ entry_of, int64_t D,
                                                          const double* __restrict__ inst_grad,
-                                                         grad_acc_t* __restrict__ grad_rec) {
+                                                         grad_acc_t* __restrict__ grad_rec, int rec_stride) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= D) return;
     const uint32_t g = gid_sorted[q];
@@ -1298,7 +1240,7 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const uint32_t* __restr
 #pragma unroll
         for (int c = 0; c < DET_INST_FLOATS; ++c) acc[c] += src[c];
     }
-    grad_acc_t* dst = grad_rec + (size_t)g * GRAD_REC_FLOATS;
+    grad_acc_t* dst = grad_rec + (size_t)g * rec_stride;
 #pragma unroll
     for (int c = 0; c < DET_INST_FLOATS; ++c) dst[c] = (grad_acc_t)acc[c];
 }
@@ -1327,19 +1269,21 @@ hipError_t launch_blend_backward_det(const ViewParams& vp, int P, const char* ge
     uint32_t* keys = (uint32_t*)(scratch + L.keys);
     uint32_t* keys_s = (uint32_t*)(scratch + L.keys_s);
     uint32_t* entry = (uint32_t*)(scratch + L.entry);
-    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom);
     hipError_t e = launch_zero(inst, sizeof(double) * DET_INST_FLOATS * (size_t)D, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp, rec, ids, ranges, final_T,
-                       n_contrib, dL_dcolor, inst, (const uint32_t*)nullptr);
+    // the reference's per-pixel backward restated literally (literal.hip): nine double sums per tile entry
+    e = launch_blend_backward_literal(vp, geom, P, ids, ranges, final_T, n_contrib, dL_dcolor, inst, s);
+    if (e != hipSuccess) return e;
     e = hipMemcpyAsync(keys, ids, 4 * (size_t)D, hipMemcpyDeviceToDevice, s);      // the sort clobbers its input
     if (e != hipSuccess) return e;
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < P) ++bits;
     e = radix_sort_pairs(keys, nullptr, keys_s, entry, D, 0, bits, scratch + L.sort, s);   // stable: entries ascending
     if (e != hipSuccess) return e;
+    // ... added per Gaussian in ascending tile order: [P, 9] packed doubles, the textbook sums the per-Gaussian backward takes
+    static_assert(sizeof(grad_acc_t) == 8, "the verification mode's sums are doubles");
     hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, keys_s, entry, D, inst,
-                       grad_rec);
+                       grad_rec, DET_INST_FLOATS);
     return hipGetLastError();
 }
 
@@ -1351,7 +1295,7 @@ hipError_t launch_blend_backward_lane_stats(const ViewParams& vp, const char* ge
     if (e != hipSuccess) return e;
     const int tiles = vp.gx * vp.gy;
     if (tiles)
-        hipLaunchKernelGGL((blend_backward_tile_kernel<false, true>), dim3(tiles), dim3(64), 0, s, vp,
+        hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(tiles), dim3(64), 0, s, vp,
                            reinterpret_cast<const GaussRec*>(geom), ids, ranges, final_T, n_contrib, (const float*)nullptr, (void*)out4,
                            (const uint32_t*)nullptr);
     return hipGetLastError();

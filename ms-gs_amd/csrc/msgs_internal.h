@@ -106,7 +106,7 @@ struct SlabHeader {
 static_assert(sizeof(SlabHeader) == 64, "SlabHeader layout");
 
 struct GeomLayout {
-    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, skey, slab_hdr, occ_hdr, occ_cut, offs_b, scan_b, total;
+    size_t rec, binrec, tiles, key, flags, weight, order, offs, nvalid, skey, slab_hdr, occ_hdr, occ_cut, offs_b, scan_b, litrec, total;
     __host__ __device__ explicit GeomLayout(int64_t P) {
         size_t o = 0;
         rec = o;    o = align256(o + sizeof(GaussRec) * P);
@@ -127,6 +127,7 @@ struct GeomLayout {
         occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth bucket per cover block (0xFFFF = open)
         offs_b = o; o = align256(o + 4 * P);        // slab B: per depth rank, instances in open tiles -> their exclusive scan
         scan_b = o; o = align256(o + 8 * (size_t)((P + SLAB_SCAN_CHUNK - 1) / SLAB_SCAN_CHUNK + 2));   // block totals of that scan
+        litrec = o; o = align256(o + 16 * P);       // verification mode (literal.hip): raw conic A, B, C and effective opacity
         total = o;
     }
 };
@@ -518,7 +519,8 @@ struct ZeroJob { uint32_t* p0; size_t n0; uint32_t* p1; size_t n1; };
 // instances (cover candidates of the occlusion cut-off) and their number
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
                              char* geom, hipStream_t s, ZeroJob zj = ZeroJob{nullptr, 0, nullptr, 0},
-                             uint32_t* heavy_list = nullptr, uint32_t* heavy_count = nullptr, uint32_t* heavy_blk = nullptr);
+                             uint32_t* heavy_list = nullptr, uint32_t* heavy_count = nullptr, uint32_t* heavy_blk = nullptr,
+                             bool write_litrec = false);     // verification mode: also GeomLayout::litrec (raw conic, opacity)
 // occlusion.hip: gather the candidates, accumulate the covers per block of tiles front to back, recount the Gaussians behind a
 // cut-off (tiles[] / key[] of `geom` are updated in place, before the depth sort)
 hipError_t launch_occlusion(const ViewParams& vp, int P, char* geom, const uint32_t* heavy_list, const uint32_t* heavy_count,
@@ -529,6 +531,13 @@ int occlusion_block_log2(int gx, int gy);  // log2(tiles per side of a cover blo
 hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians_t& g, const int32_t* radii,
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s, bool textbook = false);
+// literal.hip: the verification mode (msgs_set_deterministic) — the reference's blend loops restated literally
+hipError_t launch_blend_forward_literal(const ViewParams& vp, const char* geom, int P, const uint32_t* ids, const uint2* ranges,
+                                        float* out_color, float* out_ps, float* out_depth, float* final_T, uint32_t* n_contrib,
+                                        uint32_t* order_flag, hipStream_t s);
+hipError_t launch_blend_backward_literal(const ViewParams& vp, const char* geom, int P, const uint32_t* ids, const uint2* ranges,
+                                         const float* final_T, const uint32_t* n_contrib, const float* dL_dcolor, double* inst_grad,
+                                         hipStream_t s);
 hipError_t launch_sh_grad_from_views(int P, int n_views, int deg, const float* means3D, const float* campos,
                                      int64_t campos_stride, const float* drgb, int64_t drgb_stride, float scale,
                                      float* d_dc, float* d_rest, hipStream_t s);

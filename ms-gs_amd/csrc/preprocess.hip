@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                                                          char* __restrict__ geom, ZeroJob zj,
                                                          uint32_t* __restrict__ heavy_list,
                                                          uint32_t* __restrict__ heavy_count,
-                                                         uint32_t* __restrict__ heavy_blk) {
+                                                         uint32_t* __restrict__ heavy_blk, int write_litrec) {
     __shared__ float s_rows[4][64 * HALF_LDS];
     __shared__ uint8_t s_idx[4][64];
     __shared__ uint32_t s_heavy[4], s_hvw[4];
@@ -592,6 +592,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
                 count = (uint32_t)((maxx - minx) * (maxy - miny));
             }
         }
+        if (write_litrec)       // verification mode: what the literal blend loops read (literal.hip)
+            reinterpret_cast<float4*>(geom + L.litrec)[i] = make_float4(conA, conB, conC, o_eff);
         rec[i].r0 = make_float4(px, py, sA, sBh);
         rec[i].r1 = make_float4(sC, __log2f(o_eff), rgb[0], rgb[1]);
         rec[i].r2 = make_float4(rgb[2], t[2], out_psize, tau2);
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
 // the factors can overlap with K9 (msgs_grads_t::factors_ready).
 __global__ __launch_bounds__(256) void sh_factor_kernel(int P, const int32_t* __restrict__ radii,
                                                         const char* __restrict__ geom,
-                                                        const grad_acc_t* __restrict__ grad_rec,
+                                                        const grad_acc_t* __restrict__ grad_rec, int rec_stride,
                                                         float* __restrict__ dL_dcolors) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(256) void sh_factor_kernel(int P, const int32_t* __
     if (radii[i] > 0) {
         const GeomLayout L(P);
         const uint32_t fl = reinterpret_cast<const uint32_t*>(geom + L.flags)[i];
-        const grad_acc_t* gr = grad_rec + (size_t)i * GRAD_REC_FLOATS;
+        const grad_acc_t* gr = grad_rec + (size_t)i * rec_stride;       // (components 6..8 in both record layouts)
         c0 = (fl & 1u) ? 0.f : (float)gr[6];
         c1 = (fl & 2u) ? 0.f : (float)gr[7];
         c2 = (fl & 4u) ? 0.f : (float)gr[8];
@@ -1083,14 +1085,15 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 hipError_t launch_preprocess(const ViewParams& vp, const msgs_gaussians_t& g, int32_t* radii, float* pixel_sizes,
-                             char* geom, hipStream_t s, ZeroJob zj, uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* heavy_blk) {
+                             char* geom, hipStream_t s, ZeroJob zj, uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* heavy_blk,
+                             bool write_litrec) {
     if (g.P == 0) return hipSuccess;
     if (g.raw_params != 0 && g.shs == nullptr)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
-                           heavy_list, heavy_count, heavy_blk);
+                           heavy_list, heavy_count, heavy_blk, write_litrec ? 1 : 0);
     else
         hipLaunchKernelGGL(preprocess_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, pixel_sizes, geom, zj,
-                           heavy_list, heavy_count, heavy_blk);
+                           heavy_list, heavy_count, heavy_blk, write_litrec ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -1098,14 +1101,11 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
                                       const char* geom, const grad_acc_t* grad_rec, const msgs_grads_t& grads,
                                       hipStream_t s, bool textbook) {
     if (g.P == 0) return hipSuccess;
-    if (textbook) {
-        hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
-                           grad_rec, grads);
-        return hipGetLastError();
-    }
+    // textbook: grad_rec holds [P, 9] doubles — the TEXTBOOK 2-D gradients (msgs_backward_per_gaussian; the verification mode)
+    static_assert(sizeof(grad_acc_t) == 8, "the textbook sums are doubles");
     if (g.raw_params != 0 && grads.dL_dfeatures_dc == nullptr) {          // factored SH gradient: the factors first
         hipLaunchKernelGGL(sh_factor_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, g.P, radii, geom, grad_rec,
-                           grads.dL_dcolors);
+                           textbook ? 9 : GRAD_REC_FLOATS, grads.dL_dcolors);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (grads.factors_ready) {
@@ -1119,8 +1119,12 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
         hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)grads.wait_before_accumulate, 0);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
-                       grad_rec, grads);
+    if (textbook)
+        hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
+                           grad_rec, grads);
+    else
+        hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
+                           grad_rec, grads);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && grads.accumulated) e = hipEventRecord((hipEvent_t)grads.accumulated, s);
     return e;

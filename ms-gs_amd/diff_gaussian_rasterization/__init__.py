@@ -234,6 +234,7 @@ def _alloc_grad_records(ctx, P, dev):
     kernel is instruction-bound, the stores are free) — the backward then skips its fill launch.  Not in the verification
     mode, whose scratch is sized by the instance count."""
     ctx.grad_rec = None
+    ctx.det = bool(_C.lib.msgs_get_deterministic())
     # a backward can follow this forward (msgs_forward*: backward_follows — the tile launch order is prepared)
     ctx.backward_follows = bool(P > 0 and getattr(_caller, "grad_enabled", True) and any(ctx.needs_input_grad))
     if _forward_clear and ctx.backward_follows and not _C.lib.msgs_get_deterministic():
@@ -244,6 +245,9 @@ def _alloc_grad_records(ctx, P, dev):
 def _take_backward_scratch(ctx, P, D, dev):
     """(scratch, is_clear): the buffer the forward cleared, once; any later backward through the same graph
     (retain_graph) gets a fresh one that msgs_backward clears itself"""
+    if bool(_C.lib.msgs_get_deterministic()) != bool(getattr(ctx, "det", False)):
+        raise RuntimeError("diff_gaussian_rasterization: set_deterministic() changed between this forward and its backward (the "
+                           "verification mode's backward reads what its own forward left behind)")
     rec = getattr(ctx, "grad_rec", None)
     ctx.grad_rec = None
     if rec is not None and not _C.lib.msgs_get_deterministic():
@@ -252,9 +256,13 @@ def _take_backward_scratch(ctx, P, D, dev):
 
 
 def set_deterministic(on=True):
-    """Process-wide switch: the verification backward, reproducible by construction (exact in-tile double sums, per-entry
-    stores, stable grouping by Gaussian: DESIGN.md 4.2); about 1.4 ms slower at 1M Gaussians / 1080p.
-    Returns the previous setting.  The forward is always reproducible.  Also: MSGS_DETERMINISTIC=1 in the environment."""
+    """Process-wide switch: the VERIFICATION mode (ms-gs_amd/csrc/literal.hip).  Forward and backward blend loops
+    restate the reference's per-pixel arithmetic literally (float32, no FMA contraction, exp evaluated in double and rounded
+    once), the nine per-(pixel, Gaussian) products are summed in double in a fixed order (in-tile tree, per-entry stores, stable
+    grouping by Gaussian): bitwise reproducible by construction, and — against the CPU checker of the tests evaluated the same
+    way (exp in double) — every gradient tensor within 1e-4, the north star's sentence as written
+    (tests/test_literal_gpu.py).  Several times slower than the default path.  Must not change between a forward and its
+    backward.  Returns the previous setting.  Also: MSGS_DETERMINISTIC=1 in the environment."""
     return bool(_C.lib.msgs_set_deterministic(1 if on else 0))
 
 

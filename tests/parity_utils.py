@@ -44,18 +44,22 @@ def pixel_budget(name):
 # every pyramid level, five of seven elsewhere.  tests/test_k8_isolation_gpu.py shows by test where the listed residuals
 # come from: K8 + K9 fed the oracle's own sums agree with the oracle to ~1e-6, dL/dcov3D meets 1e-4 at C2 and C3, and the
 # printed amplification factors are what multiplies the blend backward's float32 rounding on these two tensors.
+# (The VERIFICATION mode — msgs_set_deterministic, literal.hip — carries no ceilings: tests/test_literal_gpu.py asserts 1e-4 flat
+#  on all seven tensors at every config, against the oracle evaluated the same way.  What follows is the DEFAULT mode, a different
+#  float32 evaluation of the same algorithm.)
 GRAD_CEILINGS = {
-    ("C2", False): {}, ("C2", True): {"scaling": 4e-4},
-    ("C3", False): {"scaling": 5e-4}, ("C3", True): {"rotation": 1.5e-4},
-    ("C3@k", False): {},
-    ("C5", False): {"scaling": 2.5e-4},
-    ("C4v0", False): {"scaling": 1.3e-4, "rotation": 2.2e-4}, ("C4v3", False): {"scaling": 1.5e-3, "rotation": 4e-4},
-    ("C4v3", True): {"scaling": 6e-4, "rotation": 3.5e-4}, ("C4v6", False): {"scaling": 1.4e-4},
+    "C2": {},
+    "C3": {"scaling": 5e-4},
+    "C3@k": {},
+    "C5": {"scaling": 2.5e-4},
+    "C4v0": {"scaling": 1.3e-4, "rotation": 2.2e-4}, "C4v3": {"scaling": 1.5e-3, "rotation": 4e-4},
+    "C4v6": {"scaling": 1.4e-4},
 }
 
 
 def grad_ceilings(config, deterministic=False):
-    return dict(GRAD_CEILINGS[(config, deterministic)])
+    assert not deterministic, "the verification mode has no ceilings (tests/test_literal_gpu.py)"
+    return dict(GRAD_CEILINGS[config])
 PIPE = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)   # = gaussian_renderer.PIPE
 
 

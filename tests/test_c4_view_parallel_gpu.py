@@ -39,7 +39,7 @@ def rccl_single_rank():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("v,det", [(0, False), (3, False), (3, True), (6, False)])
+@pytest.mark.parametrize("v,det", [(0, False), (3, False), (6, False)])      # (verification mode: tests/test_literal_gpu.py)
 def test_c4_ring_views_vs_oracle(c4, v, det):
     """full size: 1 M Gaussians in the ball of radius 4, camera v of 8 on the ring of radius 8, 1920x1080"""
     import diff_gaussian_rasterization as dgr
