@@ -529,6 +529,81 @@ def config_leg(name, scenes, dev, steps=20, warmup=3):
     return res
 
 
+def reference_schedule_leg(scenes, dev, iters=300, cams_per_level=25, p_change_every=50):
+    """The op under the reference's REAL call schedule (/root/reference/train.py:152-216,244-264), not a fixed view: the pyramid
+    level — a new W x H — is drawn whenever the camera stack runs empty (75 % level 0, otherwise the least-trained level, :152-194;
+    a stack of `cams_per_level` cameras here), and the model changes size every densification interval (clone / split / prune:
+    +-3 % of random rows every `p_change_every` iterations here, :253-264).  Per variant (reference API render(), raw-parameter
+    render_fused()): median, p99 and max period of an iteration (render + backward of a fixed dL/dimage; the iteration that
+    follows a model rebuild is not counted — the rebuild is host work of the harness), and how many forwards could NOT take the
+    speculative route (first visit of a view shape; afterwards the wrapper scales the last count of that shape by P)."""
+    import random as _random
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import PIPE, render, render_fused
+    from synthetic_model import SyntheticGaussians
+    sc0, _, st = scenes.config("C3")
+    levels = [(int(1920 / 2 ** k), int(1080 / 2 ** k)) for k in range(7)]
+    cams = [scenes.front_camera(w, h).to(dev) for w, h in levels]
+    dLs = [scenes.grad_seed(w, h, 40 + k).to(dev) for k, (w, h) in enumerate(levels)]
+    bg = torch.zeros(3, device=dev)
+    out = {"iterations": iters, "cameras_per_level_stack": cams_per_level, "model_size_change_every": p_change_every,
+           "what": "train.py's schedule on the C3 model: level drawn per camera stack (75 % level 0, else the least trained), "
+                   "P changed by +-3 % (random clone / prune) every 50 iterations; ms per iteration = render + backward"}
+    for name, fn in (("reference_api", render), ("fused", render_fused)):
+        rng = _random.Random(1234)
+        g = torch.Generator().manual_seed(99)
+        sc = sc0
+        pc = SyntheticGaussians(sc, dev, requires_grad=True)
+        trained = [0] * len(levels)
+        stack, lvl = 0, 0
+        before = dict(dgr.forward_stats)
+        ev, skip, switches, changes, sizes = [], set(), 0, 0, [sc.P]
+        settle_gc()
+        with quiet_gc():
+            for it in range(iters):
+                if it and it % p_change_every == 0:                 # densify / prune: a new model of a slightly different size
+                    P = sc.P
+                    Pn = int(P * (1.0 + (0.03 if rng.random() < 0.5 else -0.03)))
+                    idx = torch.randperm(P, generator=g)[:min(P, Pn)]
+                    if Pn > P:
+                        idx = torch.cat([idx, torch.randint(0, P, (Pn - P,), generator=g)])
+                    sc = sc.subset(idx)
+                    pc = SyntheticGaussians(sc, dev, requires_grad=True)
+                    torch.cuda.synchronize()
+                    skip.add(len(ev) - 1)                           # (the rebuild falls into the period that began with the last event)
+                    changes += 1
+                    sizes.append(sc.P)
+                if stack == 0:                                      # camera stack empty: draw the level (train.py:152-194)
+                    new = 0 if rng.random() < 0.75 else min(range(1, len(levels)), key=lambda k: (trained[k], k))
+                    switches += new != lvl
+                    lvl, stack = new, cams_per_level
+                stack -= 1
+                trained[lvl] += 1
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append(e)
+                for p_ in pc.parameters():
+                    p_.grad = None
+                fn(cams[lvl], pc, PIPE, bg, **st)["render"].backward(dLs[lvl])
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append(e)
+            torch.cuda.synchronize()
+        raw = [(ev[i].elapsed_time(ev[i + 1]), i) for i in range(iters) if i not in skip]
+        per = sorted(t for t, _ in raw)
+        slowest = sorted(raw, reverse=True)[:6]
+        after = dgr.forward_stats
+        out[name] = {"median_ms": round(per[len(per) // 2], 4), "p99_ms": round(per[int(0.99 * (len(per) - 1))], 4),
+                     "max_ms": round(per[-1], 4), "slowest_iterations": [[i, round(t, 3)] for t, i in slowest],
+                     "level_switches": switches, "model_size_changes": changes,
+                     "model_sizes": [sizes[0], min(sizes), max(sizes)], "iterations_per_level": trained,
+                     "forwards": after["forwards"] - before["forwards"],
+                     "non_speculative_forwards": after["non_speculative"] - before["non_speculative"]}
+        del pc
+        torch.cuda.empty_cache()
+    return out
+
+
 def verification_mode_leg(scenes, dev, steps=5, warmup=2):
     """What msgs_set_deterministic(1) costs: the C3 step through the literal verification kernels (ms-gs_amd/csrc/literal.hip)."""
     import diff_gaussian_rasterization as dgr
@@ -994,6 +1069,21 @@ def main():
                        "every rank), complete inside the step" if world > 1 else "")},
     }
 
+    if world == 1 and (P, W, H) == (1_000_000, 1920, 1080):
+        # what an N-rank run of the same line WOULD exchange per GPU and step (formula of view_parallel.FactoredGradExchange.bytes_per_step
+        # / the dense 59-float ring all-reduce), so that the driver's N = 1 record shows it; nothing is exchanged at N = 1
+        def _factored(n):       # all-gather of {dL/drgb [P,3] | camera centre + pad (4)} + ring all-reduce of the 11 non-SH floats
+            return 4 * ((n - 1) * (3 * P + 4) + 2 * (n - 1) * (11 * P) // n)
+
+        def _dense(n):          # ring all-reduce of all 59 gradient floats per Gaussian
+            return 4 * (2 * (n - 1) * (59 * P) // n)
+        result["config"]["exchange_if_view_parallel"] = {
+            "rccl_ranks": None, "backend": None,
+            "bytes_received_per_gpu_per_step": {str(n): {"factored": _factored(n), "dense_allreduce": _dense(n)} for n in (2, 4, 8)},
+            "what": "N = 1 runs no exchange.  At N ranks (python -m torch.distributed.run ... bench.py --gpus N) every step ends "
+                    "with view_parallel.FactoredGradExchange over RCCL: all-gather of the [P,3] dL/drgb factors, all-reduce "
+                    "(ncclAvg) of the 11 non-SH floats per Gaussian, SH rows rebuilt on every rank; the line then carries "
+                    "config.exchange, config.backend and config.rccl_ranks"}
     if world > 1:
         result["config"]["exchange"] = exchange_used
         # which communicator carried the exchange: "nccl" IS RCCL on ROCm; rccl_ranks = its world size (None on the gloo rehearsal)
@@ -1269,6 +1359,10 @@ def main():
             pc = dL = call_out = None           # (the closures above keep the names alive: drop the tensors, not the names)
             gc.collect()
             torch.cuda.empty_cache()
+            try:
+                result["reference_schedule"] = reference_schedule_leg(scenes, dev)
+            except Exception as e:          # informational
+                result["reference_schedule"] = {"error": repr(e)}
             try:
                 result["verification_mode"] = verification_mode_leg(scenes, dev)
             except Exception as e:          # informational

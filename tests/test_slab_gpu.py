@@ -262,7 +262,7 @@ def test_adaptive_policy_engages_on_a_view_that_terminates_early_and_not_otherwi
                     out = render(cam, pc, PIPE, bg, **PLAIN)
                     torch.cuda.synchronize()
                     imgs.append(out["render"])
-            st = dgr._fb_stats.get((0, sc.P, W, H, 0, 0))
+            st = dgr._fb_stats.get((0, W, H, 0, 0))
             print(f"[slab] adaptive: engages={engages} plan per call {active} stats {st}")
             assert all(torch.equal(imgs[0], im) for im in imgs[1:])
             assert st is not None and st["D"] >= dgr.SLAB_MIN_INSTANCES, st
