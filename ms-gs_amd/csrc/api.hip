@@ -237,28 +237,27 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
 
     // depth order of the Gaussians (not rendered -> key 0xFFFFFFFF -> sorted last, zero tiles); the sorted keys stay in geom:
     // the emit compares them with the tiles' cut-off keys
-    tm.begin(MSGS_K_DEPTH_SORT);
-    HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(geom + GL.skey),
-                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed,
-                             (uint32_t*)(geom + GL.nvalid)));
-    tm.end(MSGS_K_DEPTH_SORT);
-    if ((rc = debug_sync(view, s))) return rc;
-
     if (!blocking_sync()) sb.ensure();
     const bool polled = !blocking_sync() && sb.host != nullptr;
     const uint64_t ticket = ++sb.ticket;
     uint64_t* total_dev = (uint64_t*)(scratch + SL.total_out);
     uint64_t* status_dev = total_dev + 2;
     uint32_t* clamped_dev = (uint32_t*)(total_dev + 5);       // min(D, capacity) for a speculative stage 2
+    // the speculative stage 2's queue of heavy Gaussians starts empty (binning.hip): cleared by whoever publishes the count
+    uint32_t* heavy_q_word = spec ? (uint32_t*)((char*)spec->scratch2 + Stage2Scratch(spec->capacity).heavy_q) : nullptr;
 
+    tm.begin(MSGS_K_DEPTH_SORT);
+    HIP_TRY(radix_sort_pairs((uint32_t*)(geom + GL.key), nullptr, (uint32_t*)(geom + GL.skey),
+                             (uint32_t*)(geom + GL.order), P, 0, 32, scratch + SL.sort, s, sort1_prezeroed,
+                             (uint32_t*)(geom + GL.nvalid)));
+    tm.end(MSGS_K_DEPTH_SORT);
+    if ((rc = debug_sync(view, s))) return rc;
     tm.begin(MSGS_K_SCAN);
     HIP_TRY(exclusive_scan_u32((const uint32_t*)(geom + GL.tiles), (const uint32_t*)(geom + GL.order),
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
                                status_dev, polled ? sb.dev : nullptr, ticket,
                                (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
-                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr),
-                               // the speculative stage 2's queue of heavy Gaussians starts empty (binning.hip)
-                               spec ? (uint32_t*)((char*)spec->scratch2 + Stage2Scratch(spec->capacity).heavy_q) : nullptr));
+                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr), heavy_q_word));
     tm.end(MSGS_K_SCAN);
     pend.active = true;
     pend.polled = polled;

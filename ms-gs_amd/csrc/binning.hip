@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void slab_split_kernel(int P, char* __restrict
         hdr->DB = 0u;
         hdr->active = 1u;
         hdr->n_open = 0u;
+        hdr->pad0 = 0u;               // (overflow flag: a speculative stage 2 on buffers the view outgrew may have raised it)
         hdr->total_b = 0ull;
     }
 }

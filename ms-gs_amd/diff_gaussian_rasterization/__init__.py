@@ -312,7 +312,10 @@ def _instance_guess(key):
     if v is None:
         return None
     D, P_ref = v
-    return int(D * (key[1] / max(P_ref, 1))) + 1
+    ratio = key[1] / max(P_ref, 1)
+    if not 0.8 <= ratio <= 1.25:        # another model altogether (D does not scale with P across scenes): no guess
+        return None
+    return int(D * ratio) + 1
 
 
 def _note_instances(key, D, guess):
@@ -404,7 +407,8 @@ def _note_info(key):
             if info[5] >= 0:                            # that frame ran in slab mode: did it pay?
                 st["n_open"], st["DA"], st["DB"] = int(info[5]), int(info[6]), int(info[7])
                 if info[7] < 0:
-                    raise RuntimeError("diff_gaussian_rasterization: slab B outgrew its buffers (SlabHeader overflow flag)")
+                    raise RuntimeError(f"diff_gaussian_rasterization: slab B outgrew its buffers (SlabHeader overflow flag) "
+                                       f"[view {k}: D {int(info[3])}, D_trav {int(info[4])}, open tiles {int(info[5])}, slab A {int(info[6])}]")
                 if int(info[6]) + int(info[7]) > 0.7 * max(int(info[3]), 1):
                     st["backoff"] = SLAB_BACKOFF
     _occ_hot[key] = HEAVY_QUEUE_MEMORY if info[1] else max(_occ_hot.get(key, 1) - 1, 0)

@@ -61,3 +61,4 @@ def test_nothing_rendered_with_a_stale_guess():
     assert torch.equal(out["render"], bg.cuda().view(3, 1, 1).expand(3, H, W))
     out["render"].sum().backward()
     assert all(float(getattr(pc, n).grad.abs().max()) == 0.0 for n in LEAVES)
+
