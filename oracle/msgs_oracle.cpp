@@ -132,6 +132,18 @@ static inline real oracle_exp(real p) {
     return std::exp(p);
 }
 
+#if !defined(MSGS_ORACLE_F64)
+// introspection for tests/test_oracle_cpu.py: the two decision windows for a conic (A, B, C), its conditioning, an opacity and a
+// pixel offset — so that a test can bound them on well-conditioned footprints and they cannot grow silently
+extern "C" void msgs_oracle_windows(float A, float B, float Cc, float con_cond, float opacity, float dx, float dy, float* out2) {
+    Geom ge{};
+    ge.con[0] = A; ge.con[1] = B; ge.con[2] = Cc; ge.con_cond = con_cond; ge.opacity = opacity;
+    const real power = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+    out2[0] = alpha_window(ge, dx, dy, power);
+    out2[1] = power_sign_window(ge, dx, dy);
+}
+#endif
+
 struct msgs_oracle_state {
     int P = 0, W = 0, H = 0, gx = 0, gy = 0;
     std::vector<Geom> geom;

@@ -96,3 +96,58 @@ def test_a_giant_centred_a_hair_from_a_pixel_centre_is_blended_there():
     d = (out["render"].detach().cpu() - orc.color).abs()
     assert d[:, 226, 158].max().item() < 1e-5, d[:, 226, 158]
     assert d.max().item() < 1e-5, d.max().item()
+
+
+def test_a_genuinely_indefinite_conic_is_still_skipped_where_its_exponent_is_positive():
+    """The other half of Q11 (round-5 advisor finding): the sign-test bound sits two to four ulps ABOVE log2(opacity) so that
+    roundings of the exponent chain never skip an entry — but an exponent that is positive for real, the reference's
+    `if (power > 0) continue` on an INDEFINITE conic (a precomputed 3-D covariance that is not positive semi-definite:
+    cov2D = [[a, 2a], [2a, a]], det < 0), must still skip.  Such a footprint blends along its diagonal ridge (dx dy > 0, where the
+    cross term wins and the exponent is negative) and nowhere else.  HIP against the oracle, which implements the literal rule:
+    the same image to 1e-5 everywhere, the ridge is drawn, the off-diagonal pixels next to the centre keep the background."""
+    import math
+    import scenes
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import oracle_ctypes as oc
+    W, H = 256, 192
+    cam = scenes.front_camera(W, H)
+    sc = scenes.frustum_scene(64, W, H, seed=3, sh_degree=0, scale_k=0.004 * 1920.0 / W * 0.3)
+    P = sc.P
+    z, f = 2.0, 1000.0 * W / 1920.0
+    # four indefinite Gaussians on the optical axis region: Sigma_xx = Sigma_yy = s^2, Sigma_xy = 2 s^2 (s = 6 px at this depth)
+    n = 4
+    s2 = (6.0 * z / f) ** 2
+    cov = torch.zeros(P, 6)
+    # (the other Gaussians: an ordinary covariance from their scales / rotations)
+    from oracle import torch_oracle as to
+    cov[:] = to.cov3d_from_scale_rot(sc.scales.double(), sc.rotations.double(), 1.0).float()
+    centres = torch.tensor([[0.0, 0.0], [40.0, 25.0], [-50.0, -30.0], [60.0, -40.0]])
+    for k in range(n):
+        sc.means3D[k] = torch.tensor([centres[k, 0] * z / f, centres[k, 1] * z / f, z])
+        cov[k] = torch.tensor([s2, 2.0 * s2, 0.0, s2, 0.0, 1e-6])          # xx, xy, xz, yy, yz, zz
+        sc.opacities[k, 0] = 0.9
+    col = torch.rand(P, 3, generator=torch.Generator().manual_seed(5))
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    st = dict(filter_small=False, filter_large=False, fade_size=1.0)
+    dev = "cuda"
+    camd = cam.to(dev)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                                       bg=bg.to(dev), scale_modifier=1.0, viewmatrix=camd.world_view_transform,
+                                       projmatrix=camd.full_proj_transform, sh_degree=0, campos=camd.camera_center,
+                                       prefiltered=False, debug=False, **st)
+    # only the four indefinite ones are opaque enough to matter at their own centres: render them alone as well
+    keep = torch.arange(n)
+    with torch.no_grad():
+        img, _, _, radii, _ = GaussianRasterizer(rs)(means3D=sc.means3D[keep].to(dev), means2D=torch.zeros(n, 3, device=dev),
+                                                     opacities=sc.opacities[keep].to(dev), colors_precomp=col[keep].to(dev),
+                                                     cov3D_precomp=cov[keep].to(dev))
+    sub = sc.subset(keep)
+    orc = oc.rasterize(sub, cam, st, bg, use_cov_precomp=True, cov3D_precomp=cov[keep], use_colors_precomp=True, colors_precomp=col[keep])
+    d = (img.cpu() - orc.color).abs()
+    assert torch.equal(radii.cpu(), orc.radii) and (radii > 0).all()
+    assert d.max().item() < 1e-5, d.max().item()
+    cx, cy = int(W / 2), int(H / 2)                       # Gaussian 0 sits at the image centre (pixel centre convention: +-0.5)
+    ridge = img[:, cy + 4, cx + 4].sum().item()           # dx dy > 0: exponent negative, blended
+    off = img[:, cy - 4, cx + 4].sum().item()             # dx dy < 0: exponent +3 |A| r^2 > 0, skipped by the reference's rule
+    assert ridge > 0.05 and off == 0.0, (ridge, off)

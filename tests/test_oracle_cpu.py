@@ -461,3 +461,33 @@ def test_oracle_error_conventions():
     with pytest.raises(RuntimeError):          # both colour inputs
         oc.rasterize(sc, cam, ST0, torch.zeros(3), use_colors_precomp=False, colors_precomp=None,
                      use_cov_precomp=True, cov3D_precomp=None)
+
+
+def test_decision_windows_stay_tight_on_well_conditioned_footprints():
+    """Round-5 advisor finding: the oracle's two float32-uncertainty windows (alpha at 1/255: alpha_window; sign of the exponent:
+    power_sign_window, oracle/msgs_oracle.cpp) were widened in the round in which the kernels' sign test was repaired.  They are
+    error models, not tuning knobs: on a ROUND, well-conditioned footprint they must stay at the float32 rounding level — alpha
+    within 3e-5 relative of 1/255 anywhere inside 3.3 sigma, the exponent's sign within 1e-6 (times |log2 opacity|) — and grow
+    only with the cancellation M and the conditioning of the conic.  A change that widens them silently fails here."""
+    import ctypes as C
+    from oracle import oracle_ctypes as oc
+    L = oc.lib()
+    L.msgs_oracle_windows.restype = None
+    L.msgs_oracle_windows.argtypes = [C.c_float] * 7 + [C.POINTER(C.c_float)]
+    out = (C.c_float * 2)()
+    worst_a, worst_p = 0.0, 0.0
+    for sigma in (0.8, 2.0, 7.0, 40.0, 300.0):
+        A = Cc = 1.0 / (sigma * sigma)
+        for o in (0.99, 0.5, 0.05, 0.005):
+            for r in (0.0, 0.5, 1.0, 2.0, 3.0, 3.3):
+                for ang in (0.0, 0.7, 1.9):
+                    import math
+                    dx, dy = r * sigma * math.cos(ang), r * sigma * math.sin(ang)
+                    L.msgs_oracle_windows(A, 0.0, Cc, 1.0, o, dx, dy, out)
+                    worst_a = max(worst_a, out[0])
+                    worst_p = max(worst_p, out[1] / max(1.0, abs(math.log2(o))))
+    assert worst_a <= 3e-5, worst_a                    # 2e-5 + 3 x 2^-24 x (M + |power|), M = |power| <= 5.5 here
+    assert worst_p <= 1.4e-6, worst_p                  # 3 x 2^-24 x M + 2^-21 ln 2 per unit of |log2 opacity|
+    # ... and they DO open up where the float32 evaluation is uncertain: a needle of aspect 25 evaluated along its long axis, far out
+    L.msgs_oracle_windows(1.0 / (50.0 * 50.0), 0.0, 1.0 / (2.0 * 2.0), 600.0, 0.9, 150.0, 0.3, out)
+    assert 3e-5 < out[0] <= 0.1
