@@ -647,7 +647,15 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
 
     model = SyntheticGaussians(scene, dev)
     opt = FusedAdam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
-    out["ms_per_iteration"] = round(timed(lambda: fused_train_iteration(model, opt, cam, gt, PIPE, bg, **settings)), 4)
+    out["ms_per_iteration_optimizer_as_its_own_launch"] = round(timed(lambda: fused_train_iteration(model, opt, cam, gt, PIPE, bg, **settings)), 4)
+    del model, opt
+    # the same iteration with the Adam step taken INSIDE the per-Gaussian backward kernel (msgs_adam_in_backward_t): the
+    # 236 B of gradient per Gaussian are neither written nor read back; parameters and moments bit-identical
+    # (tests/test_train_step_gpu.py)
+    model = SyntheticGaussians(scene, dev)
+    opt = FusedAdam(model.training_setup(7, scene.target_reso_lvl), lr=0.0, eps=1e-15)
+    out["ms_per_iteration"] = round(timed(lambda: fused_train_iteration(model, opt, cam, gt, PIPE, bg, step_in_backward=True,
+                                                                        **settings)), 4)
     del model, opt
 
     model = SyntheticGaussians(scene, dev)
@@ -693,7 +701,9 @@ def train_iteration_timing(scenes, scene, cam, bg, settings, W, H, dev, steps, w
     except Exception as e:      # informational
         out["ms_per_view_8_views_per_optimizer_step"] = repr(e)
     out["note"] = ("C3 scene, fixed U(0,1) target, lambda_dssim 0.2, level 0, statistics on; informational; every figure is the "
-                   "median period of the timed iterations (period_median)")
+                   "median period of the timed iterations (period_median); ms_per_iteration = train_step.fused_train_iteration("
+                   "step_in_backward=True): render_fused + L1/SSIM loss + backward with the Adam step inside its per-Gaussian "
+                   "kernel + statistics")
     return out
 
 

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MSGS_ABI_VERSION 10
+#define MSGS_ABI_VERSION 11
 
 #define MSGS_OK 0
 #define MSGS_ERR_INVALID_ARG (-1)  /* NULL / inconsistent pointers (both or neither of shs|colors, ...) */
@@ -144,6 +144,28 @@ typedef struct msgs_gaussians {
     const float* rotations_raw;    /* [P,4]    mode 2 only: the un-normalised quaternions (gaussian_model.py:58)  */
 } msgs_gaussians_t;
 
+/* Optimizer step INSIDE the per-Gaussian backward (msgs_grads_t::adam_in_backward; ABI 11).  The reference's iteration is
+ * loss.backward() -> optimizer.step() (/root/reference/train.py:216, :416-418) with torch.optim.Adam(lr = 0.0, eps = 1e-15) over
+ * the leaf tensors (/root/reference/scene/gaussian_model.py:235-248): backward writes 59 gradient floats per Gaussian (236 B at
+ * SH degree 3, zeros for Gaussians the view did not render) and the optimizer reads them back.  With this struct the kernel that
+ * FORMS the raw-parameter gradients applies the Adam update to the parameter and its two moments on the spot — same arithmetic,
+ * term by term, as msgs_adam_step (bit-identical parameters and moments) — and the gradient tensors are neither written nor
+ * read.  Raw mode 1 only (the gradients must be those of the leaves), scales + rotations and SH given as features_dc /
+ * features_rest with sh_coeffs == 16, no accumulate, no factored SH gradient.  The parameters are the tensors of
+ * msgs_gaussians_t (means3D, features_dc, features_rest, opacities, scales, rotations — written through their const pointers),
+ * every row is updated (a Gaussian that was not rendered has gradient zero: its moments decay and it moves, as under
+ * torch.optim.Adam with dense zero gradients).  All 18 tensors 16-byte aligned.  dL_dmeans2D is still stored. */
+typedef struct msgs_adam_moments {
+    float* exp_avg;            /* same shape as the parameter                                        */
+    float* exp_avg_sq;
+    double lr;                 /* this tensor's learning rate (param_group["lr"])                    */
+} msgs_adam_moments_t;
+typedef struct msgs_adam_in_backward {
+    int64_t step;              /* the step being taken, >= 1 (bias corrections 1 - beta^step)        */
+    double beta1, beta2, eps;
+    msgs_adam_moments_t t[6];  /* means3D, features_dc, features_rest, opacities, scales, rotations  */
+} msgs_adam_in_backward_t;
+
 /* Gradient outputs of msgs_backward.  Every non-NULL buffer is fully written (zeros for
  * Gaussians that were not rendered), so the caller may pass uninitialised memory. */
 typedef struct msgs_grads {
@@ -175,6 +197,9 @@ typedef struct msgs_grads {
     void* wait_before_accumulate; /* optional hipEvent_t: the per-Gaussian kernel waits for it — the `accumulated` event of the
                                 * previous view into the same tensors when that view ran on ANOTHER stream */
     void* accumulated;         /* optional hipEvent_t recorded behind the per-Gaussian kernel */
+    const msgs_adam_in_backward_t* adam_in_backward;   /* NULL (default) or the optimizer step to take inside the per-Gaussian
+                                * kernel (above): dL_dmeans3D, dL_dfeatures_*, dL_dopacities, dL_dscales, dL_drotations are then
+                                * ignored and may be NULL */
 } msgs_grads_t;
 
 /* Optional per-kernel timing (bench.py's roofline leg).  The caller owns the events; the library

@@ -716,7 +716,21 @@ int msgs_backward(const msgs_view_t* view, const msgs_gaussians_t* g, const int3
     if (g->shs && !g->raw_params && !grads->dL_dshs) return MSGS_ERR_INVALID_ARG;
     // raw modes: either both SH gradient tensors, or neither plus dL_dcolors (factored SH gradient, msgs.h)
     if (g->raw_params && (!grads->dL_dfeatures_dc != !grads->dL_dfeatures_rest)) return MSGS_ERR_INVALID_ARG;
-    if (g->raw_params && !grads->dL_dfeatures_dc && !grads->dL_dcolors) return MSGS_ERR_INVALID_ARG;
+    if (g->raw_params && !grads->dL_dfeatures_dc && !grads->dL_dcolors && !grads->adam_in_backward) return MSGS_ERR_INVALID_ARG;
+    if (const msgs_adam_in_backward_t* ad = grads->adam_in_backward) {
+        // the optimizer step inside the per-Gaussian kernel (msgs.h): gradients of the LEAVES, on the staged SH rows, one view
+        if (g->raw_params != 1 || !g->features_dc || !g->features_rest || g->shs || g->colors_precomp || g->cov3D_precomp ||
+            !g->scales || !g->rotations || view->sh_coeffs != 16 || grads->accumulate || grads->wait_before_accumulate ||
+            ad->step < 1)
+            return MSGS_ERR_INVALID_ARG;
+        uintptr_t bits = (uintptr_t)g->means3D | (uintptr_t)g->features_dc | (uintptr_t)g->features_rest |
+                         (uintptr_t)g->opacities | (uintptr_t)g->scales | (uintptr_t)g->rotations;
+        for (int t = 0; t < 6; ++t) {
+            if (!ad->t[t].exp_avg || !ad->t[t].exp_avg_sq) return MSGS_ERR_INVALID_ARG;
+            bits |= (uintptr_t)ad->t[t].exp_avg | (uintptr_t)ad->t[t].exp_avg_sq;
+        }
+        if (bits & 15) return MSGS_ERR_INVALID_ARG;
+    }
     // accumulate mode is implemented on the staged SH rows (K = 16) and not for the factored SH gradient
     if (grads->accumulate && ((g->shs && !g->raw_params && view->sh_coeffs != 16) ||
                               (g->raw_params && !grads->dL_dfeatures_dc)))
@@ -761,7 +775,7 @@ int msgs_backward_per_gaussian(const msgs_view_t* view, const msgs_gaussians_t* 
                                void* stream) {
     int rc = check_inputs(view, g);
     if (rc) return rc;
-    if (!grads || g->raw_params) return MSGS_ERR_INVALID_ARG;
+    if (!grads || g->raw_params || grads->adam_in_backward) return MSGS_ERR_INVALID_ARG;
     // the textbook branch of the per-Gaussian kernel neither waits for `wait_before_accumulate` nor records `accumulated`:
     // accumulation across views is msgs_backward's contract only
     if (grads->accumulate || grads->wait_before_accumulate || grads->accumulated) return MSGS_ERR_INVALID_ARG;

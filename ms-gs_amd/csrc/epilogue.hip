@@ -37,17 +37,8 @@ struct AdamTable {
     uint32_t first_block[MSGS_ADAM_MAX_TENSORS + 1];
     float neg_step_size[MSGS_ADAM_MAX_TENSORS];     // -lr / bias_correction1, rounded from double like torch's scalar
     int n;
-    float w1;            // 1 - beta1
-    float beta2, w2;     // beta2, 1 - beta2
-    float bc2_sqrt, eps;
+    AdamScalars s;                                  // (adam_update: msgs_internal.h — shared with the per-Gaussian backward)
 };
-
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float nss, const AdamTable& a) {
-    m = __fmaf_rn(a.w1, g - m, m);
-    v = __fmaf_rn(a.w2 * g, g, v * a.beta2);
-    const float denom = __fsqrt_rn(v) / a.bc2_sqrt + a.eps;
-    p = p + (nss * m) / denom;
-}
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTable a) {
     int ti = 0;
@@ -72,10 +63,10 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTabl
         }
 #pragma unroll
         for (int it = 0; it < ADAM_ITERS; ++it) {
-            adam_update(p[it].x, g[it].x, m[it].x, v[it].x, nss, a);
-            adam_update(p[it].y, g[it].y, m[it].y, v[it].y, nss, a);
-            adam_update(p[it].z, g[it].z, m[it].z, v[it].z, nss, a);
-            adam_update(p[it].w, g[it].w, m[it].w, v[it].w, nss, a);
+            adam_update(p[it].x, g[it].x, m[it].x, v[it].x, nss, a.s);
+            adam_update(p[it].y, g[it].y, m[it].y, v[it].y, nss, a.s);
+            adam_update(p[it].z, g[it].z, m[it].z, v[it].z, nss, a.s);
+            adam_update(p[it].w, g[it].w, m[it].w, v[it].w, nss, a.s);
             const int64_t i = base + (int64_t)(it * ADAM_THREADS + threadIdx.x) * ADAM_VEC;
             *reinterpret_cast<float4*>(P + i) = p[it];
             *reinterpret_cast<float4*>(M + i) = m[it];
@@ -87,7 +78,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTabl
         const int64_t i = base + k;
         if (i >= T.n) break;
         float p = P[i], m = M[i], v = V[i];
-        adam_update(p, G[i], m, v, nss, a);
+        adam_update(p, G[i], m, v, nss, a.s);
         P[i] = p; M[i] = m; V[i] = v;
     }
 }
@@ -97,8 +88,6 @@ hipError_t launch_adam(const msgs_adam_tensor_t* tensors, int n, int64_t step, d
     AdamTable a{};
     a.n = n;
     uint32_t blocks = 0;
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
     for (int k = 0; k < n; ++k) {
         a.t[k] = AdamSlot{tensors[k].param, tensors[k].grad, tensors[k].exp_avg, tensors[k].exp_avg_sq, tensors[k].n, 0};
         const uintptr_t bits = (uintptr_t)tensors[k].param | (uintptr_t)tensors[k].grad | (uintptr_t)tensors[k].exp_avg |
@@ -106,14 +95,10 @@ hipError_t launch_adam(const msgs_adam_tensor_t* tensors, int n, int64_t step, d
         a.t[k].vec_ok = (bits & 15) == 0;
         a.first_block[k] = blocks;
         blocks += (uint32_t)((tensors[k].n + ADAM_CHUNK - 1) / ADAM_CHUNK);
-        a.neg_step_size[k] = (float)(-(tensors[k].lr / bc1));
+        a.neg_step_size[k] = adam_neg_step_size(tensors[k].lr, step, beta1);
     }
     for (int k = n; k <= MSGS_ADAM_MAX_TENSORS; ++k) a.first_block[k] = blocks;
-    a.w1 = (float)(1.0 - beta1);
-    a.beta2 = (float)beta2;
-    a.w2 = (float)(1.0 - beta2);
-    a.bc2_sqrt = (float)sqrt(bc2);
-    a.eps = (float)eps;
+    a.s = adam_scalars(step, beta1, beta2, eps);
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();

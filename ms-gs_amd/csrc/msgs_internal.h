@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include "../../include/msgs.h"
 
 namespace msgs {
@@ -297,7 +298,48 @@ struct ImageLayout {
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
+// One Adam step of ONE float, term by term torch.optim.Adam's single-tensor formulation (torch/optim/adam.py,
+// _single_tensor_adam; amsgrad = False, weight_decay = 0, maximize = False) with the roundings of the ATen kernels:
+//     m <- fma(1 - beta1, g - m, m)                      (Tensor.lerp_, weight < 0.5 branch)
+//     v <- fma((1 - beta2) * g, g, v * beta2)            (mul_ then addcmul_)
+//     p <- p + ((-lr / (1 - beta1^t)) * m) / (sqrt(v) / sqrt(1 - beta2^t) + eps)      (addcdiv_)
+// Shared by the multi-tensor optimizer kernel (epilogue.hip) and the per-Gaussian backward that steps on the spot
+// (preprocess.hip, msgs_adam_in_backward_t): the two give the same bits.
+struct AdamScalars {
+    float w1;            // 1 - beta1
+    float beta2, w2;     // beta2, 1 - beta2
+    float bc2_sqrt, eps;
+};
+inline AdamScalars adam_scalars(int64_t step, double beta1, double beta2, double eps) {
+    AdamScalars a;
+    a.w1 = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    a.eps = (float)eps;
+    return a;
+}
+// -lr / bias_correction1, rounded from double like torch's Python scalar
+inline float adam_neg_step_size(double lr, int64_t step, double beta1) { return (float)(-(lr / (1.0 - pow(beta1, (double)step)))); }
+
+// the optimizer step the per-Gaussian backward takes itself (msgs_grads_t::adam_in_backward): kernel-side table, tensors in the
+// order means3D, features_dc, features_rest, opacities, scales, rotations
+struct AdamInBackward {
+    float* m[6];
+    float* v[6];
+    float nss[6];
+    AdamScalars a;
+};
+
 #if defined(__HIPCC__)
+
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float nss, const AdamScalars& a) {
+#pragma clang fp contract(off)
+    m = __fmaf_rn(a.w1, g - m, m);
+    v = __fmaf_rn(a.w2 * g, g, v * a.beta2);
+    const float denom = __fsqrt_rn(v) / a.bc2_sqrt + a.eps;
+    p = p + (nss * m) / denom;
+}
 
 // Exact-culling test in the log2 domain.  The record stores the NEGATIVE-definite form
 //   f(d) = A dx^2 + 2 Bh dx dy + C dy^2  = log2 G(d)     (A, Bh, C = -1/2 log2(e) x conic)

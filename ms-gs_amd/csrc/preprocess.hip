@@ -412,6 +412,61 @@ __device__ __forceinline__ void coop_store_split_rows(const float* lds_rows, flo
     }
 }
 
+// msgs_adam_in_backward_t: the same walk over the run's dc / rest rows, but instead of storing the gradient rows the Adam step
+// is taken on the spot — parameter and both moments of EVERY row of the run are read, updated with the row's gradient (LDS; zero
+// for rows not in `live` and for coefficients beyond the active degree: exactly the values coop_store_split_rows would have
+// stored for the optimizer kernel to read) and written back.  The run's rest rows are one contiguous, 16-byte aligned block
+// (32 rows x 180 B from a multiple of 32 rows; the tensors' bases are aligned, msgs_backward checks).
+__device__ __forceinline__ void coop_adam_split_rows(const float* lds_rows, float* p_dc, float* p_rest, const AdamInBackward& ad,
+                                                     int i, bool in_range, int wave_first, int nrow, uint64_t live,
+                                                     int nfloat, int lane, int lrow) {
+    if (in_range) {
+        const bool on = (live >> lrow) & 1ull;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t at = 3 * (size_t)i + c;
+            float p = p_dc[at], m = ad.m[1][at], v = ad.v[1][at];
+            adam_update(p, on ? lds_rows[lrow * ROW_LDS + c] : 0.f, m, v, ad.nss[1], ad.a);
+            p_dc[at] = p; ad.m[1][at] = m; ad.v[1][at] = v;
+        }
+    }
+    const size_t off = (size_t)wave_first * REST_F;
+    float* __restrict__ P = p_rest + off;
+    float* __restrict__ M = ad.m[2] + off;
+    float* __restrict__ V = ad.v[2] + off;
+    const float nss = ad.nss[2];
+    const int nflat = nrow * REST_F;
+    for (int base = 0; base < nflat; base += 256) {
+        const int f0 = base + lane * 4;
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = min(f0 + j, nflat - 1);
+            const int row = f / REST_F, k = f - row * REST_F;
+            g[j] = (((live >> row) & 1ull) && 3 + k < nfloat) ? lds_rows[row * ROW_LDS + 3 + k] : 0.f;
+        }
+        if (f0 + 3 < nflat) {
+            float4 p = *reinterpret_cast<const float4*>(P + f0), m = *reinterpret_cast<const float4*>(M + f0),
+                   v = *reinterpret_cast<const float4*>(V + f0);
+            adam_update(p.x, g[0], m.x, v.x, nss, ad.a);
+            adam_update(p.y, g[1], m.y, v.y, nss, ad.a);
+            adam_update(p.z, g[2], m.z, v.z, nss, ad.a);
+            adam_update(p.w, g[3], m.w, v.w, nss, ad.a);
+            *reinterpret_cast<float4*>(P + f0) = p;
+            *reinterpret_cast<float4*>(M + f0) = m;
+            *reinterpret_cast<float4*>(V + f0) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < nflat) {
+                    float p = P[f0 + j], m = M[f0 + j], v = V[f0 + j];
+                    adam_update(p, g[j], m, v, nss, ad.a);
+                    P[f0 + j] = p; M[f0 + j] = m; V[f0 + j] = v;
+                }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
@@ -647,12 +702,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 // library's record of monomial sums but [P,9] doubles holding the textbook 2-D gradients {dL/dmean2D x, y (NDC-ish units),
 // dL/dconic A, B, C, dL/dopacity_eff, dL/drgb[3]}; the per-Gaussian factors that turn the one into the other are skipped
 // and everything behind them — the conic -> covariance -> scale / quaternion chain, projection, SH — is the same code.
-template <bool TEXTBOOK>
+// ADAM = true (msgs_grads_t::adam_in_backward; raw mode 1, staged SH rows, no accumulate, not factored): the raw-parameter
+// gradients are not stored — every Gaussian's parameters and moments take their Adam step here, with the gradient still in
+// registers / LDS (zero for a Gaussian that was not rendered).
+template <bool TEXTBOOK, bool ADAM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void preprocess_backward_kernel(ViewParams vp, msgs_gaussians_t g,
                                                                   const int32_t* __restrict__ radii,
                                                                   const char* __restrict__ geom,
                                                                   const grad_acc_t* __restrict__ grad_rec,
-                                                                  msgs_grads_t grads) {
+                                                                  msgs_grads_t grads, AdamInBackward ad) {
     // 32 rows per wave: the SH rows of a wave's 64 Gaussians pass through LDS in two runs of 32 (below).  25 KB per workgroup
     // instead of 50: the kernel is latency-bound and its time follows the occupancy (measured at C3 with 1 / 2 / 3 workgroups
     // per CU: 252 / 147 / 121 us)
@@ -681,10 +739,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
     const bool staged_sh = raw || (g.shs != nullptr && grads.dL_dshs != nullptr && K == 16);   // wave-uniform
     // factored SH gradient (view-parallel exchange, msgs_sh_grad_from_views): dL/dSH of one view is the outer product
     // basis(direction) x dL/drgb, so only the (clamp-masked) dL/drgb is delivered and the 192-byte rows are not written
-    const bool factored_sh = raw && grads.dL_dfeatures_dc == nullptr;
+    const bool factored_sh = !ADAM && raw && grads.dL_dfeatures_dc == nullptr;
     // accumulate (several views of one optimizer step into one gradient bucket): add to what the gradient tensors hold and
     // leave the rows of Gaussians this view did not render alone — no zero rows, no separate accumulation pass
-    const bool accum = grads.accumulate != 0;
+    const bool accum = !ADAM && grads.accumulate != 0;
     const int wave_first = blockIdx.x * blockDim.x + wv * 64;
     const uint64_t live = __ballot(rendered);
     if (staged_sh) {                         // list of the rendered lanes, ascending: the rows to fetch
@@ -945,7 +1003,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
             }
             if (factored_sh) continue;
             wave_lds_fence();
-            if (raw)
+            if constexpr (ADAM)
+                coop_adam_split_rows(s_rows[wv], const_cast<float*>(g.features_dc), const_cast<float*>(g.features_rest), ad, i,
+                                     in_range && mine, first, nrow, live_h, nfloat, lane, lrow);
+            else if (raw)
                 coop_store_split_rows(s_rows[wv], grads.dL_dfeatures_dc, grads.dL_dfeatures_rest, i, in_range && mine, first,
                                       nrow, live_h, nfloat, lane, lrow, accum);
             else
@@ -961,6 +1022,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void p
 
     // the screen-space gradient is per view (viewspace_points.grad of THIS render, scene/gaussian_model.py:698-701): stored
     if (grads.dL_dmeans2D) { grads.dL_dmeans2D[3 * i] = g2x; grads.dL_dmeans2D[3 * i + 1] = g2y; grads.dL_dmeans2D[3 * i + 2] = 0.f; }
+    if constexpr (ADAM) {
+        // the small tensors: this thread's own rows (gradients are zero where the Gaussian was not rendered)
+        auto step3 = [&](const float* param, int t, const float* gr) {
+            float* P = const_cast<float*>(param) + 3 * (size_t)i;
+            float* M = ad.m[t] + 3 * (size_t)i;
+            float* V = ad.v[t] + 3 * (size_t)i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pp = P[c], mm = M[c], vv = V[c];
+                adam_update(pp, gr[c], mm, vv, ad.nss[t], ad.a);
+                P[c] = pp; M[c] = mm; V[c] = vv;
+            }
+        };
+        step3(g.means3D, 0, dmean);
+        {
+            float* P = const_cast<float*>(g.opacities) + i;
+            float pp = *P, mm = ad.m[3][i], vv = ad.v[3][i];
+            adam_update(pp, dopac, mm, vv, ad.nss[3], ad.a);
+            *P = pp; ad.m[3][i] = mm; ad.v[3][i] = vv;
+        }
+        step3(g.scales, 4, dscale);
+        {
+            float4* P = reinterpret_cast<float4*>(const_cast<float*>(g.rotations)) + i;
+            float4* M = reinterpret_cast<float4*>(ad.m[5]) + i;
+            float4* V = reinterpret_cast<float4*>(ad.v[5]) + i;
+            float4 pp = *P, mm = *M, vv = *V;
+            adam_update(pp.x, dq[0], mm.x, vv.x, ad.nss[5], ad.a);
+            adam_update(pp.y, dq[1], mm.y, vv.y, ad.nss[5], ad.a);
+            adam_update(pp.z, dq[2], mm.z, vv.z, ad.nss[5], ad.a);
+            adam_update(pp.w, dq[3], mm.w, vv.w, ad.nss[5], ad.a);
+            *P = pp; *M = mm; *V = vv;
+        }
+        return;
+    }
     if (accum) {
         if (!rendered) return;
         if (grads.dL_dmeans3D) {
@@ -1103,7 +1198,8 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
     if (g.P == 0) return hipSuccess;
     // textbook: grad_rec holds [P, 9] doubles — the TEXTBOOK 2-D gradients (msgs_backward_per_gaussian; the verification mode)
     static_assert(sizeof(grad_acc_t) == 8, "the textbook sums are doubles");
-    if (g.raw_params != 0 && grads.dL_dfeatures_dc == nullptr) {          // factored SH gradient: the factors first
+    const msgs_adam_in_backward_t* aib = grads.adam_in_backward;
+    if (g.raw_params != 0 && grads.dL_dfeatures_dc == nullptr && !aib) {          // factored SH gradient: the factors first
         hipLaunchKernelGGL(sh_factor_kernel, dim3((g.P + 255) / 256), dim3(256), 0, s, g.P, radii, geom, grad_rec,
                            textbook ? 9 : GRAD_REC_FLOATS, grads.dL_dcolors);
         hipError_t e = hipGetLastError();
@@ -1119,12 +1215,20 @@ hipError_t launch_preprocess_backward(const ViewParams& vp, const msgs_gaussians
         hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)grads.wait_before_accumulate, 0);
         if (e != hipSuccess) return e;
     }
-    if (textbook)
-        hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
-                           grad_rec, grads);
-    else
-        hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((g.P + 255) / 256), dim3(256), 0, s, vp, g, radii, geom,
-                           grad_rec, grads);
+    AdamInBackward ad{};
+    if (aib) {
+        for (int t = 0; t < 6; ++t) {
+            ad.m[t] = aib->t[t].exp_avg;
+            ad.v[t] = aib->t[t].exp_avg_sq;
+            ad.nss[t] = adam_neg_step_size(aib->t[t].lr, aib->step, aib->beta1);
+        }
+        ad.a = adam_scalars(aib->step, aib->beta1, aib->beta2, aib->eps);
+    }
+    const dim3 grid((g.P + 255) / 256), block(256);
+    if (textbook && aib) hipLaunchKernelGGL((preprocess_backward_kernel<true, true>), grid, block, 0, s, vp, g, radii, geom, grad_rec, grads, ad);
+    else if (textbook) hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, 0, s, vp, g, radii, geom, grad_rec, grads, ad);
+    else if (aib) hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), grid, block, 0, s, vp, g, radii, geom, grad_rec, grads, ad);
+    else hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, 0, s, vp, g, radii, geom, grad_rec, grads, ad);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && grads.accumulated) e = hipEventRecord((hipEvent_t)grads.accumulated, s);
     return e;

@@ -857,13 +857,31 @@ def set_grad_accumulator(acc):
     return prev
 
 
+_step_in_backward = threading.local()
+
+
+def set_optimizer_in_backward(optimizer):
+    """Install (or, with None, remove) the optimizer whose step the following forwards of the RAW entry OF THIS THREAD hand to
+    their backward (include/msgs.h, msgs_adam_in_backward_t): the per-Gaussian backward kernel then applies the Adam update to
+    the six leaf tensors and their moments itself, where it forms their gradients — the 236 bytes of gradient per Gaussian are
+    neither written nor read back, the leaves receive no .grad — and `optimizer.take_step_in_backward(leaves)` is called once
+    per backward to advance the step counters and deliver the table (train_epilogue.FusedAdam implements it).  One view per
+    optimizer step, as in the reference's loop (/root/reference/train.py:203-216, :416-418); not with a GradAccumulator or the
+    factored SH gradient.  Bit-identical parameters and moments to backward + FusedAdam.step() (tests/test_train_step_gpu.py).
+    Returns the previous one."""
+    prev = getattr(_step_in_backward, "opt", None)
+    _step_in_backward.opt = optimizer
+    return prev
+
+
 def _snapshot_sinks(ctx, leaves):
     """Called in forward (the caller's thread): the sinks registered for THIS call travel on its ctx, so that the
     backward — which runs on autograd's worker thread — never reads module state another thread may be changing."""
     ctx.sinks = tuple(_sinks.grad.get(id(t)) for t in leaves)
     ctx.sh_factor = (_sinks.sh_factor[0], _sinks.sh_factor[1])
     ctx.accum = getattr(_accumulator, "acc", None)
-    ctx.leaves = leaves if ctx.accum is not None else None
+    ctx.step_opt = getattr(_step_in_backward, "opt", None)
+    ctx.leaves = leaves if (ctx.accum is not None or ctx.step_opt is not None) else None
 
 
 def _grad_out(hit, shape, dev):
@@ -914,8 +932,17 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             if factor is not None and (factor.device != dev or factor.shape[0] != P):
                 raise ValueError("sh_factor sink does not match this model (device / number of Gaussians)")
             accum = getattr(ctx, "accum", None)
+            step_opt = getattr(ctx, "step_opt", None)
             acc_flag, ev_wait, ev_rec = 0, None, None
-            if accum is not None:
+            adam = None
+            if step_opt is not None:
+                if accum is not None or factor is not None:
+                    raise ValueError("set_optimizer_in_backward cannot be combined with a GradAccumulator or the factored SH gradient")
+                if call.view.sh_coeffs != 16:
+                    raise ValueError("set_optimizer_in_backward needs 16 SH coefficients per Gaussian")
+                adam = step_opt.take_step_in_backward(ctx.leaves)        # (a _C.AdamInBackward; keeps its tensors alive itself)
+                g_xyz = g_dc = g_rest = g_opac = g_scal = g_rot = None
+            elif accum is not None:
                 if factor is not None:
                     raise ValueError("GradAccumulator and the factored SH gradient cannot be combined")
                 (g_xyz, g_dc, g_rest, g_opac, g_scal, g_rot), acc, wait, rec = accum._take(ctx.leaves)
@@ -932,12 +959,12 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             grads = _C.Grads(_ptr(g_xyz), _ptr(g_m2), None, _ptr(factor), _ptr(g_opac), _ptr(g_scal), _ptr(g_rot), None,
                              _ptr(g_dc), _ptr(g_rest),
                              C.c_void_p(ready.cuda_event) if (factor is not None and ready is not None) else None,
-                             is_clear, acc_flag, ev_wait, ev_rec)
+                             is_clear, acc_flag, ev_wait, ev_rec, C.addressof(adam) if adam is not None else None)
             _C.check(lib.msgs_backward(call.view_ref, call.g_ref, _ptr(ctx.radii), _ptr(geom),
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
                                        _C.timer_ptr(), stream), "msgs_backward")
-        if accum is not None:               # the leaf gradients live in the accumulator: nothing for autograd to add
+        if accum is not None or adam is not None:   # the leaf gradients live in the accumulator / were consumed by the step
             return (None, g_m2.view(m2_shape), None, None, None, None, None, None, None, None, None, None, None)
         return (g_xyz, g_m2.view(m2_shape), g_dc, g_rest, g_opac, g_scal, g_rot, None, None, None, None, None, None)
 

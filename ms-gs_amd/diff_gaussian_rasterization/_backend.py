@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("MSGS_HIP_LIB") or next(
     (p for p in (os.path.join(_PKG, "libmsgs_hip.so"),) if os.path.exists(p)),
     os.path.join(os.path.dirname(_PKG), "lib", "libmsgs_hip.so"))
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 K_NAMES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
            "preprocess_bwd", "slab_b")
@@ -53,7 +53,15 @@ class Grads(C.Structure):
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p),
                 ("scratch_is_clear", C.c_int32), ("accumulate", C.c_int32),
-                ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p)]
+                ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p), ("adam_in_backward", C.c_void_p)]
+
+
+class AdamMoments(C.Structure):          # msgs_adam_moments_t
+    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double)]
+
+
+class AdamInBackward(C.Structure):       # msgs_adam_in_backward_t: means3D, features_dc, features_rest, opacities, scales, rotations
+    _fields_ = [("step", C.c_int64), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("t", AdamMoments * 6)]
 
 
 class AdamTensor(C.Structure):

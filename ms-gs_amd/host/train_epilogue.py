@@ -84,6 +84,49 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
 
+    # ---- the step inside the rasterizer's backward (diff_gaussian_rasterization.set_optimizer_in_backward) ----
+    def take_step_in_backward(self, leaves):
+        """Called by the raw entry's backward with its six leaf tensors (xyz, features_dc, features_rest, opacity, scaling,
+        rotation): advances their step counters as step() would and returns the msgs_adam_in_backward_t table — the
+        per-Gaussian backward kernel then updates parameters and moments itself (include/msgs.h).  The six tensors must be
+        parameters of this optimizer with common betas / eps / step (the reference's setup, gaussian_model.py:235-248)."""
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        table = _C.AdamInBackward()
+        common = None
+        keep = []
+        for k, p in enumerate(leaves):
+            group = group_of.get(id(p))
+            if group is None:
+                raise ValueError("take_step_in_backward: a leaf of the render call is not a parameter of this optimizer "
+                                 "(densification re-creates the tensors: install the optimizer again after it)")
+            _require_gpu_f32(p, "FusedAdam param")
+            if p.grad is not None:
+                raise RuntimeError("take_step_in_backward: the parameter already holds a .grad — the step inside the backward "
+                                   "would ignore it (call zero_grad(set_to_none=True) first)")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            _require_gpu_f32(st["exp_avg"], "FusedAdam exp_avg")
+            _require_gpu_f32(st["exp_avg_sq"], "FusedAdam exp_avg_sq")
+            if st["exp_avg"].numel() != p.numel() or st["exp_avg_sq"].numel() != p.numel():
+                raise ValueError("FusedAdam: optimizer state and parameter sizes differ")
+            key = (int(st["step"].item()) + 1, tuple(group["betas"]), float(group["eps"]))
+            if common is None:
+                common = key
+            elif key != common:
+                raise ValueError(f"take_step_in_backward: the six tensors must share step / betas / eps, got {common} and {key}")
+            table.t[k] = _C.AdamMoments(_ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), float(group["lr"]))
+            keep.append((st["exp_avg"], st["exp_avg_sq"]))
+        for p in leaves:
+            self.state[p]["step"] += 1
+        table.step, (table.beta1, table.beta2), table.eps = common[0], common[1], common[2]
+        table._keep = keep
+        self.steps_in_backward = getattr(self, "steps_in_backward", 0) + 1
+        return table
+
+
 def update_training_stats(model, viewspace_points, radii, pixel_sizes, reso_lvl=0, *, base_mask=False,
                           update_pixel_sizes=True, densify=True):
     """One launch for the reference's per-iteration statistics (train.py:239-250).  `model` carries the reference's

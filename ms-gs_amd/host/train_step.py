@@ -12,6 +12,7 @@ control plane, out of scope here.
 """
 import torch
 
+import diff_gaussian_rasterization as dgr
 from gaussian_renderer import render_fused
 from loss_utils import l1_ssim_loss
 from train_epilogue import update_training_stats
@@ -19,9 +20,21 @@ from train_epilogue import update_training_stats
 
 def fused_train_iteration(model, optimizer, cam, gt_image, pipe, bg, *, lambda_dssim=0.2, loss_multiplier=1.0,
                           reso_lvl=0, filter_small=False, filter_large=False, fade_size=1.0, base_mask=False,
-                          update_pixel_sizes=True, densify=True):
-    """Returns (loss, Ll1, render_pkg); loss / Ll1 are 0-dim GPU tensors (no host sync is issued here)."""
-    pkg = render_fused(cam, model, pipe, bg, filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)
+                          update_pixel_sizes=True, densify=True, step_in_backward=False):
+    """Returns (loss, Ll1, render_pkg); loss / Ll1 are 0-dim GPU tensors (no host sync is issued here).
+    step_in_backward: the Adam step of the six leaf tensors is taken INSIDE the rasterizer's per-Gaussian backward kernel
+    (include/msgs.h, msgs_adam_in_backward_t): no gradient tensors are written or read (2 x 236 bytes per Gaussian), the
+    parameters and moments come out bit-identical to the default composition.  The statistics below read only the render
+    outputs and the screen-space gradient, so their order against the step does not matter."""
+    if step_in_backward:
+        taken = getattr(optimizer, "steps_in_backward", 0)
+        prev = dgr.set_optimizer_in_backward(optimizer)
+        try:
+            pkg = render_fused(cam, model, pipe, bg, filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)
+        finally:
+            dgr.set_optimizer_in_backward(prev)
+    else:
+        pkg = render_fused(cam, model, pipe, bg, filter_small=filter_small, filter_large=filter_large, fade_size=fade_size)
     loss, Ll1 = l1_ssim_loss(pkg["render"], gt_image, lambda_dssim)
     if loss_multiplier != 1.0:                      # train.py:212-215 (0.1 on the coarser levels)
         loss = loss * loss_multiplier
@@ -32,7 +45,12 @@ def fused_train_iteration(model, optimizer, cam, gt_image, pipe, bg, *, lambda_d
     with torch.no_grad():
         update_training_stats(model, pkg["viewspace_points"], pkg["radii"], pkg["pixel_sizes"], reso_lvl,
                               base_mask=base_mask, update_pixel_sizes=update_pixel_sizes, densify=densify)
-        optimizer.step()
+        if step_in_backward:
+            if getattr(optimizer, "steps_in_backward", 0) != taken + 1:
+                raise RuntimeError("fused_train_iteration: the backward did not take the optimizer step (render_fused did not go "
+                                   "through the raw rasterizer entry?)")
+        else:
+            optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return loss.detach(), Ll1, pkg
 

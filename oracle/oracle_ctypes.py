@@ -45,7 +45,7 @@ class Grads(C.Structure):
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dfeatures_dc", C.c_void_p), ("dL_dfeatures_rest", C.c_void_p), ("factors_ready", C.c_void_p),
                 ("scratch_is_clear", C.c_int32), ("accumulate", C.c_int32),
-                ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p)]
+                ("wait_before_accumulate", C.c_void_p), ("accumulated", C.c_void_p), ("adam_in_backward", C.c_void_p)]
 
 
 _SO_NAMES = {"f32": "liboracle.so", "f64": "liboracle64.so", "fma": "liboracle_fma.so"}

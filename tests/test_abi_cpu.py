@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/msgs.h but not exported"
     assert set(dgr._C.EXPORTS) == set(names)
-    assert lib.msgs_abi_version() == dgr._C.ABI_VERSION == 10
+    assert lib.msgs_abi_version() == dgr._C.ABI_VERSION == 11
     assert b"exactly one" in lib.msgs_error_string(-1)
 
 
@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     from oracle import oracle_ctypes as oc
     assert C.sizeof(dgr._C.View) == 16 * 4 + 4 * 8 == C.sizeof(oc.View)
     assert C.sizeof(dgr._C.Gaussians) == 8 + 15 * 8 == C.sizeof(oc.Gaussians)
-    assert C.sizeof(dgr._C.Grads) == 14 * 8 == C.sizeof(oc.Grads) and dgr._C.Grads.scratch_is_clear.offset == 88
+    assert C.sizeof(dgr._C.Grads) == 15 * 8 == C.sizeof(oc.Grads) and dgr._C.Grads.adam_in_backward.offset == 112 and C.sizeof(dgr._C.AdamInBackward) == 32 + 6 * 24 and dgr._C.Grads.scratch_is_clear.offset == 88
     assert dgr._C.Grads.accumulate.offset == 92 and dgr._C.Grads.wait_before_accumulate.offset == 96
     assert dgr._C.View.bg.offset == 64 and dgr._C.View.slab_fraction.offset == 56 and dgr._C.Gaussians.means3D.offset == 8
     assert [f[0] for f in dgr._C.View._fields_] == [f[0] for f in oc.View._fields_]

@@ -24,4 +24,4 @@ def test_setup_py_build_ships_the_library_inside_the_package(tmp_path):
     assert q.returncode == 0, q.stderr[-2000:]
     path, abi, ok = q.stdout.strip().splitlines()[-3:]
     assert os.path.realpath(path) == os.path.realpath(os.path.join(lib_dir, "diff_gaussian_rasterization", "libmsgs_hip.so"))
-    assert int(abi) == 10 and ok == "True"
+    assert int(abi) == 11 and ok == "True"

@@ -43,7 +43,7 @@ def _oracle(scene, cam, st, bg, dL=None, **kw):
 def test_library_is_the_hip_one():
     import diff_gaussian_rasterization as dgr
     assert dgr._C._LIB_PATH.endswith("libmsgs_hip.so")
-    assert dgr._C.lib.msgs_abi_version() == dgr._C.ABI_VERSION == 10
+    assert dgr._C.lib.msgs_abi_version() == dgr._C.ABI_VERSION == 11
 
 
 @pytest.mark.parametrize("P,W,H,seed,deg,bgv", [

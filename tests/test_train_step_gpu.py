@@ -152,3 +152,68 @@ def test_multi_view_iteration_equals_the_serial_composition():
         pa, pb = ga_["params"][0], gb_["params"][0]
         assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
         assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+
+
+@pytest.mark.parametrize("deg", [3, 1])
+def test_the_step_inside_the_backward_gives_the_same_bits_as_backward_plus_optimizer(deg):
+    """fused_train_iteration(step_in_backward=True): the per-Gaussian backward kernel applies the Adam update itself
+    (include/msgs.h, msgs_adam_in_backward_t) — parameters, both moments, the statistics and the losses of a 12-iteration run
+    are BIT-identical to the default composition (gradient tensors written by the backward, read by FusedAdam.step), with a
+    model whose size is not a multiple of the kernel's 32-row runs, filters on, an active SH degree below the stored one."""
+    from synthetic_model import SyntheticGaussians
+    from train_epilogue import FusedAdam
+    from train_step import fused_train_iteration
+    W, H = 160, 128
+    sc, cam = small_scene(6007, W, H, 23, multiscale=True, scale_k=0.004 * 1920.0 / W * 0.2, sh_degree=deg)
+    st = dict(filter_small=True, filter_large=True, fade_size=0.0)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).cuda()
+    bg = torch.zeros(3).cuda()
+    camd = cam.to("cuda")
+    a, b = SyntheticGaussians(sc, "cuda"), SyntheticGaussians(sc, "cuda")
+    oa = FusedAdam(a.training_setup(7, sc.target_reso_lvl), lr=0.0, eps=1e-15)
+    ob = FusedAdam(b.training_setup(7, sc.target_reso_lvl), lr=0.0, eps=1e-15)
+    for it in range(12):
+        la, _, pa = fused_train_iteration(a, oa, camd, gt, PIPE, bg, step_in_backward=True, **st)
+        lb, _, pb = fused_train_iteration(b, ob, camd, gt, PIPE, bg, **st)
+        assert all(getattr(a, n).grad is None for n in a.LEAVES)           # no gradient tensors were formed
+        assert torch.equal(la, lb), it
+        assert torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"])
+    assert (pa["radii"] == 0).any() and (pa["radii"] > 0).any()            # rendered and unrendered rows both took the step
+    for n in a.LEAVES:
+        p, q = getattr(a, n), getattr(b, n)
+        assert torch.equal(p, q), n
+        sa, sb = oa.state[p], ob.state[q]
+        assert sa["step"].item() == sb["step"].item() == 12
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), n
+        assert sa["exp_avg"].abs().max().item() > 0
+    for k in ("denom", "max_radii2D", "max_pixel_sizes", "min_pixel_sizes", "xyz_gradient_accum"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_the_step_inside_the_backward_refuses_what_it_cannot_serve():
+    import diff_gaussian_rasterization as dgr
+    from gaussian_renderer import render_fused
+    from synthetic_model import SyntheticGaussians
+    from train_epilogue import FusedAdam
+    W, H = 96, 64
+    sc, cam = small_scene(500, W, H, 5)
+    camd, bg = cam.to("cuda"), torch.zeros(3).cuda()
+    model = SyntheticGaussians(sc, "cuda")
+    opt = FusedAdam(model.training_setup(1), lr=0.0, eps=1e-15)
+    other = FusedAdam([{"params": [torch.nn.Parameter(torch.zeros(4, device="cuda"))], "lr": 0.1, "name": "x"}], lr=0.0, eps=1e-15)
+    prev = dgr.set_optimizer_in_backward(other)            # an optimizer that does not own the model's tensors
+    try:
+        out = render_fused(camd, model, PIPE, bg)["render"].sum()
+    finally:
+        assert dgr.set_optimizer_in_backward(prev) is other
+    with pytest.raises(ValueError, match="not a parameter of this optimizer"):
+        out.backward()
+    model._xyz.grad = torch.zeros_like(model._xyz)         # a pending .grad would be ignored by the step: refused
+    dgr.set_optimizer_in_backward(opt)
+    try:
+        out = render_fused(camd, model, PIPE, bg)["render"].sum()
+    finally:
+        dgr.set_optimizer_in_backward(None)
+    with pytest.raises(RuntimeError, match="already holds a .grad"):
+        out.backward()
+    assert getattr(opt, "steps_in_backward", 0) == 0 and len(opt.state) == 0
