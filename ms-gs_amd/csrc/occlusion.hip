@@ -25,20 +25,21 @@
 // workgroups.  Every workgroup first adds up the candidate counts preprocess_kernel left per workgroup (a few KB) — no barrier,
 // no shared counter to clear:
 //   fewer than three candidates in the whole view (a cover weighs at most 6.65 of the 14.3 bits needed; an ordinary training
-//     view has none): every workgroup leaves — ~3 us;
+//     view has none): every workgroup leaves — 4.6 us at BASELINE C3 including the launch;
 //   up to OCC_SMALL candidates (BASELINE C3: four): every workgroup collects ALL of them into its LDS, ranks them by depth
 //     bucket, and its waves take the tile blocks one each: lane <-> candidate, one 64-lane prefix sum, the bucket of the lane
 //     at which the product crosses;
-//   more: the phases of round 5 behind grid barriers — depth histogram of the candidates -- barrier -- keep the nearest
-//     OCC_MAX_CAND (whole depth buckets) and gather their records -- barrier -- per block of tiles: bucketed sums of
-//     -log2(1 - alpha_min), prefix, cut-off bucket.
+//   more: the phases of round 5 behind grid barriers — (only with more than OCC_MAX_CAND candidates: depth histogram of the
+//     candidates -- barrier -- keep the nearest OCC_MAX_CAND, whole depth buckets) gather the records -- barrier -- per group of
+//     up to four blocks of tiles: one walk over the records, bucketed sums of -log2(1 - alpha_min), prefix, cut-off bucket.
 // Then ONE more grid barrier, behind which every workgroup knows whether anything closed: if not (the rule), it leaves; if so,
 // the Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in place; a Gaussian left
 // without instances leaves the depth sort: key 0xFFFFFFFF).  The pass runs on EVERY forward, and the wrapper's adaptive skip
 // policy of round 5 — with its cliff, a closing view inside the 31 skipped calls rendered uncut — is gone.
-// Grid barriers: one counter per barrier in the header preprocess_kernel clears; the table and the flags are written with
-// agent-scope (write-through) stores, the candidate records with plain stores behind an agent-scope release; every workgroup
-// takes one agent-scope acquire before it reads another workgroup's data (cdna_hip_programming.md G16).  The waits are bounded.
+// Grid barriers: one counter per barrier in the header preprocess_kernel clears; the table, the flags and the candidate records
+// are written with agent-scope (write-through) stores — no release fence anywhere: one would write back everything
+// preprocess_kernel left dirty in the XCD's L2, 60 us —; every workgroup takes one agent-scope acquire before it reads another
+// workgroup's data (cdna_hip_programming.md G16).  The waits are bounded.
 // A workgroup whose wait expires raises OccHeader::watchdog and leaves, and whatever the others still do the state stays VALID:
 // a table entry is either open or a proven cut-off; the cover phase starts only after EVERY workgroup has finished the gather;
 // any subset of covers, of blocks and of recounted Gaussians is a valid (weaker) cut (count >= emitted, surplus slots go to the
@@ -119,7 +120,8 @@ struct OccGatherLds {
 };
 constexpr int OCC_SMALL = 64;               // up to this many candidates every workgroup handles the whole view's covers itself
 union OccLds {
-    uint32_t hist[OCC_BUCKETS];               // depth histogram of a chunk; bucket sums of a cover block
+    uint32_t hist[OCC_BUCKETS];               // depth histogram of a chunk
+    uint32_t sums[4][OCC_BUCKETS];            // bucket sums of a group of cover blocks (OCC_GROUP = 4)
     OccGatherLds g;                           // selection + gather
     OccTable table;                           // recount
 };
@@ -246,7 +248,14 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
         c.rect_hi = __float_as_uint(b.q1.w);                                          // maxx | maxy << 16   (exclusive)
         c.pad0 = c.pad1 = 0u;
         const uint32_t pos = S.by_depth ? L.base + e : (L.prefix[ls] + j) / S.stride;
-        if (pos < (uint32_t)OCC_MAX_CAND) cand[pos] = c;
+        if (pos < (uint32_t)OCC_MAX_CAND) {
+            // write-through (agent-scope) stores: the barrier behind this phase then needs no release fence — which would write
+            // back everything preprocess_kernel left dirty in this XCD's L2 (60 us measured)
+            uint64_t* d = reinterpret_cast<uint64_t*>(cand + pos);
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(&c);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(OccCand) / 8); ++k) __hip_atomic_store(d + k, w[k], OCC_RLX_AGENT);
+        }
     }
     __syncthreads();
     (void)dummy;
@@ -285,57 +294,96 @@ __device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, flo
     return (uint32_t)(w * (OCC_FIX * 0.999f));          // rounded down
 }
 
-// ---- phase 3: one block of B x B tiles ---------------------------------------------------------------------------------------
-// returns (to every thread) the depth bucket in which the block's product crosses, 0xFFFFFFFF when it does not; a crossing in
-// the last bucket — which also holds the keys clamped into it — closes nothing (callers test < OCC_BUCKETS - 1)
-__device__ __forceinline__ uint32_t occ_cover_block(int blk, const ViewParams& vp, int B, int nbx, uint32_t n,
-                                                    const OccCand* cand, uint32_t* s_b, uint32_t* s_wave, uint32_t* s_cross) {
-    const int bx = blk % nbx, by = blk / nbx;
-    const int tx0 = bx * B, ty0 = by * B;
-    const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
-    __syncthreads();                                    // (LDS of the previous block consumed)
-    for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) s_b[k] = 0u;
-    if (threadIdx.x == 0) *s_cross = 0xFFFFFFFFu;
+// ---- phase 3: a GROUP of up to OCC_GROUP consecutive blocks of B x B tiles -------------------------------------------------
+// One walk over the candidate records serves the whole group (at 4K a workgroup owns eight blocks: two walks instead of eight),
+// four records in flight per thread, and every group starts its walk at a different record: 256 workgroups reading the same
+// records in lockstep queue up on the same L2 channels (measured at BASELINE C5, 10 751 candidates, 2040 blocks: 102 us of the
+// pass's 175 in this phase, a microsecond per pair of dependent record loads).  The sums are integers: the order is free.
+// Writes the cut-off bucket of every block of the group whose product crosses (the table started all-open; a crossing in the
+// last bucket — which also holds the keys clamped into it — closes nothing).
+constexpr int OCC_GROUP = 4;
+__device__ __forceinline__ void occ_cover_group(int blk0, int nb, const ViewParams& vp, int B, int nbx, uint32_t n,
+                                                const OccCand* cand, uint32_t (*s_b)[OCC_BUCKETS], uint32_t* s_wave,
+                                                uint32_t* s_cross, uint32_t* occ_cut, OccHeader* hdr) {
+    __syncthreads();                                    // (LDS of the previous group consumed)
+    for (int k = threadIdx.x; k < nb * OCC_BUCKETS; k += OCC_THREADS) s_b[0][k] = 0u;
+    if (threadIdx.x < OCC_GROUP) s_cross[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
-    const float x0 = (float)(tx0 * TILE), y0 = (float)(ty0 * TILE);
-    const float x1 = (float)(min(tx1 * TILE, vp.W) - 1), y1 = (float)(min(ty1 * TILE, vp.H) - 1);   // pixels inside the image
+    // the group's blocks, and the tile range that holds them all (a candidate whose rect misses it is done after four compares)
+    int tx0[OCC_GROUP], ty0[OCC_GROUP], tx1[OCC_GROUP], ty1[OCC_GROUP];
+    float x0[OCC_GROUP], y0[OCC_GROUP], x1[OCC_GROUP], y1[OCC_GROUP];
+    int gx0 = 0x7FFFFFFF, gy0 = 0x7FFFFFFF, gx1 = 0, gy1 = 0;
+#pragma unroll
+    for (int j = 0; j < OCC_GROUP; ++j) {
+        const int blk = blk0 + min(j, nb - 1);
+        const int bx = blk % nbx, by = blk / nbx;
+        tx0[j] = bx * B; ty0[j] = by * B;
+        tx1[j] = min(tx0[j] + B, vp.gx); ty1[j] = min(ty0[j] + B, vp.gy);
+        x0[j] = (float)(tx0[j] * TILE); y0[j] = (float)(ty0[j] * TILE);
+        x1[j] = (float)(min(tx1[j] * TILE, vp.W) - 1); y1[j] = (float)(min(ty1[j] * TILE, vp.H) - 1);   // pixels inside the image
+        gx0 = min(gx0, tx0[j]); gy0 = min(gy0, ty0[j]); gx1 = max(gx1, tx1[j]); gy1 = max(gy1, ty1[j]);
+    }
     auto add = [&](const OccCand& cc) {
-        const uint32_t w = cover_weight(cc, x0, x1, y0, y1, tx0, tx1, ty0, ty1);
-        if (w) atomicAdd(&s_b[occ_bucket(__float_as_uint(cc.c1.z))], w);
+        const int minx = (int)(cc.rect_lo & 0xFFFFu), miny = (int)(cc.rect_lo >> 16);
+        const int maxx = (int)(cc.rect_hi & 0xFFFFu), maxy = (int)(cc.rect_hi >> 16);
+        if (minx >= gx1 || maxx <= gx0 || miny >= gy1 || maxy <= gy0) return;       // (a block must lie INSIDE the rect to count)
+        const uint32_t bucket = occ_bucket(__float_as_uint(cc.c1.z));
+#pragma unroll
+        for (int j = 0; j < OCC_GROUP; ++j) {
+            if (j >= nb) break;
+            const uint32_t w = cover_weight(cc, x0[j], x1[j], y0[j], y1[j], tx0[j], tx1[j], ty0[j], ty1[j]);
+            if (w) atomicAdd(&s_b[j][bucket], w);
+        }
     };
-    uint32_t c = threadIdx.x;
-    for (; c + OCC_THREADS < n; c += 2 * OCC_THREADS) {                 // two records in flight per thread
-        const OccCand ca = cand[c], cb = cand[c + OCC_THREADS];
-        add(ca);
-        add(cb);
+    const uint32_t rot = n ? (uint32_t)(((uint64_t)(uint32_t)blk0 * 2654435761ull) % n) : 0u;
+    constexpr int FLY = 4;
+    for (uint32_t c = threadIdx.x; c < n; c += FLY * OCC_THREADS) {
+        OccCand r[FLY];
+#pragma unroll
+        for (int u = 0; u < FLY; ++u) {
+            uint32_t at = c + (uint32_t)(u * OCC_THREADS);
+            at = at < n ? at : threadIdx.x;                                 // (tail: a valid record, not added)
+            at += rot;
+            r[u] = cand[at >= n ? at - n : at];
+        }
+#pragma unroll
+        for (int u = 0; u < FLY; ++u)
+            if (c + (uint32_t)(u * OCC_THREADS) < n) add(r[u]);
     }
-    if (c < n) add(cand[c]);
     __syncthreads();
-    // front-to-back prefix over the buckets: thread t owns PER consecutive buckets
+    // front-to-back prefix over the buckets of each block: thread t owns PER consecutive buckets
     constexpr int PER = OCC_BUCKETS / OCC_THREADS;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { v[k] = min(s_b[threadIdx.x * PER + k], 0x00FFFFFFu); sum += v[k]; }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = sum;
+    for (int j = 0; j < nb; ++j) {
+        uint32_t v[PER], sum = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) s_wave[wv] = inc;
-    __syncthreads();
-    uint32_t run = inc - sum;
-    for (int k = 0; k < wv; ++k) run += s_wave[k];
-    uint32_t cross = 0xFFFFFFFFu;
+        for (int k = 0; k < PER; ++k) { v[k] = min(s_b[j][threadIdx.x * PER + k], 0x00FFFFFFu); sum += v[k]; }
+        uint32_t inc = sum;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        run += v[k];
-        if (cross == 0xFFFFFFFFu && run >= OCC_THRESHOLD) cross = (uint32_t)(threadIdx.x * PER + k);
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wave[4 * j + wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int k = 0; k < wv; ++k) run += s_wave[4 * j + k];
+        uint32_t cross = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            run += v[k];
+            if (cross == 0xFFFFFFFFu && run >= OCC_THRESHOLD) cross = (uint32_t)(threadIdx.x * PER + k);
+        }
+        if (cross != 0xFFFFFFFFu) atomicMin(&s_cross[j], cross);
     }
-    if (cross != 0xFFFFFFFFu) atomicMin(s_cross, cross);
     __syncthreads();
-    return *s_cross;        // everything up to and including the crossing bucket stays
+    if (threadIdx.x < (unsigned)nb) {
+        const uint32_t q = s_cross[threadIdx.x];        // everything up to and including the crossing bucket stays
+        if (q < (uint32_t)(OCC_BUCKETS - 1)) {
+            __hip_atomic_store(&occ_cut[blk0 + threadIdx.x], q, OCC_RLX_AGENT);
+            __hip_atomic_store(&hdr->any_closed, 1u, OCC_RLX_AGENT);
+        }
+    }
 }
 
 // ---- recount --------------------------------------------------------------------------------------------------------------
@@ -433,7 +481,7 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
     __shared__ OccLds lds;
     __shared__ OccCand s_cand[OCC_SMALL];
     __shared__ uint8_t s_rank[OCC_SMALL];
-    __shared__ uint32_t s_w[4], s_ws[4], s_ok, s_cross, s_n;
+    __shared__ uint32_t s_w[16], s_ws[4], s_ok, s_cross[4], s_n, s_nz, s_nzq[OCC_SMALL];
     const GeomLayout GL(P);
     OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + GL.occ_hdr);
     uint32_t* hist = reinterpret_cast<uint32_t*>(geom + GL.occ_hdr + sizeof(OccHeader));
@@ -447,19 +495,49 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
     // ... and the sum of the largest weights they could possibly have (a cover's weight over any block is at most the one at its
     // own centre, -log2(1 - min(0.99, opacity))): below the threshold no block can close (BASELINE C3: four heavy Gaussians of
     // ordinary opacity)
+    // (two pairs per load, four loads in flight, and every workgroup starts somewhere else: as a plain strided loop this sum was
+    //  5.6 of the pass's 6.7 us at BASELINE C3 — 15 dependent L2 round trips — and 29 us at C5.)  On the way the workgroups of
+    //  preprocess_kernel that HAVE candidates are noted: the few-candidates path below fetches only their lists
     uint32_t total = 0, wsum = 0;
     const uint2* blk2 = reinterpret_cast<const uint2*>(heavy_blk);
-    for (int q = threadIdx.x; q < n_wg; q += OCC_THREADS) {
-        const uint2 v = blk2[q];
-        total += v.x;
-        wsum = min(wsum + v.y, 0x3FFFFFFFu);
+    if (threadIdx.x == 0) { s_n = 0u; s_nz = 0u; }
+    __syncthreads();
+    {
+        const uint4* blk4 = reinterpret_cast<const uint4*>(heavy_blk);
+        const int n4 = n_wg >> 1;
+        const int rot = n4 ? (int)(((uint32_t)blockIdx.x * 2654435761u) % (uint32_t)n4) : 0;
+        for (int j = threadIdx.x; j < n4; j += 4 * OCC_THREADS) {
+            uint4 v[4];
+            int qs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + u * OCC_THREADS;
+                int q = (jj < n4 ? jj : j) + rot;
+                q = q >= n4 ? q - n4 : q;
+                qs[u] = q;
+                v[u] = blk4[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j + u * OCC_THREADS >= n4) continue;
+                total += v[u].x + v[u].z;
+                wsum = min(wsum + min(v[u].y + v[u].w, 0x1FFFFFFFu), 0x3FFFFFFFu);
+                if (v[u].x) { const uint32_t at = atomicAdd(&s_nz, 1u); if (at < (uint32_t)OCC_SMALL) s_nzq[at] = (uint32_t)(2 * qs[u]); }
+                if (v[u].z) { const uint32_t at = atomicAdd(&s_nz, 1u); if (at < (uint32_t)OCC_SMALL) s_nzq[at] = (uint32_t)(2 * qs[u] + 1); }
+            }
+        }
+        if ((n_wg & 1) && threadIdx.x == 0) {
+            const uint2 v = blk2[n_wg - 1];
+            total += v.x;
+            wsum = min(wsum + v.y, 0x3FFFFFFFu);
+            if (v.x) { const uint32_t at = atomicAdd(&s_nz, 1u); if (at < (uint32_t)OCC_SMALL) s_nzq[at] = (uint32_t)(n_wg - 1); }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         total += (uint32_t)__shfl_xor((int)total, off);
         wsum = min(wsum + (uint32_t)__shfl_xor((int)wsum, off), 0x3FFFFFFFu);
     }
     if (lane == 0) { s_w[wv] = total; s_ws[wv] = wsum; }
-    if (threadIdx.x == 0) s_n = 0u;
     __syncthreads();
     total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     wsum = min(min(s_ws[0] + s_ws[1], 0x3FFFFFFFu) + min(s_ws[2] + s_ws[3], 0x3FFFFFFFu), 0x7FFFFFFFu);
@@ -476,8 +554,9 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
     const int B = 1 << block_log2;
     if (total <= (uint32_t)OCC_SMALL) {
         // ---- few candidates: every workgroup collects ALL of them (the set, not the order, matters: the sums are integers) ...
-        for (int q = threadIdx.x; q < n_wg; q += OCC_THREADS) {
-            if (blk2[q].x == 0u) continue;
+        // (at most OCC_SMALL workgroups of preprocess_kernel hold them: total <= OCC_SMALL)
+        for (int z = threadIdx.x; z < (int)min(s_nz, (uint32_t)OCC_SMALL); z += OCC_THREADS) {
+            const int q = (int)s_nzq[z];
             for (int w4 = 0; w4 < 4; ++w4) {
                 const int slot = 4 * q + w4;
                 const uint32_t c = heavy_count[slot];
@@ -545,12 +624,19 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
         // ---- many candidates: histogram -- barrier -- selection + gather -- barrier -- covers
         for (int q = blockIdx.x * OCC_THREADS + threadIdx.x; q < n_blocks; q += gridDim.x * OCC_THREADS)
             __hip_atomic_store(&occ_cut[q], 0xFFFFu, OCC_RLX_AGENT);
-        for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) occ_hist_chunk(c, heavy_list, heavy_count, n_slots, hist, lds.hist, s_w);
-        if (!occ_grid_barrier<false>(hdr, 0, &s_ok)) return;              // (the histogram: atomics only)
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
+        // (the depth histogram only decides WHICH candidates are kept when there are more than OCC_MAX_CAND: otherwise all are,
+        //  and the first phase and its barrier are skipped — BASELINE C5: 10 751 candidates, 13 us)
+        const bool all_kept = total <= (uint32_t)OCC_MAX_CAND;
+        if (!all_kept) {
+            for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) occ_hist_chunk(c, heavy_list, heavy_count, n_slots, hist, lds.hist, s_w);
+            if (!occ_grid_barrier<false>(hdr, 0, &s_ok)) return;              // (the histogram: atomics only)
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+        }
         {
-            const OccSelect S = occ_select(total, hist, lds.g);
+            OccSelect S;
+            if (all_kept) { S.total = total; S.limit = (uint32_t)(OCC_BUCKETS - 1); S.stride = 1u; S.keep_total = total; S.by_depth = true; }
+            else S = occ_select(total, hist, lds.g);
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 __hip_atomic_store(&hdr->n_cand, S.by_depth ? (total <= (uint32_t)OCC_MAX_CAND ? total : S.keep_total)
                                                              : (total + S.stride - 1) / S.stride, OCC_RLX_AGENT);
@@ -559,18 +645,16 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
             for (int c = blockIdx.x; c < n_chunks; c += gridDim.x)
                 occ_gather_chunk(c, S, P, geom, heavy_list, heavy_count, n_slots, hdr, cand, lds.g);
         }
-        if (!occ_grid_barrier<true>(hdr, 1, &s_ok)) return;               // (the candidate records: plain stores)
+        if (!occ_grid_barrier<false>(hdr, 1, &s_ok)) return;              // (the candidate records: write-through stores)
         if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
         {
             const uint32_t n = min(__hip_atomic_load(&hdr->n_cand, OCC_RLX_AGENT), (uint32_t)OCC_MAX_CAND);
-            for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-                const uint32_t q = occ_cover_block(b, vp, B, nbx, n, cand, lds.hist, s_w, &s_cross);
-                if (threadIdx.x == 0 && q < (uint32_t)(OCC_BUCKETS - 1)) {
-                    __hip_atomic_store(&occ_cut[b], q, OCC_RLX_AGENT);    // (the table started all-open: only proven cut-offs)
-                    __hip_atomic_store(&hdr->any_closed, 1u, OCC_RLX_AGENT);
-                }
-            }
+            // groups of consecutive blocks: as large as keeps every workgroup busy (1080p, 510 blocks: two; 4K, 2040 blocks: four)
+            const int per = max(1, min(OCC_GROUP, (n_blocks + (int)gridDim.x - 1) / (int)gridDim.x));
+            const int n_groups = (n_blocks + per - 1) / per;
+            for (int g = blockIdx.x; g < n_groups; g += gridDim.x)
+                occ_cover_group(g * per, min(per, n_blocks - g * per), vp, B, nbx, n, cand, lds.sums, s_w, s_cross, occ_cut, hdr);
         }
     }
 
