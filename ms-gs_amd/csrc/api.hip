@@ -198,6 +198,15 @@ static bool blocking_sync() {
     return blocking;
 }
 
+// Depth-slab binning for this call?  (msgs_view_t.slab_fraction; include/msgs.h)  Independent of the buffers, which
+// SlabGeom checks.
+static bool slab_wanted(const msgs_view_t* view, const msgs_gaussians_t* g) {
+    const float f = view->slab_fraction;
+    if (!(f > 0.f) || !(f <= 0.5f) || g->P <= 0 || g_deterministic.load() != 0) return false;
+    const int64_t tiles = (int64_t)((view->image_width + TILE - 1) / TILE) * ((view->image_height + TILE - 1) / TILE);
+    return tiles >= SLAB_MIN_TILES && tiles < 65535 * 16 && forward_uses_quadrant_kernel((int)tiles);
+}
+
 // Launches K1, the depth sort and the scan — and, with `spec`, stage 2 right behind them — WITHOUT waiting for D.
 int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, int32_t* radii, float* pixel_sizes,
                           void* geom_v, size_t geom_bytes, void* scratch_v, size_t scratch_bytes,
@@ -257,7 +266,12 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
                                (uint32_t*)(geom + GL.offs), P, (uint64_t*)(scratch + SL.scan_partials), total_dev, s,
                                status_dev, polled ? sb.dev : nullptr, ticket,
                                (const uint32_t*)(geom + GL.nvalid), spec ? clamped_dev : nullptr,
-                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr), heavy_q_word));
+                               spec ? (uint64_t)spec->capacity : 0, (const uint32_t*)(geom + GL.occ_hdr), heavy_q_word, nullptr,
+                               // the counts sit below the Gaussians' coarse cell ranges; a view that may run in depth slabs gets the
+                               // ranges in depth order (in offs_b: slab B's recount reads them and leaves its counts there)
+                               vp.cell_sx >= 0 ? TILE_COUNT_MASK : 0xFFFFFFFFu,
+                               vp.cell_sx >= 0 && slab_wanted(view, g) ? (uint32_t*)(geom + GL.offs_b) : nullptr,
+                               &reinterpret_cast<SlabHeader*>(geom + GL.slab_hdr)->pad[0]));
     tm.end(MSGS_K_SCAN);
     pend.active = true;
     pend.polled = polled;
@@ -357,14 +371,6 @@ int msgs_forward_stage1(const msgs_view_t* view, const msgs_gaussians_t* g, int3
                                timing, stream, nullptr);
 }
 
-// Depth-slab binning for this call?  (msgs_view_t.slab_fraction; include/msgs.h)  Independent of the buffers, which
-// SlabGeom checks.
-static bool slab_wanted(const msgs_view_t* view, const msgs_gaussians_t* g) {
-    const float f = view->slab_fraction;
-    if (!(f > 0.f) || !(f <= 0.5f) || g->P <= 0 || g_deterministic.load() != 0) return false;
-    const int64_t tiles = (int64_t)((view->image_width + TILE - 1) / TILE) * ((view->image_height + TILE - 1) / TILE);
-    return tiles >= SLAB_MIN_TILES && tiles < 65535 * 16 && forward_uses_quadrant_kernel((int)tiles);
-}
 // instance capacities of the caller's stage-2 buffers: ids of `binning`, and what the scratch serves
 static void stage2_capacities(const msgs_view_t* view, size_t binning_bytes, size_t scratch2_bytes, int64_t& cb, int64_t& cs) {
     const int W0 = view->image_width, H0 = view->image_height;
@@ -668,7 +674,7 @@ int forward_stage2_impl(const msgs_view_t* view, const msgs_gaussians_t* g, cons
         // ---------------- slab B: the complete lists of the tiles slab A left open ----------------
         tm.begin(MSGS_K_SLAB_B);
         uint32_t* offs_b = (uint32_t*)(geom + GL.offs_b);
-        HIP_TRY(launch_slab_recount(vp, P, geom, open_bits, D, D_dev, s));
+        HIP_TRY(launch_slab_recount(vp, P, geom, open_bits, open_list, D, D_dev, s));
         HIP_TRY(exclusive_scan_u32(offs_b, nullptr, offs_b, P, (uint64_t*)(geom + GL.scan_b), &hdr->total_b, s, nullptr, nullptr, 0,
                                    (const uint32_t*)(geom + GL.nvalid), &hdr->DB, (uint64_t)cap_b, nullptr, heavy_q, &hdr->pad0));
         ZeroJob zjB{nullptr, 0, nullptr, 0};

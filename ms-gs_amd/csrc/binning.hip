@@ -433,11 +433,23 @@ __global__ __launch_bounds__(256) void slab_split_kernel(int P, char* __restrict
 
 // Slab B's count: per depth rank, the instances that fall into OPEN tiles — the same per-row extents and margin as the count in
 // preprocess_kernel (hence >= what the emit will write there), the same occlusion predicate as recount / emit.  One thread per
-// rank; the bitmap is read through the cache (4 KB at 4K).
+// rank.  Normally a handful of tiles are open and the kernel exists to PROVE that two or three million ranks have nothing in
+// them: the open-tile bitmap sits in LDS (4 KB at 4K; read per tile row of every rect from global memory, 64 lanes on up to 32
+// different lines, the loads were what the kernel waited for: 118 us at BASELINE C5) and in front of it a 64-bit mask of the
+// 8 x 8 coarse screen cells that hold an open tile at all — most rects are answered by four shifts and an AND.
+constexpr int SLAB_LDS_WORDS = 4096;              // bitmap words held in LDS (131 072 tiles); larger grids read global memory
+constexpr int SLAB_FEW_OPEN = 64;                 // up to this many open tiles a Gaussian tests the tiles themselves
+constexpr int SLAB_RECOUNT_GRID = 1024;           // persistent workgroups (four per CU): the bitmap is staged once per workgroup,
+                                                  // not once per 256 ranks (19 531 workgroups at 5 M Gaussians: their prologues —
+                                                  // dependent loads, 4 KB of bitmap, three barriers — were most of the kernel)
 __global__ __launch_bounds__(256) void slab_recount_kernel(ViewParams vp, int P, const char* __restrict__ geom,
-                                                           const uint32_t* __restrict__ open_bits, int64_t D_host,
+                                                           const uint32_t* __restrict__ open_bits,
+                                                           const uint32_t* __restrict__ open_list, int64_t D_host,
                                                            const uint32_t* __restrict__ D_dev, uint32_t* __restrict__ cnt_b) {
     __shared__ OccTable T;
+    __shared__ uint32_t s_open[SLAB_LDS_WORDS];
+    __shared__ uint32_t s_cells[2];
+    __shared__ uint32_t s_list[SLAB_FEW_OPEN];
     const GeomLayout L(P);
     const uint32_t* order = reinterpret_cast<const uint32_t*>(geom + L.order);
     const uint32_t* offs = reinterpret_cast<const uint32_t*>(geom + L.offs);
@@ -445,13 +457,37 @@ __global__ __launch_bounds__(256) void slab_recount_kernel(ViewParams vp, int P,
     const SlabHeader* hdr = reinterpret_cast<const SlabHeader*>(geom + L.slab_hdr);
     const OccHeader* occ = reinterpret_cast<const OccHeader*>(geom + L.occ_hdr);
     const int V = (int)*reinterpret_cast<const uint32_t*>(geom + L.nvalid);
-    const int r0 = blockIdx.x * blockDim.x;
-    if (r0 >= V) return;
-    const int r = r0 + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= V) return;
     const uint32_t n_open = hdr->n_open;                                       // final: blend A has completed
     if (n_open == 0u) {                                                        // nothing left open: slab B is empty
-        if (r < V) cnt_b[r] = 0u;
+        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < V; r += gridDim.x * blockDim.x) cnt_b[r] = 0u;
         return;
+    }
+    const int n_tiles = vp.gx * vp.gy;
+    const int n_words = (n_tiles + 31) / 32;
+    const bool in_lds = n_words <= SLAB_LDS_WORDS;                             // workgroup-uniform
+    // coarse cells: 2^cs x 2^ct tiles each, at most 8 x 8 of them (ViewParams: the same shifts as preprocess_kernel's ranges)
+    const bool ranged = vp.cell_sx >= 0 && hdr->pad[0] == 1u;       // (pad[0]: the scan of THIS forward delivered the ranges)
+    const int cs = vp.cell_sx, ct = vp.cell_sy;
+    const bool use_cells = ranged && in_lds && n_open <= 1024u;                // (many open tiles: every cell is set anyway)
+    if (threadIdx.x < 2) s_cells[threadIdx.x] = use_cells ? 0u : 0xFFFFFFFFu;
+    // a handful of open tiles (the rule): a Gaussian that passes the cell test walks THEM, not the rows of its rect — the
+    // multi-scale levels' giants have rects of a hundred rows, one lane of their wave walked them alone (80 us at BASELINE C5)
+    const bool few = n_open <= (uint32_t)SLAB_FEW_OPEN && open_list != nullptr;
+    if (few && threadIdx.x < n_open) { const uint32_t t = open_list[threadIdx.x]; s_list[threadIdx.x] = (t % (uint32_t)vp.gx) | ((t / (uint32_t)vp.gx) << 16); }
+    __syncthreads();
+    if (in_lds) {
+        for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+            uint32_t m = open_bits[w];
+            if (w == n_words - 1 && (n_tiles & 31)) m &= 0xFFFFFFFFu >> (32 - (n_tiles & 31));
+            s_open[w] = m;
+            while (use_cells && m) {
+                const int t = 32 * w + __ffs((int)m) - 1;
+                m &= m - 1u;
+                const int cell = ((t / vp.gx) >> ct) * 8 + ((t % vp.gx) >> cs);
+                atomicOr(&s_cells[cell >> 5], 1u << (cell & 31));
+            }
+        }
     }
     const bool occ_on = occ->enabled != 0u && occ->any_closed != 0u;
     const int occ_lb = (int)occ->block_log2, occ_nbx = (int)occ->nbx;
@@ -460,44 +496,61 @@ __global__ __launch_bounds__(256) void slab_recount_kernel(ViewParams vp, int P,
         occ_table_load(T, reinterpret_cast<const uint32_t*>(geom + L.occ_cut), occ_nbx, (int)occ->nby);
         cut_min = T.cut_min;
     }
-    if (r >= V) return;
+    __syncthreads();
+    const uint64_t cells = (uint64_t)s_cells[0] | ((uint64_t)s_cells[1] << 32);
+    auto open_count = [&](uint32_t a, uint32_t b) { return in_lds ? open_in_range(s_open, a, b) : open_in_range(open_bits, a, b); };
     const int64_t D = D_dev ? (int64_t)*D_dev : D_host;
-    const uint32_t full = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - (int64_t)offs[r]);
-    uint32_t c = 0;
-    if (full) {
-        const uint32_t gi = order[r];
-        const float4 q1 = binrec[gi].q1, q0 = binrec[gi].q0;         // (one 32-byte line)
-        const uint32_t kmine = cut_min != 0xFFFFFFFFu ? occ_bucket(reinterpret_cast<const uint32_t*>(geom + L.skey)[r]) : 0u;
-        const bool cut_check = kmine > cut_min;
-        const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
-        const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
-        const float tau2 = q1.y;
-        const bool test = tau2 > -1.0e38f;
-        LevelSetRows ls{};
-        bool ls_ready = false;
-        for (int ty = miny; ty < maxy; ++ty) {
-            if (cut_check && T.rowmax[ty >> occ_lb] < kmine) continue;
-            const uint32_t row = (uint32_t)(ty * vp.gx);
-            // (normally a handful of tiles are open: no open tile in this row of the rect -> no extent to compute)
-            if (open_in_range(open_bits, row + (uint32_t)minx, row + (uint32_t)(maxx - 1)) == 0u) continue;
-            if (test && !ls_ready) { ls = levelset_rows_setup(q0.z, q0.w, q1.x, tau2); ls_ready = true; }
-            int tlo = minx, thi = maxx - 1;
-            if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi)) continue;
-            if (tlo > thi) continue;
-            if (!cut_check) {
-                c += open_in_range(open_bits, row + (uint32_t)tlo, row + (uint32_t)thi);
-            } else {
-                const int brow = (ty >> occ_lb) * occ_nbx;
-                for (int tx = tlo; tx <= thi;) {
-                    const int bend = min(thi, (((tx >> occ_lb) + 1) << occ_lb) - 1);
-                    if (T.cut[brow + (tx >> occ_lb)] >= kmine) c += open_in_range(open_bits, row + (uint32_t)tx, row + (uint32_t)bend);
-                    tx = bend + 1;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < V; r += gridDim.x * blockDim.x) {
+        const uint32_t full = (uint32_t)((r + 1 < V ? (int64_t)offs[r + 1] : D) - (int64_t)offs[r]);
+        uint32_t c = 0;
+        // the coarse cells this rank's rect touches came with the scan (depth order, in cnt_b itself): only a Gaussian that
+        // touches a cell with an open tile fetches its record — a random 32-byte gather per rank otherwise
+        if (full && (!ranged || (cell_range_mask(cnt_b[r]) & cells))) {
+            const uint32_t gi = order[r];
+            const float4 q1 = binrec[gi].q1, q0 = binrec[gi].q0;         // (one 32-byte line)
+            const uint32_t rcx = __float_as_uint(q1.z), rcy = __float_as_uint(q1.w);
+            const int minx = rcx & 0xFFFF, miny = rcx >> 16, maxx = rcy & 0xFFFF, maxy = rcy >> 16;
+            const uint32_t kmine = cut_min != 0xFFFFFFFFu ? occ_bucket(reinterpret_cast<const uint32_t*>(geom + L.skey)[r]) : 0u;
+            const bool cut_check = kmine > cut_min;
+            const float tau2 = q1.y;
+            const bool test = tau2 > -1.0e38f;
+            LevelSetRows ls{};
+            bool ls_ready = false;
+            if (few) {
+                for (uint32_t k = 0; k < n_open; ++k) {
+                    const int tx = (int)(s_list[k] & 0xFFFFu), ty = (int)(s_list[k] >> 16);
+                    if (tx < minx || tx >= maxx || ty < miny || ty >= maxy) continue;
+                    if (cut_check && T.cut[(ty >> occ_lb) * occ_nbx + (tx >> occ_lb)] < kmine) continue;
+                    if (test && !ls_ready) { ls = levelset_rows_setup(q0.z, q0.w, q1.x, tau2); ls_ready = true; }
+                    int tlo = minx, thi = maxx - 1;
+                    if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi)) continue;
+                    c += (tx >= tlo && tx <= thi) ? 1u : 0u;
+                }
+            } else
+            for (int ty = miny; ty < maxy; ++ty) {
+                if (cut_check && T.rowmax[ty >> occ_lb] < kmine) continue;
+                const uint32_t row = (uint32_t)(ty * vp.gx);
+                // (no open tile in this row of the rect -> no extent to compute)
+                if (open_count(row + (uint32_t)minx, row + (uint32_t)(maxx - 1)) == 0u) continue;
+                if (test && !ls_ready) { ls = levelset_rows_setup(q0.z, q0.w, q1.x, tau2); ls_ready = true; }
+                int tlo = minx, thi = maxx - 1;
+                if (test && !levelset_row_interval(ls, q0.x, q0.y, ty, minx, maxx, LEVELSET_MARGIN_COUNT, tlo, thi)) continue;
+                if (tlo > thi) continue;
+                if (!cut_check) {
+                    c += open_count(row + (uint32_t)tlo, row + (uint32_t)thi);
+                } else {
+                    const int brow = (ty >> occ_lb) * occ_nbx;
+                    for (int tx = tlo; tx <= thi;) {
+                        const int bend = min(thi, (((tx >> occ_lb) + 1) << occ_lb) - 1);
+                        if (T.cut[brow + (tx >> occ_lb)] >= kmine) c += open_count(row + (uint32_t)tx, row + (uint32_t)bend);
+                        tx = bend + 1;
+                    }
                 }
             }
+            c = min(c, full);    // (a subset of the first count's tiles; the clamp only guards the scan against a rounding surprise)
         }
-        c = min(c, full);        // (a subset of the first count's tiles; the clamp only guards the scan against a rounding surprise)
+        cnt_b[r] = c;
     }
-    cnt_b[r] = c;
 }
 
 }  // namespace
@@ -560,11 +613,11 @@ hipError_t launch_slab_split(int P, char* geom, int64_t D, const uint32_t* D_dev
     return hipGetLastError();
 }
 
-hipError_t launch_slab_recount(const ViewParams& vp, int P, char* geom, const uint32_t* open_bits, int64_t D,
+hipError_t launch_slab_recount(const ViewParams& vp, int P, char* geom, const uint32_t* open_bits, const uint32_t* open_list, int64_t D,
                                const uint32_t* D_dev, hipStream_t s) {
     if (P == 0) return hipSuccess;
     const GeomLayout L(P);
-    hipLaunchKernelGGL(slab_recount_kernel, dim3((P + 255) / 256), dim3(256), 0, s, vp, P, (const char*)geom, open_bits, D, D_dev,
+    hipLaunchKernelGGL(slab_recount_kernel, dim3(std::min((P + 255) / 256, SLAB_RECOUNT_GRID)), dim3(256), 0, s, vp, P, (const char*)geom, open_bits, open_list, D, D_dev,
                        reinterpret_cast<uint32_t*>(geom + L.offs_b));
     return hipGetLastError();
 }

@@ -537,7 +537,25 @@ struct ViewParams {            // by-value kernel argument
     const float* viewmatrix;
     const float* projmatrix;
     const float* campos;
+    int cell_sx, cell_sy;         // log2 of the tiles per coarse screen cell (at most 8 x 8 cells), -1: no cell ranges (below)
 };
+
+// Coarse cell range of a Gaussian's tile rect, packed into the 12 bits above its tile count in GeomLayout::tiles (a count is at
+// most gx * gy < 2^20 whenever the ranges are used): { first column, last column, first row, last row } of the 8 x 8 coarse cells
+// the rect touches, 3 bits each.  The scan of the counts gathers tiles[] through the depth order anyway; in slab mode it hands
+// the ranges on in depth order, and slab B's recount answers "nothing of this Gaussian lies in a cell with an open tile" from
+// them without fetching the Gaussian's record (binning.hip).
+constexpr uint32_t TILE_COUNT_BITS = 20, TILE_COUNT_MASK = (1u << TILE_COUNT_BITS) - 1u;
+__host__ __device__ inline uint32_t cell_range_pack(int minx, int miny, int maxx, int maxy, int sx, int sy) {   // rect: [min, max)
+    return (uint32_t)(minx >> sx) | ((uint32_t)((maxx - 1) >> sx) << 3) | ((uint32_t)(miny >> sy) << 6) | ((uint32_t)((maxy - 1) >> sy) << 9);
+}
+__host__ __device__ inline uint64_t cell_range_mask(uint32_t packed) {
+    const uint32_t c0 = packed & 7u, c1 = (packed >> 3) & 7u, r0 = (packed >> 6) & 7u, r1 = (packed >> 9) & 7u;
+    const uint64_t cols = ((2ull << c1) - (1ull << c0)) & 0xFFull;
+    uint64_t m = 0;
+    for (uint32_t r = r0; r <= r1; ++r) m |= cols << (8u * r);
+    return m;
+}
 
 inline ViewParams make_view_params(const msgs_view_t* v) {
     ViewParams p;
@@ -549,6 +567,12 @@ inline ViewParams make_view_params(const msgs_view_t* v) {
     p.sh_degree = v->sh_degree; p.sh_coeffs = v->sh_coeffs;
     p.filter_small = v->filter_small; p.filter_large = v->filter_large;
     p.bg = v->bg; p.viewmatrix = v->viewmatrix; p.projmatrix = v->projmatrix; p.campos = v->campos;
+    p.cell_sx = p.cell_sy = -1;
+    if ((int64_t)p.gx * p.gy < (int64_t)(1u << TILE_COUNT_BITS)) {
+        p.cell_sx = p.cell_sy = 0;
+        while ((p.gx + (1 << p.cell_sx) - 1) >> p.cell_sx > 8) ++p.cell_sx;
+        while ((p.gy + (1 << p.cell_sy) - 1) >> p.cell_sy > 8) ++p.cell_sy;
+    }
     return p;
 }
 
@@ -601,13 +625,16 @@ bool radix_sort_supports_device_count(int64_t n, int begin_bit, int end_bit);
 
 // out[r] = exclusive sum of in[gather ? gather[r] : r]; *total (device, u64) = grand total
 // n_ptr (optional, device word): the number of elements actually scanned, <= n (n sizes the grids)
+// in_mask / side_out (gathered scans only): the scanned value is in[gather[i]] & in_mask, and side_out[i] — when given —
+// receives in[gather[i]] >> TILE_COUNT_BITS (the cell ranges of GeomLayout::tiles, in depth order)
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials /* scan_blocks(n)+2 */, uint64_t* total, hipStream_t s,
                               uint64_t* status = nullptr, uint64_t* host_mapped = nullptr, uint64_t ticket = 0,
                               const uint32_t* n_ptr = nullptr, uint32_t* clamped_total = nullptr, uint64_t clamp = 0,
                               const uint32_t* extra = nullptr,    // extra: two device words forwarded with the status
                               uint32_t* zero_word = nullptr,      // zero_word: one device word cleared on behalf of a later launch
-                              uint32_t* overflow_flag = nullptr); // set to 1 when the total exceeds `clamp`
+                              uint32_t* overflow_flag = nullptr, uint32_t in_mask = 0xFFFFFFFFu, uint32_t* side_out = nullptr,
+                              uint32_t* side_flag = nullptr);    // side_flag: set to 1 when side_out was written // set to 1 when the total exceeds `clamp`
 // device-side fill with zeros (sort.hip): an ordinary kernel launch — hipMemsetAsync costs ~10 us of queue latency per
 // call on this runtime (barrier packets around the fill), four of them per step were 3 % of the C3 step
 hipError_t launch_zero(void* ptr, size_t bytes, hipStream_t s);     // ptr and bytes multiples of 4
@@ -625,7 +652,7 @@ hipError_t launch_emit(const ViewParams& vp, int P, const char* geom, uint32_t* 
 hipError_t launch_slab_split(int P, char* geom, int64_t D, const uint32_t* D_dev, float fraction, uint32_t* open_bits,
                              int num_tiles, hipStream_t s);
 // slab mode, behind slab A's blend: GeomLayout::offs_b[r] = instances of rank r in open tiles (not yet scanned)
-hipError_t launch_slab_recount(const ViewParams& vp, int P, char* geom, const uint32_t* open_bits, int64_t D,
+hipError_t launch_slab_recount(const ViewParams& vp, int P, char* geom, const uint32_t* open_bits, const uint32_t* open_list, int64_t D,
                                const uint32_t* D_dev, hipStream_t s);
 // heavy_q (Stage2Scratch::heavy_q; word 0 must be zero when the launch starts): Gaussians with more than EMIT_HEAVY_MIN
 // instances in blocks that write straight to HBM are queued and emitted by a second launch, one workgroup per Gaussian

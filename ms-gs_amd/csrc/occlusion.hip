@@ -403,7 +403,9 @@ __device__ __forceinline__ void occ_recount_chunk(int chunk, const ViewParams& v
     const int i = chunk * OCC_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0, k = 0;
-    if (i < P) { cnt = tiles[i]; k = occ_bucket(key[i]); }             // k: this Gaussian's depth bucket
+    uint32_t cells = 0;                                                  // (the coarse cell range above the count stays)
+    const uint32_t cmask = vp.cell_sx >= 0 ? TILE_COUNT_MASK : 0xFFFFFFFFu;
+    if (i < P) { cnt = tiles[i]; cells = cnt & ~cmask; cnt &= cmask; k = occ_bucket(key[i]); }   // k: this Gaussian's depth bucket
     const bool affected = cnt > 0 && k > cut_min;
     const bool all_behind = affected && k > cut_max;                    // behind the cut-off of EVERY block (none stayed open)
     const bool work = affected && !all_behind;
@@ -467,7 +469,7 @@ __device__ __forceinline__ void occ_recount_chunk(int chunk, const ViewParams& v
         if (lane == src) newcnt = c;
     }
     if (affected) {
-        tiles[i] = newcnt;
+        tiles[i] = newcnt | cells;
         if (newcnt == 0) key[i] = 0xFFFFFFFFu;                          // leaves the (compacting) depth sort
     }
 }

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
 
     int32_t out_radius = 0;
     float out_psize = 0.f;
-    uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu, out_flags = 0;
+    uint32_t out_tiles = 0, out_cells = 0, out_key = 0xFFFFFFFFu, out_flags = 0;
     float out_weight = 0.f, out_tau2 = -3.0e38f;
 
     // ---- phase A: geometry, pixel size, multi-scale filters (one lane per Gaussian) ----
@@ -656,6 +656,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
             binrec[i].q0 = make_float4(px, py, sA, sBh);
             binrec[i].q1 = make_float4(sC, tau2, __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
                                        __uint_as_float((uint32_t)maxx | ((uint32_t)maxy << 16)));
+            if (vp.cell_sx >= 0)          // the coarse cells of the rect ride above the count (msgs_internal.h, cell_range_pack)
+                out_cells = cell_range_pack(minx, miny, maxx, maxy, vp.cell_sx, vp.cell_sy) << TILE_COUNT_BITS;
         }
         out_radius = (int32_t)my_radius;
         out_tau2 = tau2;
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(ViewParams vp, msgs_gau
     if (in_range) {
         radii[i] = out_radius;
         pixel_sizes[i] = out_psize;
-        tiles[i] = out_tiles;
+        tiles[i] = out_tiles | out_cells;
         key[i] = out_key;
         flags[i] = out_flags;
         weight[i] = out_weight;

@@ -85,9 +85,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
                                                                    const uint32_t* __restrict__ gather,
                                                                    int64_t n, uint64_t* __restrict__ partials,
                                                                    uint32_t* __restrict__ staged,
-                                                                   const uint32_t* __restrict__ n_ptr) {
+                                                                   const uint32_t* __restrict__ n_ptr, uint32_t in_mask,
+                                                                   uint32_t* __restrict__ side_out, uint32_t* __restrict__ side_flag) {
     __shared__ uint32_t s_wave[4];
     if (n_ptr) n = (int64_t)*n_ptr;
+    if (side_flag && blockIdx.x == 0 && threadIdx.x == 0) *side_flag = 1u;
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     if (gather) {
@@ -95,6 +97,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
         scan_load_items(gather, base, n, g);
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < n ? in[g[k]] : 0u;
+        if (side_out) {                     // what travels above the scanned bits (GeomLayout::tiles: the cell ranges)
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) g[k] = v[k] >> TILE_COUNT_BITS;
+            scan_store_items(side_out, base, n, g);
+        }
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] &= in_mask;
         if (staged) scan_store_items(staged, base, n, v);
     } else {
         scan_load_items(in, base, n, v);
@@ -403,7 +412,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT*
 hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                               uint64_t* partials, uint64_t* total, hipStream_t s, uint64_t* status,
                               uint64_t* host_mapped, uint64_t ticket, const uint32_t* n_ptr, uint32_t* clamped_total,
-                              uint64_t clamp, const uint32_t* extra, uint32_t* zero_word, uint32_t* overflow_flag) {
+                              uint64_t clamp, const uint32_t* extra, uint32_t* zero_word, uint32_t* overflow_flag,
+                              uint32_t in_mask, uint32_t* side_out, uint32_t* side_flag) {
+    if ((in_mask != 0xFFFFFFFFu || side_out) && gather == nullptr) return hipErrorInvalidValue;
     if (n <= 0) {       // nothing to scan: one block publishes a total of zero (no partials are read)
         hipLaunchKernelGGL(scan_apply_fused_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, in, out, (int64_t)0,
                            (const uint64_t*)partials, (int64_t)0, (const uint32_t*)nullptr, total, status,
@@ -415,7 +426,7 @@ hipError_t exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32
     // with a gather the first pass leaves the gathered values in `out` and the second pass scans `out` in place
     const bool stage = gather != nullptr;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, gather, n, partials,
-                       stage ? out : (uint32_t*)nullptr, n_ptr);
+                       stage ? out : (uint32_t*)nullptr, n_ptr, in_mask, side_out, side_out ? side_flag : (uint32_t*)nullptr);
     hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s,
                        stage ? (const uint32_t*)out : in, out, n, (const uint64_t*)partials, nb, n_ptr, total, status,
                        (volatile uint64_t*)host_mapped, ticket, clamped_total, clamp, extra, zero_word, overflow_flag);

@@ -209,7 +209,12 @@ def test_config_c5_stress_4k():
     bg = torch.tensor([0.0, 0.0, 0.0])
     W, H = cam.image_width, cam.image_height
     dL = scenes.grad_seed(W, H, 5)
-    out, pc, m2 = hip_render(sc, cam, st, bg, dL)
+    import diff_gaussian_rasterization as dgr
+    prev, dgr.slab_policy = dgr.slab_policy, "never"     # the checksum below reads the single-pass list layout (an earlier test of
+    try:                                                 # this process may have published D / D_trav for this view shape:
+        out, pc, m2 = hip_render(sc, cam, st, bg, dL)    # tests/test_slab_gpu.py covers the slab layout)
+    finally:
+        dgr.slab_policy = prev
     ctx = out["render"].grad_fn
     geom, binning, image, D = ctx.state
     assert D > 10_000_000
