@@ -49,17 +49,13 @@ __device__ __forceinline__ uint32_t open_in_range(const uint32_t* __restrict__ b
 }
 
 // OutT: the element type of the key array in HBM — uint16_t when the tile sort runs on 16-bit keys (radix_sort_keys16_ok)
-template <int EMIT_STAGE, typename KeyT, typename OutT = uint32_t, bool SLAB_B = false>
-__global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
-                                                   OutT* __restrict__ keys, uint32_t* __restrict__ ids,
-                                                   int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev,
-                                                   uint32_t* __restrict__ heavy_q, SlabArgs sl) {
+// emit_rank_block: the work of ONE block of 256 consecutive depth ranks (rank block `bx`); every `return` is workgroup-uniform.
+template <int EMIT_STAGE, typename KeyT, typename OutT, bool SLAB_B>
+__device__ __forceinline__ void emit_rank_block(const int bx, const ViewParams& vp, int P, const char* __restrict__ geom,
+                                                OutT* __restrict__ keys, uint32_t* __restrict__ ids,
+                                                int64_t D, const uint32_t* __restrict__ D_dev,
+                                                uint32_t* __restrict__ heavy_q, const SlabArgs& sl) {
     // ranks 0 .. V-1 of the depth order are the Gaussians that stayed in the compacting depth sort (GeomLayout::nvalid)
-    {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
-        const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
-        for (size_t t = t0; t < zj.n0; t += nt) zj.p0[t] = 0u;
-        for (size_t t = t0; t < zj.n1; t += nt) zj.p1[t] = 0u;
-    }
     __shared__ KeyT s_keys[EMIT_STAGE];
     __shared__ uint8_t s_own[EMIT_STAGE];
     __shared__ uint32_t s_gi[256];
@@ -78,7 +74,7 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
 
     if (D_dev) D = (int64_t)*D_dev;      // speculative stage 2: min(instance count, capacity), from the scan
     const int V = (int)(sl.V_dev ? *sl.V_dev : *reinterpret_cast<const uint32_t*>(geom + L.nvalid));
-    const int r0 = blockIdx.x * blockDim.x;
+    const int r0 = bx * (int)blockDim.x;
     if (r0 >= V) return;
     if (SLAB_B) {       // normally a handful of tiles are open: most workgroups have nothing to emit and learn it from two words
         const int64_t lo = offs[r0], hi = r0 + (int)blockDim.x < V ? (int64_t)offs[r0 + blockDim.x] : D;
@@ -242,6 +238,21 @@ __global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const c
     }
 }
 
+template <int EMIT_STAGE, typename KeyT, typename OutT = uint32_t, bool SLAB_B = false>
+__global__ __launch_bounds__(256) void emit_kernel(ViewParams vp, int P, const char* __restrict__ geom,
+                                                   OutT* __restrict__ keys, uint32_t* __restrict__ ids,
+                                                   int64_t D, ZeroJob zj, const uint32_t* __restrict__ D_dev,
+                                                   uint32_t* __restrict__ heavy_q, SlabArgs sl) {
+    {   // housekeeping for the launches that follow: the tile sort's group-sum table and the tile-range array
+        const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+        for (size_t t = t0; t < zj.n0; t += nt) zj.p0[t] = 0u;
+        for (size_t t = t0; t < zj.n1; t += nt) zj.p1[t] = 0u;
+    }
+    // (slab B on a capped grid that walks the rank blocks was tried: 2048 workgroups x 9.5 blocks 50 us against 40 us for 19 531
+    //  workgroups that mostly learn from two words that they have nothing to emit — fewer workgroups hide less latency)
+    emit_rank_block<EMIT_STAGE, KeyT, OutT, SLAB_B>((int)blockIdx.x, vp, P, geom, keys, ids, D, D_dev, heavy_q, sl);
+}
+
 // One workgroup per queued Gaussian (emit_kernel above): all four waves compute the Gaussian's row extents (lane <-> tile row,
 // 64 rows at a time) and the exclusive scan of the rows' instance counts, so every wave knows where every row starts without
 // talking to the others; wave w then writes the rows r with r % 4 == w, lanes on consecutive tiles.  Behind an occlusion cut-off
@@ -351,7 +362,10 @@ __global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ ke
                                                      uint2* __restrict__ ranges, int num_tiles,
                                                      const uint32_t* __restrict__ D_dev, uint32_t base) {
     if (D_dev) D = (int64_t)*D_dev;
-    const int64_t i0 = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    // (capped grid: a launch sized for a worst-case capacity whose device count is small costs its workgroups' exits otherwise —
+    //  53 k workgroups, 16 us, for slab B's 10 k instances at BASELINE C5)
+    for (int64_t blk = blockIdx.x; blk * (4 * (int64_t)blockDim.x) < D; blk += gridDim.x) {
+    const int64_t i0 = 4 * (blk * blockDim.x + threadIdx.x);
     const int lane = threadIdx.x & 63;
     const bool full = i0 + 3 < D;
     uint32_t k[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ ke
     }
     // key in front of k[0] / behind k[3] (every lane takes part in the shuffles)
     uint32_t prev = (uint32_t)__shfl_up((int)k[3], 1), next = (uint32_t)__shfl_down((int)k[0], 1);
-    if (i0 >= D) return;
+    if (i0 >= D) continue;
     if (lane == 0) prev = i0 > 0 ? (uint32_t)keys[i0 - 1] : 0xFFFFFFFFu;
     if (lane == 63) next = i0 + 4 < D ? (uint32_t)keys[i0 + 4] : 0xFFFFFFFFu;
     const uint32_t nt = (uint32_t)num_tiles;
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(256) void ranges_kernel(const KeyT* __restrict__ ke
         const uint32_t after = (j == 3 || i + 1 >= D) ? (j == 3 ? next : 0xFFFFFFFFu) : k[j + 1];
         if (i == 0 || before != t) ranges[t].x = base + (uint32_t)i;           // base: where this key array's ids start in `ids`
         if (i == D - 1 || after != t) ranges[t].y = base + (uint32_t)(i + 1);
+    }
     }
 }
 
@@ -629,7 +644,7 @@ hipError_t launch_ranges(const uint32_t* keys, int64_t D, uint2* ranges, int num
         if (e != hipSuccess) return e;
     }
     if (D == 0) return hipSuccess;
-    const dim3 grid((unsigned)((D + 1023) / 1024)), block(256);
+    const dim3 grid((unsigned)std::min<int64_t>((D + 1023) / 1024, 8192)), block(256);
     if (keys16)
         hipLaunchKernelGGL(ranges_kernel<uint16_t>, grid, block, 0, s, reinterpret_cast<const uint16_t*>(keys), D, ranges, num_tiles,
                            D_dev, base);
