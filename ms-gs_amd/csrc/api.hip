@@ -229,7 +229,7 @@ int forward_stage1_launch(const msgs_view_t* view, const msgs_gaussians_t* g, in
 
     // K1 also clears the depth sort's group-sum table (saves a fill launch) and the header of the occlusion cut-off
     // (enabled = 0, no candidates: what the emit reads when the pass does not run)
-    ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.slab_hdr), (GL.occ_hdr - GL.slab_hdr) / 4 + sizeof(OccHeader) / 4 + (size_t)OCC_BUCKETS};
+    ZeroJob zj1{nullptr, 0, (uint32_t*)(geom + GL.slab_hdr), (GL.occ_hdr - GL.slab_hdr) / 4 + sizeof(OccHeader) / 4 + 2 * (size_t)OCC_BUCKETS};
     const bool sort1_prezeroed = radix_sort_zero_region(P, 0, 32, scratch + SL.sort, &zj1.p0, &zj1.n0);
     // exact per-tile occlusion cut-off (occlusion.hip): on unless switched off
     const bool occlusion = get_occlusion() != 0;

@@ -123,7 +123,7 @@ struct GeomLayout {
         skey = o;   o = align256(o + 4 * P);        // depth keys in depth order (the sort's key output): emit's cut-off test
         slab_hdr = o; o += 256;                     // SlabHeader, directly in front of the occlusion header: K1 clears both with
                                                     // one range
-        occ_hdr = o; o = align256(o + sizeof(OccHeader) + 4 * (size_t)OCC_BUCKETS);   // header + depth histogram of the
+        occ_hdr = o; o = align256(o + sizeof(OccHeader) + 8 * (size_t)OCC_BUCKETS);   // header + depth histogram + fill counters of the
                                                                                         // cover candidates (both cleared by K1)
         occ_cut = o; o = align256(o + 4 * (size_t)OCC_MAX_BLOCKS);  // cut-off depth bucket per cover block (0xFFFF = open)
         offs_b = o; o = align256(o + 4 * P);        // slab B: per depth rank, instances in open tiles -> their exclusive scan

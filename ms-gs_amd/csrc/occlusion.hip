@@ -30,8 +30,10 @@
 //     bucket, and its waves take the tile blocks one each: lane <-> candidate, one 64-lane prefix sum, the bucket of the lane
 //     at which the product crosses;
 //   more: the phases of round 5 behind grid barriers — (only with more than OCC_MAX_CAND candidates: depth histogram of the
-//     candidates -- barrier -- keep the nearest OCC_MAX_CAND, whole depth buckets) gather the records -- barrier -- per group of
-//     up to four blocks of tiles: one walk over the records, bucketed sums of -log2(1 - alpha_min), prefix, cut-off bucket.
+//     candidates -- barrier -- keep the nearest OCC_MAX_CAND, whole depth buckets) gather the records (then: in depth-bucket
+//     order) -- barrier -- per group of up to four blocks of tiles: one walk over the records, bucketed sums of
+//     -log2(1 - alpha_min), prefix, cut-off bucket; over depth-ordered records the walk stops when every block of the group has
+//     its 14.3 bits (the filters-off multi-scale model: 185 k heavy Gaussians, 32 k kept, closed within the nearest few hundred).
 // Then ONE more grid barrier, behind which every workgroup knows whether anything closed: if not (the rule), it leaves; if so,
 // the Gaussians behind the nearest cut-off recount their tile instances (index order, tiles[] / key[] in place; a Gaussian left
 // without instances leaves the depth sort: key 0xFFFFFFFF).  The pass runs on EVERY forward, and the wrapper's adaptive skip
@@ -117,6 +119,8 @@ struct OccGatherLds {
     uint16_t kept[OCC_GATHER_SLOTS * 64];     // (local slot << 6) | index in the slot
     uint32_t prefix[OCC_GATHER_SLOTS];
     uint32_t red[4], scan[4], kappa, keep, base;
+    uint32_t start[OCC_BUCKETS];              // depth-ordered gather: first record position of every depth bucket (view-wide)
+    uint32_t place[OCC_BUCKETS];              // ... and, per chunk, the chunk's count per bucket -> its next free position
 };
 constexpr int OCC_SMALL = 64;               // up to this many candidates every workgroup handles the whole view's covers itself
 union OccLds {
@@ -155,7 +159,7 @@ __device__ __forceinline__ void occ_hist_chunk(int chunk, const uint32_t* __rest
 // chunk — the ORDER of the records is irrelevant, the cover sums are integers; the SET is deterministic) and gathers their
 // records.  When the nearest non-empty bucket alone holds more than fit (thousands of covers at one depth), every stride-th
 // candidate in index order is kept instead: positions by formula from all slot counts.
-struct OccSelect { uint32_t total, limit, stride, keep_total; bool by_depth; };
+struct OccSelect { uint32_t total, limit, stride, keep_total; bool by_depth, ordered; };
 __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* hist, OccGatherLds& L) {
     // deepest bucket kappa with (candidates in buckets <= kappa) <= OCC_MAX_CAND; thread t owns PER consecutive buckets
     constexpr int PER = OCC_BUCKETS / OCC_THREADS;
@@ -168,6 +172,7 @@ __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* 
     uint32_t best = 0xFFFFFFFFu, keep = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
+        L.start[threadIdx.x * PER + k] = run;                           // exclusive prefix: where this bucket's records start
         run += hv[k];
         if (hv[k] && run <= (uint32_t)OCC_MAX_CAND) { best = (uint32_t)(threadIdx.x * PER + k); keep = run; }
     }
@@ -181,6 +186,7 @@ __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* 
     S.by_depth = total <= (uint32_t)OCC_MAX_CAND || L.kappa != 0xFFFFFFFFu;
     S.limit = total <= (uint32_t)OCC_MAX_CAND ? (uint32_t)(OCC_BUCKETS - 1) : L.kappa;
     S.stride = S.by_depth ? 1u : (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND;
+    S.ordered = S.by_depth;      // a selection by depth places the records in depth-bucket order (occ_gather_chunk)
     __syncthreads();
     return S;
 }
@@ -188,7 +194,7 @@ __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* 
 __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, int P, const char* __restrict__ geom,
                                                  const uint32_t* __restrict__ heavy_list,
                                                  const uint32_t* __restrict__ heavy_count, int n_slots, OccHeader* hdr,
-                                                 OccCand* cand, OccGatherLds& L) {
+                                                 OccCand* cand, OccGatherLds& L, uint32_t* __restrict__ fill) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int slot0 = chunk * OCC_GATHER_SLOTS;
     const int slot = slot0 + threadIdx.x;
@@ -225,7 +231,22 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
     L.prefix[threadIdx.x] = first;
     uint32_t kept_total;
     uint32_t at = block_exclusive_256(kept, L.scan, &kept_total);       // <= 256 * 64 entries
-    if (S.by_depth) {
+    if (S.ordered) {
+        // depth-ordered placement: the chunk counts its kept candidates per bucket (LDS), reserves a run of positions in every
+        // non-empty bucket with ONE atomic on the view's fill counter (cleared by preprocess_kernel), and its candidates take
+        // the positions start[bucket] + run + rank.  The order INSIDE a bucket is arbitrary — the cover sums are per bucket
+        for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) L.place[k] = 0u;
+        __syncthreads();
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t bk = occ_bucket(ent[(size_t)slot * 64 + j].y);
+            if (bk <= S.limit) { L.kept[at++] = (uint16_t)((threadIdx.x << 6) | j); atomicAdd(&L.place[bk], 1u); }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) {
+            const uint32_t c = L.place[k];
+            if (c) L.place[k] = L.start[k] + atomicAdd(&fill[k], c);
+        }
+    } else if (S.by_depth) {
         for (uint32_t j = 0; j < cnt; ++j)
             if (occ_bucket(ent[(size_t)slot * 64 + j].y) <= S.limit) L.kept[at++] = (uint16_t)((threadIdx.x << 6) | j);
         if (threadIdx.x == 0) L.base = kept_total ? atomicAdd(&hdr->n_written, kept_total) : 0u;
@@ -247,7 +268,8 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
         c.rect_lo = __float_as_uint(b.q1.z);                                          // minx | miny << 16   (tiles)
         c.rect_hi = __float_as_uint(b.q1.w);                                          // maxx | maxy << 16   (exclusive)
         c.pad0 = c.pad1 = 0u;
-        const uint32_t pos = S.by_depth ? L.base + e : (L.prefix[ls] + j) / S.stride;
+        const uint32_t pos = S.ordered ? atomicAdd(&L.place[occ_bucket(ge.y)], 1u)
+                                       : (S.by_depth ? L.base + e : (L.prefix[ls] + j) / S.stride);
         if (pos < (uint32_t)OCC_MAX_CAND) {
             // write-through (agent-scope) stores: the barrier behind this phase then needs no release fence — which would write
             // back everything preprocess_kernel left dirty in this XCD's L2 (60 us measured)
@@ -304,10 +326,11 @@ __device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, flo
 constexpr int OCC_GROUP = 4;
 __device__ __forceinline__ void occ_cover_group(int blk0, int nb, const ViewParams& vp, int B, int nbx, uint32_t n,
                                                 const OccCand* cand, uint32_t (*s_b)[OCC_BUCKETS], uint32_t* s_wave,
-                                                uint32_t* s_cross, uint32_t* occ_cut, OccHeader* hdr) {
+                                                uint32_t* s_cross, uint32_t* s_tot, uint32_t* occ_cut, OccHeader* hdr,
+                                                bool ordered) {
     __syncthreads();                                    // (LDS of the previous group consumed)
     for (int k = threadIdx.x; k < nb * OCC_BUCKETS; k += OCC_THREADS) s_b[0][k] = 0u;
-    if (threadIdx.x < OCC_GROUP) s_cross[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x < OCC_GROUP) { s_cross[threadIdx.x] = 0xFFFFFFFFu; s_tot[threadIdx.x] = 0u; }
     __syncthreads();
     // the group's blocks, and the tile range that holds them all (a candidate whose rect misses it is done after four compares)
     int tx0[OCC_GROUP], ty0[OCC_GROUP], tx1[OCC_GROUP], ty1[OCC_GROUP];
@@ -332,12 +355,25 @@ __device__ __forceinline__ void occ_cover_group(int blk0, int nb, const ViewPara
         for (int j = 0; j < OCC_GROUP; ++j) {
             if (j >= nb) break;
             const uint32_t w = cover_weight(cc, x0[j], x1[j], y0[j], y1[j], tx0[j], tx1[j], ty0[j], ty1[j]);
-            if (w) atomicAdd(&s_b[j][bucket], w);
+            if (w) { atomicAdd(&s_b[j][bucket], w); if (ordered) atomicAdd(&s_tot[j], min(w, 0x00FFFFFFu)); }
         }
     };
-    const uint32_t rot = n ? (uint32_t)(((uint64_t)(uint32_t)blk0 * 2654435761ull) % n) : 0u;
+    // ordered: the records are in depth-bucket order (occ_gather_chunk) and the walk starts at the front and STOPS as soon as
+    // every block of the group has collected its 14.3 bits: every bucket in front of the one the last chunk ended in is then
+    // complete, and the crossing lies in one of them or in that last bucket itself — whose sum can only grow —, i.e. the
+    // prefix below finds the same bucket as after a full walk.  (A view full of opaque giants closes its blocks within the
+    // nearest few hundred of 32 768 records.)  Otherwise: any order, every group starts somewhere else.
+    const uint32_t rot = (n && !ordered) ? (uint32_t)(((uint64_t)(uint32_t)blk0 * 2654435761ull) % n) : 0u;
     constexpr int FLY = 4;
-    for (uint32_t c = threadIdx.x; c < n; c += FLY * OCC_THREADS) {
+    for (uint32_t c = threadIdx.x; c - threadIdx.x < n; c += FLY * OCC_THREADS) {
+        if (ordered && c != threadIdx.x) {              // (workgroup-uniform: c - threadIdx.x is)
+            __syncthreads();
+            bool done = true;
+            for (int j = 0; j < nb; ++j) done = done && s_tot[j] >= OCC_THRESHOLD;
+            __syncthreads();                            // (nobody adds to s_tot before everybody has read it)
+            if (done) break;
+        }
+        if (c >= n) continue;
         OccCand r[FLY];
 #pragma unroll
         for (int u = 0; u < FLY; ++u) {
@@ -483,7 +519,7 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
     __shared__ OccLds lds;
     __shared__ OccCand s_cand[OCC_SMALL];
     __shared__ uint8_t s_rank[OCC_SMALL];
-    __shared__ uint32_t s_w[16], s_ws[4], s_ok, s_cross[4], s_n, s_nz, s_nzq[OCC_SMALL];
+    __shared__ uint32_t s_w[16], s_ws[4], s_ok, s_cross[4], s_tot[4], s_n, s_nz, s_nzq[OCC_SMALL];
     const GeomLayout GL(P);
     OccHeader* hdr = reinterpret_cast<OccHeader*>(geom + GL.occ_hdr);
     uint32_t* hist = reinterpret_cast<uint32_t*>(geom + GL.occ_hdr + sizeof(OccHeader));
@@ -629,6 +665,7 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
         // (the depth histogram only decides WHICH candidates are kept when there are more than OCC_MAX_CAND: otherwise all are,
         //  and the first phase and its barrier are skipped — BASELINE C5: 10 751 candidates, 13 us)
         const bool all_kept = total <= (uint32_t)OCC_MAX_CAND;
+        bool ordered = false;                              // (workgroup-uniform, the same in every workgroup)
         if (!all_kept) {
             for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) occ_hist_chunk(c, heavy_list, heavy_count, n_slots, hist, lds.hist, s_w);
             if (!occ_grid_barrier<false>(hdr, 0, &s_ok)) return;              // (the histogram: atomics only)
@@ -637,7 +674,7 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
         }
         {
             OccSelect S;
-            if (all_kept) { S.total = total; S.limit = (uint32_t)(OCC_BUCKETS - 1); S.stride = 1u; S.keep_total = total; S.by_depth = true; }
+            if (all_kept) { S.total = total; S.limit = (uint32_t)(OCC_BUCKETS - 1); S.stride = 1u; S.keep_total = total; S.by_depth = true; S.ordered = false; }
             else S = occ_select(total, hist, lds.g);
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 __hip_atomic_store(&hdr->n_cand, S.by_depth ? (total <= (uint32_t)OCC_MAX_CAND ? total : S.keep_total)
@@ -645,7 +682,8 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
                 hdr->depth_limit = S.by_depth ? S.limit : 0xFFFFFFFFu;
             }
             for (int c = blockIdx.x; c < n_chunks; c += gridDim.x)
-                occ_gather_chunk(c, S, P, geom, heavy_list, heavy_count, n_slots, hdr, cand, lds.g);
+                occ_gather_chunk(c, S, P, geom, heavy_list, heavy_count, n_slots, hdr, cand, lds.g, hist + OCC_BUCKETS);
+            ordered = S.ordered;
         }
         if (!occ_grid_barrier<false>(hdr, 1, &s_ok)) return;              // (the candidate records: write-through stores)
         if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -656,7 +694,8 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
             const int per = max(1, min(OCC_GROUP, (n_blocks + (int)gridDim.x - 1) / (int)gridDim.x));
             const int n_groups = (n_blocks + per - 1) / per;
             for (int g = blockIdx.x; g < n_groups; g += gridDim.x)
-                occ_cover_group(g * per, min(per, n_blocks - g * per), vp, B, nbx, n, cand, lds.sums, s_w, s_cross, occ_cut, hdr);
+                occ_cover_group(g * per, min(per, n_blocks - g * per), vp, B, nbx, n, cand, lds.sums, s_w, s_cross, s_tot, occ_cut, hdr,
+                                ordered);
         }
     }
 
