@@ -865,7 +865,8 @@ def set_optimizer_in_backward(optimizer):
     their backward (include/msgs.h, msgs_adam_in_backward_t): the per-Gaussian backward kernel then applies the Adam update to
     the six leaf tensors and their moments itself, where it forms their gradients — the 236 bytes of gradient per Gaussian are
     neither written nor read back, the leaves receive no .grad — and `optimizer.take_step_in_backward(leaves)` is called once
-    per backward to advance the step counters and deliver the table (train_epilogue.FusedAdam implements it).  One view per
+    per backward to deliver the table, `optimizer.commit_step_in_backward(leaves)` behind the launch to advance the step
+    counters (train_epilogue.FusedAdam implements both).  One view per
     optimizer step, as in the reference's loop (/root/reference/train.py:203-216, :416-418); not with a GradAccumulator or the
     factored SH gradient.  Bit-identical parameters and moments to backward + FusedAdam.step() (tests/test_train_step_gpu.py).
     Returns the previous one."""
@@ -964,6 +965,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                        geom.numel(), D, _ptr(binning), binning.numel(), _ptr(image),
                                        image.numel(), _ptr(dL), _ptr(scratch), scratch.numel(), C.byref(grads),
                                        _C.timer_ptr(), stream), "msgs_backward")
+            if adam is not None:
+                step_opt.commit_step_in_backward(ctx.leaves)
         if accum is not None or adam is not None:   # the leaf gradients live in the accumulator / were consumed by the step
             return (None, g_m2.view(m2_shape), None, None, None, None, None, None, None, None, None, None, None)
         return (g_xyz, g_m2.view(m2_shape), g_dc, g_rest, g_opac, g_scal, g_rot, None, None, None, None, None, None)

@@ -87,9 +87,10 @@ class FusedAdam(torch.optim.Optimizer):
     # ---- the step inside the rasterizer's backward (diff_gaussian_rasterization.set_optimizer_in_backward) ----
     def take_step_in_backward(self, leaves):
         """Called by the raw entry's backward with its six leaf tensors (xyz, features_dc, features_rest, opacity, scaling,
-        rotation): advances their step counters as step() would and returns the msgs_adam_in_backward_t table — the
-        per-Gaussian backward kernel then updates parameters and moments itself (include/msgs.h).  The six tensors must be
-        parameters of this optimizer with common betas / eps / step (the reference's setup, gaussian_model.py:235-248)."""
+        rotation): returns the msgs_adam_in_backward_t table of the step that step() would take next — the per-Gaussian
+        backward kernel then updates parameters and moments itself (include/msgs.h) — WITHOUT advancing the step counters:
+        the backward calls commit_step_in_backward(leaves) once the library has accepted the launch.  The six tensors must
+        be parameters of this optimizer with common betas / eps / step (the reference's setup, gaussian_model.py:235-248)."""
         group_of = {id(p): g for g in self.param_groups for p in g["params"]}
         table = _C.AdamInBackward()
         common = None
@@ -119,12 +120,15 @@ class FusedAdam(torch.optim.Optimizer):
                 raise ValueError(f"take_step_in_backward: the six tensors must share step / betas / eps, got {common} and {key}")
             table.t[k] = _C.AdamMoments(_ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), float(group["lr"]))
             keep.append((st["exp_avg"], st["exp_avg_sq"]))
-        for p in leaves:
-            self.state[p]["step"] += 1
         table.step, (table.beta1, table.beta2), table.eps = common[0], common[1], common[2]
         table._keep = keep
-        self.steps_in_backward = getattr(self, "steps_in_backward", 0) + 1
         return table
+
+    def commit_step_in_backward(self, leaves):
+        """the kernel that takes the step has been launched: advance the six tensors' step counters"""
+        for p in leaves:
+            self.state[p]["step"] += 1
+        self.steps_in_backward = getattr(self, "steps_in_backward", 0) + 1
 
 
 def update_training_stats(model, viewspace_points, radii, pixel_sizes, reso_lvl=0, *, base_mask=False,
