@@ -98,7 +98,10 @@ typedef struct msgs_view {
                                * shrinks is the work of emit / tile sort / ranges on instances nobody walks (BASELINE C5: 54.9 M
                                * instances, 4.35 M walked).  Needs binning >= msgs_binning_bytes_slab(D, W, H, fraction); ignored
                                * (single pass) with fewer than 2048 tiles, in deterministic mode, with fine blend granularity
-                               * forced, or when the buffers are too small.  0: single pass                                  */
+                               * forced, or when the buffers are too small.  0: single pass.  With the two-call form pass the
+                               * SAME value to msgs_forward_stage1: its scan then hands slab B's count the coarse screen-cell
+                               * range of every Gaussian in depth order; without them (stage 1 called with 0) slab B still gives
+                               * the same results but fetches every Gaussian's record to learn that it has nothing to add   */
     int32_t reserved1;        /* 0 */
     const float* bg;          /* [3]   device                                                        */
     const float* viewmatrix;  /* [16]  device; world_view_transform = W2C^T row-major (cameras.py:54) */
