@@ -31,7 +31,8 @@
 //     at which the product crosses;
 //   more: the phases of round 5 behind grid barriers — (only with more than OCC_MAX_CAND candidates: depth histogram of the
 //     candidates -- barrier -- keep the nearest OCC_MAX_CAND, whole depth buckets) gather the records (then: in depth-bucket
-//     order) -- barrier -- per group of up to four blocks of tiles: one walk over the records, bucketed sums of
+//     order; otherwise every candidate adds its weight to the TOTAL of the blocks in its rect on the way, and when no total
+//     reaches the threshold — BASELINE C5 — everybody leaves behind the next barrier) -- barrier -- per group of up to four blocks of tiles: one walk over the records, bucketed sums of
 //     -log2(1 - alpha_min), prefix, cut-off bucket; over depth-ordered records the walk stops when every block of the group has
 //     its 14.3 bits (the filters-off multi-scale model: 185 k heavy Gaussians, 32 k kept, closed within the nearest few hundred).
 // Then ONE more grid barrier, behind which every workgroup knows whether anything closed: if not (the rule), it leaves; if so,
@@ -159,7 +160,11 @@ __device__ __forceinline__ void occ_hist_chunk(int chunk, const uint32_t* __rest
 // chunk — the ORDER of the records is irrelevant, the cover sums are integers; the SET is deterministic) and gathers their
 // records.  When the nearest non-empty bucket alone holds more than fit (thousands of covers at one depth), every stride-th
 // candidate in index order is kept instead: positions by formula from all slot counts.
-struct OccSelect { uint32_t total, limit, stride, keep_total; bool by_depth, ordered; };
+struct OccSelect { uint32_t total, limit, stride, keep_total; bool by_depth, ordered, bound; };
+__device__ __forceinline__ uint32_t cover_weight(const OccCand& c, float x0, float x1, float y0, float y1, int tx0, int tx1,
+                                                 int ty0, int ty1);
+constexpr int OCC_BOUND_BLOCKS = 64;        // blocks a candidate adds its weight to while it is gathered (S.bound, below) ...
+constexpr int OCC_BOUND_WAVE_BLOCKS = 512;  // ... with its whole wave above that, and not at all beyond this (a flag instead)
 __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* hist, OccGatherLds& L) {
     // deepest bucket kappa with (candidates in buckets <= kappa) <= OCC_MAX_CAND; thread t owns PER consecutive buckets
     constexpr int PER = OCC_BUCKETS / OCC_THREADS;
@@ -187,6 +192,7 @@ __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* 
     S.limit = total <= (uint32_t)OCC_MAX_CAND ? (uint32_t)(OCC_BUCKETS - 1) : L.kappa;
     S.stride = S.by_depth ? 1u : (total + OCC_MAX_CAND - 1) / OCC_MAX_CAND;
     S.ordered = S.by_depth;      // a selection by depth places the records in depth-bucket order (occ_gather_chunk)
+    S.bound = false;
     __syncthreads();
     return S;
 }
@@ -194,7 +200,8 @@ __device__ __forceinline__ OccSelect occ_select(uint32_t total, const uint32_t* 
 __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, int P, const char* __restrict__ geom,
                                                  const uint32_t* __restrict__ heavy_list,
                                                  const uint32_t* __restrict__ heavy_count, int n_slots, OccHeader* hdr,
-                                                 OccCand* cand, OccGatherLds& L, uint32_t* __restrict__ fill) {
+                                                 OccCand* cand, OccGatherLds& L, uint32_t* __restrict__ fill,
+                                                 const ViewParams& vp, int lb, int nbx) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int slot0 = chunk * OCC_GATHER_SLOTS;
     const int slot = slot0 + threadIdx.x;
@@ -257,12 +264,16 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
     const GeomLayout GL(P);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + GL.binrec);
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom + GL.rec);
-    for (uint32_t e = threadIdx.x; e < kept_total; e += OCC_THREADS) {
+    for (uint32_t e = threadIdx.x; e - threadIdx.x < kept_total; e += OCC_THREADS) {       // (workgroup-uniform trip count)
+        OccCand c;
+        c.c0 = c.c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        c.rect_lo = c.rect_hi = c.pad0 = c.pad1 = 0u;
+        bool big = false;
+        if (e < kept_total) {
         const uint32_t code = L.kept[e];
         const uint32_t ls = code >> 6, j = code & 63u;
         const uint2 ge = ent[(size_t)(slot0 + ls) * 64 + j];
         const BinRec b = binrec[ge.x];
-        OccCand c;
         c.c0 = b.q0;                                                                  // px, py, kA, kB(half)
         c.c1 = make_float4(b.q1.x, rec[ge.x].r1.y, __uint_as_float(ge.y), __uint_as_float(ge.x));   // kC, log2 o, depth key, id
         c.rect_lo = __float_as_uint(b.q1.z);                                          // minx | miny << 16   (tiles)
@@ -277,6 +288,60 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
             const uint64_t* w = reinterpret_cast<const uint64_t*>(&c);
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(OccCand) / 8); ++k) __hip_atomic_store(d + k, w[k], OCC_RLX_AGENT);
+        }
+        if (S.bound) {
+            // every candidate is kept (at most OCC_MAX_CAND of them) and nobody needs the fill counters: while its record is in
+            // registers the candidate adds its weight to the TOTAL of every block inside its rect — the same integer
+            // cover_weight the cover phase would add to one of the block's buckets.  If afterwards no total reaches the 14.3
+            // bits, no block can close and the cover phase — a walk over all records per group of blocks, 60 us at BASELINE C5,
+            // whose 10 751 mid-sized candidates close nothing — is skipped.  (A rect of more than OCC_BOUND_BLOCKS blocks: below.)
+            const int B = 1 << lb;
+            const int minx = (int)(c.rect_lo & 0xFFFFu), miny = (int)(c.rect_lo >> 16);
+            const int maxx = (int)(c.rect_hi & 0xFFFFu), maxy = (int)(c.rect_hi >> 16);
+            const int bx0 = minx >> lb, bx1 = (maxx - 1) >> lb, by0 = miny >> lb, by1 = (maxy - 1) >> lb;
+            big = (bx1 - bx0 + 1) * (by1 - by0 + 1) > OCC_BOUND_BLOCKS;
+            if (!big) {
+                for (int by = by0; by <= by1; ++by)
+                    for (int bx = bx0; bx <= bx1; ++bx) {
+                        const int tx0 = bx * B, ty0 = by * B;
+                        const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
+                        const uint32_t w = cover_weight(c, (float)(tx0 * TILE), (float)(min(tx1 * TILE, vp.W) - 1), (float)(ty0 * TILE),
+                                                        (float)(min(ty1 * TILE, vp.H) - 1), tx0, tx1, ty0, ty1);
+                        if (w) atomicAdd(&fill[by * nbx + bx], w);
+                    }
+            }
+        }
+        }
+        // ... and a candidate with a larger rect is taken by its whole wave, lanes on the blocks of the rect
+        if (S.bound) {
+            uint64_t bm = __ballot(big);
+            while (bm) {
+                const int src = __ffsll((long long)bm) - 1;
+                bm &= bm - 1;
+                OccCand g;
+                g.c0 = make_float4(__shfl(c.c0.x, src), __shfl(c.c0.y, src), __shfl(c.c0.z, src), __shfl(c.c0.w, src));
+                g.c1 = make_float4(__shfl(c.c1.x, src), __shfl(c.c1.y, src), __shfl(c.c1.z, src), __shfl(c.c1.w, src));
+                g.rect_lo = (uint32_t)__shfl((int)c.rect_lo, src);
+                g.rect_hi = (uint32_t)__shfl((int)c.rect_hi, src);
+                g.pad0 = g.pad1 = 0u;
+                const int B = 1 << lb;
+                const int minx = (int)(g.rect_lo & 0xFFFFu), miny = (int)(g.rect_lo >> 16);
+                const int maxx = (int)(g.rect_hi & 0xFFFFu), maxy = (int)(g.rect_hi >> 16);
+                const int bx0 = minx >> lb, bx1 = (maxx - 1) >> lb, by0 = miny >> lb, by1 = (maxy - 1) >> lb;
+                const int nbw = bx1 - bx0 + 1, nblk = nbw * (by1 - by0 + 1);
+                if (nblk > OCC_BOUND_WAVE_BLOCKS) {     // a giant: where there are such, blocks do close — the cover phase decides
+                    if (lane == 0) __hip_atomic_store(&hdr->pad[0], 1u, OCC_RLX_AGENT);
+                    continue;
+                }
+                for (int q = lane; q < nblk; q += 64) {
+                    const int bx = bx0 + q % nbw, by = by0 + q / nbw;
+                    const int tx0 = bx * B, ty0 = by * B;
+                    const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
+                    const uint32_t w = cover_weight(g, (float)(tx0 * TILE), (float)(min(tx1 * TILE, vp.W) - 1), (float)(ty0 * TILE),
+                                                    (float)(min(ty1 * TILE, vp.H) - 1), tx0, tx1, ty0, ty1);
+                    if (w) atomicAdd(&fill[by * nbx + bx], w);
+                }
+            }
         }
     }
     __syncthreads();
@@ -674,7 +739,10 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
         }
         {
             OccSelect S;
-            if (all_kept) { S.total = total; S.limit = (uint32_t)(OCC_BUCKETS - 1); S.stride = 1u; S.keep_total = total; S.by_depth = true; S.ordered = false; }
+            if (all_kept) {
+                S.total = total; S.limit = (uint32_t)(OCC_BUCKETS - 1); S.stride = 1u; S.keep_total = total; S.by_depth = true;
+                S.ordered = false; S.bound = true;
+            }
             else S = occ_select(total, hist, lds.g);
             if (blockIdx.x == 0 && threadIdx.x == 0) {
                 __hip_atomic_store(&hdr->n_cand, S.by_depth ? (total <= (uint32_t)OCC_MAX_CAND ? total : S.keep_total)
@@ -682,12 +750,24 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
                 hdr->depth_limit = S.by_depth ? S.limit : 0xFFFFFFFFu;
             }
             for (int c = blockIdx.x; c < n_chunks; c += gridDim.x)
-                occ_gather_chunk(c, S, P, geom, heavy_list, heavy_count, n_slots, hdr, cand, lds.g, hist + OCC_BUCKETS);
+                occ_gather_chunk(c, S, P, geom, heavy_list, heavy_count, n_slots, hdr, cand, lds.g, hist + OCC_BUCKETS, vp, block_log2, nbx);
             ordered = S.ordered;
         }
         if (!occ_grid_barrier<false>(hdr, 1, &s_ok)) return;              // (the candidate records: write-through stores)
         if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
+        if (all_kept) {
+            // the blocks' total weights came with the gather (S.bound): can anything close at all?  Every workgroup reads the
+            // same final values and takes the same decision; "no" leaves any_closed = 0 and the table unread
+            const uint32_t* tot = hist + OCC_BUCKETS;
+            uint32_t mx = 0;
+            for (int q = threadIdx.x; q < n_blocks; q += OCC_THREADS) mx = max(mx, __hip_atomic_load(&tot[q], OCC_RLX_AGENT));
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+            if (lane == 0) s_w[8 + wv] = mx;
+            __syncthreads();
+            mx = max(max(s_w[8], s_w[9]), max(s_w[10], s_w[11]));
+            if (__hip_atomic_load(&hdr->pad[0], OCC_RLX_AGENT) == 0u && mx < OCC_THRESHOLD) return;
+        }
         {
             const uint32_t n = min(__hip_atomic_load(&hdr->n_cand, OCC_RLX_AGENT), (uint32_t)OCC_MAX_CAND);
             // groups of consecutive blocks: as large as keeps every workgroup busy (1080p, 510 blocks: two; 4K, 2040 blocks: four)
