@@ -260,6 +260,11 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
     } else {
         for (uint32_t g = g0; g < first + cnt; g += S.stride) L.kept[at++] = (uint16_t)((threadIdx.x << 6) | (g - first));
     }
+    // S.bound: the chunk's contributions to the blocks' total weights are summed in LDS (L.place is free: no ordered placement)
+    // and flushed with one atomic per non-zero block — thousands of candidates that each cover most of a dozen blocks (the
+    // filters-off model at 240 x 135: 2.4 ms of atomics on twelve words when every candidate added to global memory itself)
+    if (S.bound)
+        for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) L.place[k] = 0u;
     __syncthreads();
     const GeomLayout GL(P);
     const BinRec* binrec = reinterpret_cast<const BinRec*>(geom + GL.binrec);
@@ -307,7 +312,7 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
                         const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
                         const uint32_t w = cover_weight(c, (float)(tx0 * TILE), (float)(min(tx1 * TILE, vp.W) - 1), (float)(ty0 * TILE),
                                                         (float)(min(ty1 * TILE, vp.H) - 1), tx0, tx1, ty0, ty1);
-                        if (w) atomicAdd(&fill[by * nbx + bx], w);
+                        if (w) atomicAdd(&L.place[by * nbx + bx], w);
                     }
             }
         }
@@ -339,12 +344,17 @@ __device__ __forceinline__ void occ_gather_chunk(int chunk, const OccSelect& S, 
                     const int tx1 = min(tx0 + B, vp.gx), ty1 = min(ty0 + B, vp.gy);
                     const uint32_t w = cover_weight(g, (float)(tx0 * TILE), (float)(min(tx1 * TILE, vp.W) - 1), (float)(ty0 * TILE),
                                                     (float)(min(ty1 * TILE, vp.H) - 1), tx0, tx1, ty0, ty1);
-                    if (w) atomicAdd(&fill[by * nbx + bx], w);
+                    if (w) atomicAdd(&L.place[by * nbx + bx], w);
                 }
             }
         }
     }
     __syncthreads();
+    if (S.bound)
+        for (int k = threadIdx.x; k < OCC_BUCKETS; k += OCC_THREADS) {
+            const uint32_t w = L.place[k];
+            if (w) atomicAdd(&fill[k], w);
+        }
     (void)dummy;
 }
 
@@ -729,7 +739,10 @@ __global__ __launch_bounds__(OCC_THREADS) void occ_pass_kernel(ViewParams vp, in
             __hip_atomic_store(&occ_cut[q], 0xFFFFu, OCC_RLX_AGENT);
         // (the depth histogram only decides WHICH candidates are kept when there are more than OCC_MAX_CAND: otherwise all are,
         //  and the first phase and its barrier are skipped — BASELINE C5: 10 751 candidates, 13 us)
-        const bool all_kept = total <= (uint32_t)OCC_MAX_CAND;
+        // (... and is only skipped while "nothing closes" is plausible — at most 16 candidates per block; a block needs at least
+        //  three covers, in practice dozens: BASELINE C5 has 5 per block.  A dense view — the filters-off model at 240 x 135:
+        //  2500 per block — takes the histogram and with it the depth-ordered records and the early-stopping cover walk)
+        const bool all_kept = total <= (uint32_t)OCC_MAX_CAND && total <= 16u * (uint32_t)n_blocks;
         bool ordered = false;                              // (workgroup-uniform, the same in every workgroup)
         if (!all_kept) {
             for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) occ_hist_chunk(c, heavy_list, heavy_count, n_slots, hist, lds.hist, s_w);
